@@ -1,0 +1,256 @@
+"""Deterministic Groth16 key / witness synthesiser (snarkjs `.zkey` / `.wtns` writers).
+
+No circom / snarkjs / ptau download is available offline, so the benchmark inputs
+(`/root/reference/benchmark/<N>/circuit.circom:3-23`, input `{"a":"3"}`) are regenerated here from
+a known-toxic-waste setup.  The files follow the snarkjs container the reference reads
+(src/file_wrapper.rs:45-103, src/zkey.rs:47-85, src/cache.rs:126-181):
+
+  zkey: sec1 protocol=1 | sec2 header (n8q q n8r r n_vars n_public domain α₁ β₁ β₂ γ₂ δ₁ δ₂)
+        sec3 IC | sec4 coefficients {m:u32 c:u32 s:u32 value·R² (32 B)} | sec5 A | sec6 B1 | sec7 B2
+        sec8 C | sec9 H | sec10 contributions (empty);  all coordinates Montgomery form, LE.
+  wtns: sec1 n8 q n_witness | sec2 witness (standard form, LE)
+
+Section-9 basis (SURVEY.md §8 a-H): with g = ω_{2n}, Z(x) = xⁿ − 1 the prover's H scalars are
+d_j = (A·B − C)(g·ωʲ) = −2·h(g·ωʲ), hence H_j = [ L_j(τ/g) · Z(τ) / (−2δ) ]₁ with L_j the Lagrange
+basis of the size-n domain.
+
+The elliptic-curve work (many fixed-base scalar multiplications) is delegated to a caller-supplied
+``fixed_base_mul(group, scalars_u64[n,4]) -> affine_u64[n,2|4,4]`` (standard form): tests pass the CPU
+oracle's, bench.py passes the HIP library's.  This module itself is pure Python/numpy.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+# fp_config::rou, primitive 2^28-th root (icicle/include/icicle/fields/snark_fields/bn254_scalar.h:68-69)
+ROU_28 = 0x2A3C09F0A58A7E8500E0A7EB8EF62ABC402D111E41112ED49BD61B6E725B19F0
+MONT_R = 1 << 256
+SEED = 0x1C1C1E
+
+
+def omega(logn: int) -> int:
+    w = ROU_28
+    for _ in range(28 - logn):
+        w = w * w % R_MOD
+    return w
+
+
+def ints_to_arr(xs) -> np.ndarray:
+    return np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in xs), dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def arr_to_ints(a: np.ndarray):
+    raw = np.ascontiguousarray(a).view(np.uint8).reshape(-1, 32)
+    return [int.from_bytes(r.tobytes(), "little") for r in raw]
+
+
+class _Prng:
+    """splitmix64-based deterministic stream of field elements (documented seed 0x1c1c1e)."""
+
+    def __init__(self, seed: int):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def u64(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    def fr(self) -> int:
+        v = 0
+        for _ in range(4):
+            v = (v << 64) | self.u64()
+        return v % R_MOD or 1
+
+
+@dataclass
+class R1CS:
+    """Sparse R1CS: lists of (constraint, wire, value) per matrix. Wire 0 is the constant 1,
+    wires 1..n_public are the public signals."""
+    n_vars: int
+    n_public: int
+    n_constraints: int
+    A: list = field(default_factory=list)
+    B: list = field(default_factory=list)
+    C: list = field(default_factory=list)
+
+
+def squaring_chain(N: int, a: int = 3):
+    """benchmark/<N>/circuit.circom:3-23 after circom's linear simplification:
+    wires [1, c(=b[N-1]), a, b[0..N-2]], constraint j: prev·prev = cur."""
+    r = R1CS(n_vars=N + 2, n_public=1, n_constraints=N)
+    w = [0] * (N + 2)
+    w[0], w[2] = 1, a % R_MOD
+    prev_wire, prev_val = 2, w[2]
+    for j in range(N):
+        cur_wire = 3 + j if j < N - 1 else 1
+        cur_val = prev_val * prev_val % R_MOD
+        w[cur_wire] = cur_val
+        r.A.append((j, prev_wire, 1))
+        r.B.append((j, prev_wire, 1))
+        r.C.append((j, cur_wire, 1))
+        prev_wire, prev_val = cur_wire, cur_val
+    return r, w
+
+
+def random_circuit(n_constraints: int, n_public: int, n_inputs: int, bit_fraction: float = 0.7,
+                   a_terms: int = 3, b_terms: int = 2, seed: int = 7):
+    """Synthetic stand-in for the real RSA/SHA-heavy circuits (anon_aadhaar / keyless are not
+    buildable offline): random sparse A, B rows over earlier wires, every constraint defines one fresh
+    wire through C, a `bit_fraction` of constraints are booleanity-style (w·(w−1)=0 ⇒ wire ∈ {0,1})
+    so that the witness is dominated by 0/1 values like real circuits."""
+    rng = np.random.default_rng(seed)
+    pr = _Prng(seed)
+    n_vars = 1 + n_public + n_inputs + n_constraints
+    r = R1CS(n_vars=n_vars, n_public=n_public, n_constraints=n_constraints)
+    w = [0] * n_vars
+    w[0] = 1
+    first_free = 1 + n_public + n_inputs
+    for i in range(1, first_free):
+        w[i] = int(rng.integers(0, 2)) if rng.random() < bit_fraction else pr.fr()
+    for j in range(n_constraints):
+        out = first_free + j
+        if rng.random() < bit_fraction:
+            # out = x AND y for two earlier bit-ish wires:  x · y = out  (stays in {0,1} when inputs are bits)
+            x, y = (int(v) for v in rng.integers(1, out, size=2))
+            r.A.append((j, x, 1)); r.B.append((j, y, 1)); r.C.append((j, out, 1))
+            w[out] = w[x] * w[y] % R_MOD
+        else:
+            sa, sb = 0, 0
+            for x in rng.integers(0, out, size=a_terms):
+                v = int(rng.integers(1, 1 << 16)); r.A.append((j, int(x), v)); sa += v * w[int(x)]
+            for x in rng.integers(0, out, size=b_terms):
+                v = int(rng.integers(1, 1 << 16)); r.B.append((j, int(x), v)); sb += v * w[int(x)]
+            r.C.append((j, out, 1))
+            w[out] = (sa % R_MOD) * (sb % R_MOD) % R_MOD
+    # public signals: expose the last wires' values by aliasing  pub_i · 1 = wire  is not needed for a
+    # stand-in; publics are free inputs already assigned above.
+    return r, w
+
+
+def _batch_inverse(xs):
+    n = len(xs)
+    pref = [1] * (n + 1)
+    for i, x in enumerate(xs):
+        pref[i + 1] = pref[i] * x % R_MOD
+    inv = pow(pref[n], -1, R_MOD)
+    out = [0] * n
+    for i in range(n - 1, -1, -1):
+        out[i] = pref[i] * inv % R_MOD
+        inv = inv * xs[i] % R_MOD
+    return out
+
+
+def lagrange_at(n: int, logn: int, y: int):
+    """[L_j(y)]_j for the size-n domain: L_j(y) = ωʲ (yⁿ − 1) / (n (y − ωʲ))."""
+    w = omega(logn)
+    ws = [1] * n
+    for j in range(1, n):
+        ws[j] = ws[j - 1] * w % R_MOD
+    dinv = _batch_inverse([(y - wj) % R_MOD for wj in ws])
+    c = (pow(y, n, R_MOD) - 1) * pow(n, -1, R_MOD) % R_MOD
+    return [ws[j] * c % R_MOD * dinv[j] % R_MOD for j in range(n)]
+
+
+def _section(sid: int, payload: bytes) -> bytes:
+    return struct.pack("<IQ", sid, len(payload)) + payload
+
+
+def _mont_fq_bytes(aff: np.ndarray) -> bytes:
+    """affine standard-form coordinates → Montgomery form bytes (pure Python; small arrays only)."""
+    return b"".join((v * MONT_R % Q_MOD).to_bytes(32, "little") for v in arr_to_ints(aff))
+
+
+def write_wtns(witness) -> bytes:
+    hdr = struct.pack("<I", 32) + R_MOD.to_bytes(32, "little") + struct.pack("<I", len(witness))
+    body = b"".join(int(x).to_bytes(32, "little") for x in witness)
+    return b"wtns" + struct.pack("<II", 2, 2) + _section(1, hdr) + _section(2, body)
+
+
+def setup(r1cs: R1CS, fixed_base_mul, points_to_mont=None, seed: int = SEED):
+    """Groth16 setup with toxic waste (τ, α, β, γ, δ) = first five outputs of the fixed-seed PRNG.
+    Returns (zkey_bytes, vk dict with standard-form affine numpy points).
+
+    points_to_mont(arr_u64[..., 4]) -> same shape: optional fast Fq std→Montgomery converter for the big
+    point arrays (the HIP library's or the oracle's); defaults to pure Python."""
+    pr = _Prng(seed)
+    tau, alpha, beta, gamma, delta = (pr.fr() for _ in range(5))
+    m, npub, nc = r1cs.n_vars, r1cs.n_public, r1cs.n_constraints
+    n = 1
+    while n < nc + npub + 1:
+        n <<= 1
+    logn = n.bit_length() - 1
+    L = lagrange_at(n, logn, tau)
+    a_tau, b_tau, c_tau = [0] * m, [0] * m, [0] * m
+    coeffs = []  # (m, c, s, value)
+    for (j, i, v) in r1cs.A:
+        a_tau[i] = (a_tau[i] + v * L[j]) % R_MOD
+        coeffs.append((0, j, i, v))
+    for (j, i, v) in r1cs.B:
+        b_tau[i] = (b_tau[i] + v * L[j]) % R_MOD
+        coeffs.append((1, j, i, v))
+    for (j, i, v) in r1cs.C:
+        c_tau[i] = (c_tau[i] + v * L[j]) % R_MOD
+    for s in range(npub + 1):  # snarkjs' extra rows binding the public inputs (A only)
+        a_tau[s] = (a_tau[s] + L[nc + s]) % R_MOD
+        coeffs.append((0, nc + s, s, 1))
+    dinv, ginv = pow(delta, -1, R_MOD), pow(gamma, -1, R_MOD)
+    comb = [(beta * a_tau[i] + alpha * b_tau[i] + c_tau[i]) % R_MOD for i in range(m)]
+    ic_s = [comb[i] * ginv % R_MOD for i in range(npub + 1)]
+    c_s = [comb[i] * dinv % R_MOD for i in range(npub + 1, m)]
+    # H basis
+    g = omega(logn + 1)
+    Lc = lagrange_at(n, logn, tau * pow(g, -1, R_MOD) % R_MOD)
+    zt = (pow(tau, n, R_MOD) - 1) * pow((-2 * delta) % R_MOD, -1, R_MOD) % R_MOD
+    h_s = [x * zt % R_MOD for x in Lc]
+
+    # one fixed-base batch for G1, one for G2
+    g1_scalars = [alpha, beta, delta] + ic_s + a_tau + b_tau + c_s + h_s
+    g1 = fixed_base_mul("g1", ints_to_arr(g1_scalars))
+    g2 = fixed_base_mul("g2", ints_to_arr([beta, gamma, delta] + b_tau))
+    o = 0
+    vk_alpha_1, vk_beta_1, vk_delta_1 = g1[0], g1[1], g1[2]; o = 3
+    IC = g1[o:o + npub + 1]; o += npub + 1
+    A = g1[o:o + m]; o += m
+    B1 = g1[o:o + m]; o += m
+    Cp = g1[o:o + m - npub - 1]; o += m - npub - 1
+    H = g1[o:o + n]
+    vk_beta_2, vk_gamma_2, vk_delta_2 = g2[0], g2[1], g2[2]
+    B2 = g2[3:]
+
+    if points_to_mont is None:
+        def points_to_mont(arr):
+            flat = arr_to_ints(arr.reshape(-1, 4))
+            return ints_to_arr([v * MONT_R % Q_MOD for v in flat]).reshape(arr.shape)
+    pm = lambda arr: np.ascontiguousarray(points_to_mont(np.ascontiguousarray(arr))).tobytes()
+
+    hdr = struct.pack("<I", 32) + Q_MOD.to_bytes(32, "little") + struct.pack("<I", 32) + R_MOD.to_bytes(32, "little")
+    hdr += struct.pack("<III", m, npub, n)
+    hdr += pm(vk_alpha_1) + pm(vk_beta_1) + pm(vk_beta_2) + pm(vk_gamma_2) + pm(vk_delta_1) + pm(vk_delta_2)
+    R2 = MONT_R * MONT_R % R_MOD
+    rec = np.zeros((len(coeffs), 44), dtype=np.uint8)
+    mcs = np.array([(c[0], c[1], c[2]) for c in coeffs], dtype=np.uint32)
+    rec[:, 0:12] = mcs.view(np.uint8).reshape(-1, 12)
+    cache = {}
+    vals = bytearray()
+    for c in coeffs:
+        v = c[3]
+        if v not in cache:
+            cache[v] = (v * R2 % R_MOD).to_bytes(32, "little")
+        vals += cache[v]
+    rec[:, 12:44] = np.frombuffer(bytes(vals), dtype=np.uint8).reshape(-1, 32)
+    sec4 = struct.pack("<I", len(coeffs)) + rec.tobytes()
+
+    body = _section(1, struct.pack("<I", 1)) + _section(2, hdr) + _section(3, pm(IC)) + _section(4, sec4)
+    body += _section(5, pm(A)) + _section(6, pm(B1)) + _section(7, pm(B2)) + _section(8, pm(Cp)) + _section(9, pm(H))
+    body += _section(10, struct.pack("<I", 0))
+    zkey = b"zkey" + struct.pack("<II", 1, 10) + body
+    vk = dict(vk_alpha_1=vk_alpha_1, vk_beta_2=vk_beta_2, vk_gamma_2=vk_gamma_2, vk_delta_2=vk_delta_2,
+              IC=[IC[i] for i in range(npub + 1)], n_public=npub)
+    return zkey, vk
