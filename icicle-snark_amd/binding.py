@@ -1,1 +1,407 @@
-"""placeholder — replaced by the ctypes mirror of include/icicle_snark_hip.h"""
+"""ctypes mirror of include/icicle_snark_hip.h (the reference's extern "C" surface for the Groth16 path).
+
+Names follow the reference's Rust wrappers so that tests read like theirs:
+``msm`` (icicle-core/src/msm/mod.rs:106-154), ``ntt`` / ``initialize_domain`` / ``release_domain`` /
+``get_root_of_unity`` (ntt/mod.rs:202-216,290-305), ``mul_scalars`` / ``sub_scalars`` / ``add_scalars``
+(vec_ops/mod.rs:233-245), ``from_mont`` / ``to_mont`` (field.rs:379-398, curve.rs:140-154), ``DeviceVec``
+(icicle-runtime/src/memory.rs), ``IcicleStream`` (stream.rs).
+
+There is NO fallback of any kind here: if the shared library is missing or no HIP device is present the
+calls raise.  Arrays are numpy uint64 with a trailing dimension of 4 (32-byte little-endian elements).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libicicle_snark_hip.so")
+
+SUCCESS = 0
+ERRORS = ["SUCCESS", "INVALID_DEVICE", "OUT_OF_MEMORY", "INVALID_POINTER", "ALLOCATION_FAILED", "DEALLOCATION_FAILED",
+          "COPY_FAILED", "SYNCHRONIZATION_FAILED", "STREAM_CREATION_FAILED", "STREAM_DESTRUCTION_FAILED",
+          "API_NOT_IMPLEMENTED", "INVALID_ARGUMENT", "BACKEND_LOAD_FAILED", "LICENSE_CHECK_ERROR", "UNKNOWN_ERROR"]
+
+
+class IcicleError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        name = ERRORS[code] if 0 <= code < len(ERRORS) else str(code)
+        super().__init__(f"eIcicleError::{name} {what}".strip())
+
+
+class Device(C.Structure):
+    _fields_ = [("type", C.c_char * 64), ("id", C.c_int)]
+
+
+class MSMConfig(C.Structure):
+    _fields_ = [("stream", C.c_void_p), ("precompute_factor", C.c_int), ("c", C.c_int), ("bitsize", C.c_int),
+                ("batch_size", C.c_int), ("are_points_shared_in_batch", C.c_bool), ("are_scalars_on_device", C.c_bool),
+                ("are_scalars_montgomery_form", C.c_bool), ("are_points_on_device", C.c_bool),
+                ("are_points_montgomery_form", C.c_bool), ("are_results_on_device", C.c_bool), ("is_async", C.c_bool),
+                ("ext", C.c_void_p)]
+
+    @staticmethod
+    def default():
+        return MSMConfig(None, 1, 0, 0, 1, True, False, False, False, False, False, False, None)
+
+
+class NTTConfig(C.Structure):
+    _fields_ = [("stream", C.c_void_p), ("coset_gen", C.c_uint32 * 8), ("batch_size", C.c_int), ("columns_batch", C.c_bool),
+                ("ordering", C.c_int), ("are_inputs_on_device", C.c_bool), ("are_outputs_on_device", C.c_bool),
+                ("is_async", C.c_bool), ("ext", C.c_void_p)]
+
+    @staticmethod
+    def default():
+        one = (C.c_uint32 * 8)(1, 0, 0, 0, 0, 0, 0, 0)
+        return NTTConfig(None, one, 1, False, 0, False, False, False, None)
+
+
+class NTTInitDomainConfig(C.Structure):
+    _fields_ = [("stream", C.c_void_p), ("is_async", C.c_bool), ("ext", C.c_void_p)]
+
+
+class VecOpsConfig(C.Structure):
+    _fields_ = [("stream", C.c_void_p), ("is_a_on_device", C.c_bool), ("is_b_on_device", C.c_bool),
+                ("is_result_on_device", C.c_bool), ("is_async", C.c_bool), ("batch_size", C.c_int),
+                ("columns_batch", C.c_bool), ("ext", C.c_void_p)]
+
+    @staticmethod
+    def default():
+        return VecOpsConfig(None, False, False, False, False, 1, False, None)
+
+
+# every symbol include/icicle_snark_hip.h declares (checked by tests/test_abi.py)
+DECLARED_SYMBOLS = """
+icicle_load_backend icicle_load_backend_from_env_or_default icicle_set_device icicle_set_default_device
+icicle_get_active_device icicle_is_host_memory icicle_is_active_device_memory icicle_get_device_count
+icicle_is_device_available icicle_get_registered_devices icicle_malloc icicle_malloc_async icicle_free icicle_free_async
+icicle_get_available_memory icicle_memset icicle_memset_async icicle_copy icicle_copy_async icicle_copy_to_host
+icicle_copy_to_host_async icicle_copy_to_device icicle_copy_to_device_async icicle_create_stream icicle_destroy_stream
+icicle_stream_synchronize icicle_device_synchronize
+create_config_extension destroy_config_extension config_extension_set_int config_extension_set_bool
+config_extension_get_int config_extension_get_bool clone_config_extension
+bn254_generate_scalars bn254_add bn254_sub bn254_mul bn254_inv bn254_pow bn254_from_u32
+bn254_eq bn254_ecadd bn254_ecsub bn254_mul_scalar bn254_to_affine bn254_from_affine bn254_generator bn254_is_on_curve
+bn254_base_field_from_u32 bn254_g2_eq bn254_g2_ecadd bn254_g2_ecsub bn254_g2_mul_scalar bn254_g2_to_affine
+bn254_g2_from_affine bn254_g2_generator bn254_g2_is_on_curve bn254_g2_base_field_from_u32
+bn254_vector_add bn254_vector_sub bn254_vector_mul bn254_scalar_convert_montgomery
+bn254_affine_convert_montgomery bn254_g2_affine_convert_montgomery
+bn254_ntt bn254_ntt_init_domain bn254_ntt_release_domain bn254_get_root_of_unity bn254_get_root_of_unity_from_domain
+bn254_msm bn254_g2_msm
+icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
+""".split()
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library. Raises if it has not been built — there is no Python/CPU substitute."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make` (hipcc --offload-arch=gfx950); "
+                              "this package has no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.icicle_snark_last_error.restype = C.c_char_p
+        for n in ("bn254_eq", "bn254_g2_eq", "bn254_is_on_curve", "bn254_g2_is_on_curve"):
+            getattr(_lib, n).restype = C.c_bool
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != SUCCESS:
+        msg = lib().icicle_snark_last_error()
+        raise IcicleError(rc, f"{what}: {msg.decode() if msg else ''}")
+
+
+def set_device(dev_type: str = "HIP", dev_id: int = 0):
+    """try_load_and_set_backend_device — src/lib.rs:25-31"""
+    if dev_type != "CPU":
+        check(lib().icicle_load_backend_from_env_or_default(), "load_backend")
+    d = Device(dev_type.encode(), dev_id)
+    check(lib().icicle_set_device(C.byref(d)), f"set_device({dev_type},{dev_id})")
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, DeviceVec):
+        return C.c_void_p(a.ptr)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    raise TypeError(type(a))
+
+
+def _on_dev(a):
+    return isinstance(a, (DeviceVec, int))
+
+
+class IcicleStream:
+    """icicle-runtime/src/stream.rs"""
+
+    def __init__(self, handle=None):
+        if handle is None:
+            h = C.c_void_p()
+            check(lib().icicle_create_stream(C.byref(h)), "create_stream")
+            self.handle, self._own = h.value, True
+        else:
+            self.handle, self._own = handle, False
+
+    def synchronize(self):
+        check(lib().icicle_stream_synchronize(C.c_void_p(self.handle)), "stream_synchronize")
+
+    def destroy(self):
+        if self._own and self.handle is not None:
+            check(lib().icicle_destroy_stream(C.c_void_p(self.handle)), "destroy_stream")
+            self.handle = None
+
+
+class DeviceVec:
+    """A device allocation of `nbytes` bytes (icicle-runtime/src/memory.rs:351-417). Slices share the parent."""
+
+    def __init__(self, nbytes: int, stream: IcicleStream | None = None, _ptr=None, _parent=None):
+        self.nbytes = nbytes
+        self._parent = _parent
+        if _ptr is not None:
+            self.ptr = _ptr
+            return
+        p = C.c_void_p()
+        if stream is None:
+            check(lib().icicle_malloc(C.byref(p), C.c_size_t(max(nbytes, 1))), "malloc")
+        else:
+            check(lib().icicle_malloc_async(C.byref(p), C.c_size_t(max(nbytes, 1)), C.c_void_p(stream.handle)), "malloc_async")
+        self.ptr = p.value
+
+    @staticmethod
+    def from_host(a: np.ndarray, stream: IcicleStream | None = None) -> "DeviceVec":
+        a = np.ascontiguousarray(a)
+        d = DeviceVec(a.nbytes, stream)
+        d.copy_from_host(a, stream)
+        return d
+
+    def slice(self, byte_off: int, nbytes: int) -> "DeviceVec":
+        assert 0 <= byte_off and byte_off + nbytes <= self.nbytes
+        return DeviceVec(nbytes, _ptr=self.ptr + byte_off, _parent=self)
+
+    def copy_from_host(self, a: np.ndarray, stream: IcicleStream | None = None):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        if stream is None:
+            check(lib().icicle_copy_to_device(C.c_void_p(self.ptr), _p(a), C.c_size_t(a.nbytes)), "copy_to_device")
+        else:
+            check(lib().icicle_copy_to_device_async(C.c_void_p(self.ptr), _p(a), C.c_size_t(a.nbytes), C.c_void_p(stream.handle)), "copy_to_device_async")
+
+    def to_host(self, shape, dtype=np.uint64, stream: IcicleStream | None = None) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        if stream is None:
+            check(lib().icicle_copy_to_host(_p(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)), "copy_to_host")
+        else:
+            check(lib().icicle_copy_to_host_async(_p(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), C.c_void_p(stream.handle)), "copy_to_host_async")
+            stream.synchronize()
+        return out
+
+    def free(self):
+        if self._parent is None and self.ptr:
+            check(lib().icicle_free(C.c_void_p(self.ptr)), "free")
+            self.ptr = 0
+
+
+# --------------------------------------------------------------------------------------------- vec ops
+def _vec_op(name, a, b, out, n, stream, is_async):
+    cfg = VecOpsConfig.default()
+    cfg.is_a_on_device, cfg.is_b_on_device, cfg.is_result_on_device = _on_dev(a), _on_dev(b), _on_dev(out)
+    cfg.is_async = is_async
+    cfg.stream = stream.handle if stream else None
+    check(getattr(lib(), name)(_p(a), _p(b), C.c_uint64(n), C.byref(cfg), _p(out)), name)
+
+
+def _n_of(a):
+    return a.size // 4 if isinstance(a, np.ndarray) else a.nbytes // 32
+
+
+def mul_scalars(a, b, out=None, stream=None, is_async=False):
+    if out is None:
+        out = np.empty_like(a)
+    _vec_op("bn254_vector_mul", a, b, out, _n_of(a), stream, is_async)
+    return out
+
+
+def sub_scalars(a, b, out=None, stream=None, is_async=False):
+    if out is None:
+        out = np.empty_like(a)
+    _vec_op("bn254_vector_sub", a, b, out, _n_of(a), stream, is_async)
+    return out
+
+
+def add_scalars(a, b, out=None, stream=None, is_async=False):
+    if out is None:
+        out = np.empty_like(a)
+    _vec_op("bn254_vector_add", a, b, out, _n_of(a), stream, is_async)
+    return out
+
+
+def scalar_convert_montgomery(a, to_mont: bool, out=None, stream=None, is_async=False):
+    if out is None:
+        out = np.empty_like(a) if isinstance(a, np.ndarray) else a
+    cfg = VecOpsConfig.default()
+    cfg.is_a_on_device, cfg.is_result_on_device = _on_dev(a), _on_dev(out)
+    cfg.is_async = is_async
+    cfg.stream = stream.handle if stream else None
+    check(lib().bn254_scalar_convert_montgomery(_p(a), C.c_uint64(_n_of(a)), C.c_bool(to_mont), C.byref(cfg), _p(out)), "scalar_convert_montgomery")
+    return out
+
+
+def affine_convert_montgomery(group: str, a, to_mont: bool, out=None, stream=None, is_async=False):
+    per = 64 if group == "g1" else 128
+    n = (a.nbytes if isinstance(a, (np.ndarray, DeviceVec)) else 0) // per
+    if out is None:
+        out = np.empty_like(a) if isinstance(a, np.ndarray) else a
+    cfg = VecOpsConfig.default()
+    cfg.is_a_on_device, cfg.is_result_on_device = _on_dev(a), _on_dev(out)
+    cfg.is_async = is_async
+    cfg.stream = stream.handle if stream else None
+    name = "bn254_affine_convert_montgomery" if group == "g1" else "bn254_g2_affine_convert_montgomery"
+    check(getattr(lib(), name)(_p(a), C.c_uint64(n), C.c_bool(to_mont), C.byref(cfg), _p(out)), name)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- NTT
+def get_root_of_unity(max_size: int) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib().bn254_get_root_of_unity(C.c_uint64(max_size), _p(out)), "get_root_of_unity")
+    return out
+
+
+def initialize_domain(root: np.ndarray, stream=None):
+    cfg = NTTInitDomainConfig(stream.handle if stream else None, False, None)
+    check(lib().bn254_ntt_init_domain(_p(np.ascontiguousarray(root)), C.byref(cfg)), "ntt_init_domain")
+
+
+def release_domain():
+    check(lib().bn254_ntt_release_domain(), "ntt_release_domain")
+
+
+def ntt(inp, inverse: bool, out=None, batch_size=1, size=None, stream=None, is_async=False, coset_gen=None, ordering=0):
+    if size is None:
+        size = _n_of(inp) // batch_size
+    if out is None:
+        out = np.empty_like(inp) if isinstance(inp, np.ndarray) else inp
+    cfg = NTTConfig.default()
+    cfg.batch_size = batch_size
+    cfg.are_inputs_on_device, cfg.are_outputs_on_device = _on_dev(inp), _on_dev(out)
+    cfg.is_async = is_async
+    cfg.ordering = ordering
+    cfg.stream = stream.handle if stream else None
+    if coset_gen is not None:
+        cg = np.ascontiguousarray(coset_gen, dtype=np.uint64).view(np.uint32)
+        for i in range(8):
+            cfg.coset_gen[i] = int(cg[i])
+    check(lib().bn254_ntt(_p(inp), C.c_int(size), C.c_int(1 if inverse else 0), C.byref(cfg), _p(out)), "ntt")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- MSM
+def msm(group: str, scalars, bases, out=None, stream=None, is_async=False, c=0, size=None,
+        scalars_mont=False, points_mont=False, ext=None):
+    """msm() — icicle-core/src/msm/mod.rs:106-154. Returns the projective result (3,4)/(6,4) u64 when `out` is None."""
+    if size is None:
+        size = _n_of(scalars)
+    host_out = out is None
+    if host_out:
+        out = np.zeros((3, 4) if group == "g1" else (6, 4), dtype=np.uint64)
+    cfg = MSMConfig.default()
+    cfg.c = c
+    cfg.are_scalars_on_device, cfg.are_points_on_device, cfg.are_results_on_device = _on_dev(scalars), _on_dev(bases), _on_dev(out)
+    cfg.are_scalars_montgomery_form, cfg.are_points_montgomery_form = scalars_mont, points_mont
+    cfg.is_async = is_async
+    cfg.stream = stream.handle if stream else None
+    cfg.ext = ext
+    name = "bn254_msm" if group == "g1" else "bn254_g2_msm"
+    check(getattr(lib(), name)(_p(scalars), _p(bases), C.c_int(size), C.byref(cfg), _p(out)), name)
+    return out
+
+
+def last_msm_timings():
+    out = (C.c_float * 4)()
+    check(lib().icicle_snark_last_msm_timings(out), "last_msm_timings")
+    return list(out)
+
+
+def generator_mul(group: str, scalars: np.ndarray) -> np.ndarray:
+    """out[i] = s[i]·G, affine standard form (extension; used by the zkey synthesiser)."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = scalars.shape[0]
+    dims = 2 if group == "g1" else 4
+    d_s = DeviceVec.from_host(scalars)
+    d_o = DeviceVec(n * dims * 32)
+    name = "icicle_snark_g1_generator_mul" if group == "g1" else "icicle_snark_g2_generator_mul"
+    check(getattr(lib(), name)(C.c_void_p(d_s.ptr), C.c_uint64(n), None, C.c_void_p(d_o.ptr)), name)
+    check(lib().icicle_device_synchronize(), "sync")
+    out = d_o.to_host((n, dims, 4))
+    d_s.free()
+    d_o.free()
+    return out
+
+
+# --------------------------------------------------------------------------------------------- host FFI
+def i2a(x):
+    return np.frombuffer(int(x).to_bytes(32, "little"), dtype=np.uint64).copy()
+
+
+def a2i(a):
+    return int.from_bytes(np.ascontiguousarray(a).tobytes(), "little")
+
+
+def fr_op(op: str, a: int, b: int) -> int:
+    out = np.zeros(4, dtype=np.uint64)
+    getattr(lib(), f"bn254_{op}")(_p(i2a(a)), _p(i2a(b)), _p(out))
+    return a2i(out)
+
+
+def fr_inv(a: int) -> int:
+    out = np.zeros(4, dtype=np.uint64)
+    lib().bn254_inv(_p(i2a(a)), _p(out))
+    return a2i(out)
+
+
+_PRE = {"g1": "bn254_", "g2": "bn254_g2_"}
+_DIMS = {"g1": (2, 3), "g2": (4, 6)}
+
+
+def ec(group: str, op: str, *args):
+    """host curve FFI: ecadd/ecsub(p,q), mul_scalar(p, int), to_affine(p), from_affine(a), generator()"""
+    f = getattr(lib(), _PRE[group] + op)
+    na, npj = _DIMS[group]
+    if op in ("ecadd", "ecsub"):
+        out = np.zeros((npj, 4), dtype=np.uint64)
+        f(_p(np.ascontiguousarray(args[0])), _p(np.ascontiguousarray(args[1])), _p(out))
+    elif op == "mul_scalar":
+        out = np.zeros((npj, 4), dtype=np.uint64)
+        f(_p(np.ascontiguousarray(args[0])), _p(i2a(args[1])), _p(out))
+    elif op == "to_affine":
+        out = np.zeros((na, 4), dtype=np.uint64)
+        f(_p(np.ascontiguousarray(args[0])), _p(out))
+    elif op == "from_affine":
+        out = np.zeros((npj, 4), dtype=np.uint64)
+        f(_p(np.ascontiguousarray(args[0])), _p(out))
+    elif op == "generator":
+        out = np.zeros((npj, 4), dtype=np.uint64)
+        f(_p(out))
+    else:
+        raise ValueError(op)
+    return out
+
+
+def ec_eq(group, a, b) -> bool:
+    return bool(getattr(lib(), _PRE[group] + "eq")(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b))))
+
+
+def ec_is_on_curve(group, a) -> bool:
+    return bool(getattr(lib(), _PRE[group] + "is_on_curve")(_p(np.ascontiguousarray(a))))

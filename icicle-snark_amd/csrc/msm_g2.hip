@@ -1,0 +1,21 @@
+// msm_g2.hip — G2 (Fq2 coordinates) instantiation of the MSM pipeline (see msm_impl.h).
+#include "msm_impl.h"
+
+ISNARK_API eIcicleError bn254_g2_msm(const bn254_scalar_t* scalars, const bn254_g2_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_g2_projective_t* results)
+{
+  return msm_impl<G2>(scalars, bases, msm_size, cfg, results);
+}
+ISNARK_API eIcicleError icicle_snark_g2_generator_mul(const bn254_scalar_t* s, uint64_t n, icicleStreamHandle stream, bn254_g2_affine_t* out)
+{
+  // icicle/include/icicle/curves/params/bn254.h:32-39
+  static const uint32_t xr[8] = {0xd992f6ed, 0x46debd5c, 0xf75edadd, 0x674322d4, 0x5e5c4479, 0x426a0066, 0x121f1e76, 0x1800deef};
+  static const uint32_t xi[8] = {0xaef312c2, 0x97e485b7, 0x35a9e712, 0xf1aa4933, 0x31fb5d25, 0x7260bfb7, 0x920d483a, 0x198e9393};
+  static const uint32_t yr[8] = {0x66fa7daa, 0x4ce6cc01, 0x0c43d37b, 0xe3d1e769, 0x8dcb408f, 0x4aab7180, 0xdb8c6deb, 0x12c85ea5};
+  static const uint32_t yi[8] = {0xd122975b, 0x55acdadc, 0x70b38ef3, 0xbc4b3133, 0x690c3395, 0xec9e99ad, 0x585ff075, 0x090689d0};
+  G2::A gen;
+  memcpy(gen.x.c0.l, xr, 32);
+  memcpy(gen.x.c1.l, xi, 32);
+  memcpy(gen.y.c0.l, yr, 32);
+  memcpy(gen.y.c1.l, yi, 32);
+  return generator_mul_impl<G2, Fq2Ops>(s, n, (hipStream_t)stream, out, gen);
+}

@@ -1,0 +1,442 @@
+// ntt.hip — NTT / iNTT over the BN254 scalar field for gfx950.
+//
+// Replaces icicle/backend/cuda/include/ntt/ntt.cuh (Domain :441-562, dispatch :661-758) and
+// icicle/backend/cuda/src/ntt/mixed_radix_ntt.cu behind bn254_ntt / bn254_ntt_init_domain /
+// bn254_ntt_release_domain / bn254_get_root_of_unity.
+//
+// Design (MI355X-first, not the reference's 64-thread register-tiled radix-16/32/64 plan):
+//  * a transform of size n = R1·R2[·R3] is 1–3 passes of a Cooley–Tukey decimation; each pass is a
+//    batch of size-R sub-transforms done entirely in LDS.  A workgroup owns a tile of R rows × C
+//    columns (R·C = 2048 elements = 64 KiB of the CU's 160 KiB LDS, two workgroups per CU), the
+//    C columns being C consecutive elements in memory, so global traffic is runs of C·32 B.
+//  * inside the tile: radix-2 DIF stages over the rows, one __syncthreads per stage; the tile is
+//    kept as two uint4 planes (limbs 0-3 / 4-7) so that consecutive lanes read consecutive 16-B
+//    LDS slots (no bank conflicts for ds_read_b128 / ds_write_b128).
+//  * the inter-pass twiddle ω_n^(k·t), the final 1/n of the inverse transform and the
+//    natural-order permutation are fused into the pass that produces the data — there is no
+//    separate digit-reverse or normalise pass (the reference runs both:
+//    mixed_radix_ntt.cu:61-126).
+//  * data stay in STANDARD form; twiddles are stored in Montgomery form, so one Montgomery
+//    multiply yields the standard-form product directly.
+//  * per element each pass reads 32 B and writes 32 B: 64·P bytes of HBM traffic per element
+//    (P = number of passes), the twiddle table (N·32 B) is L2/Infinity-Cache resident.
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+#include "common.h"
+#include "ff.h"
+
+using namespace bn254;
+using namespace isnark;
+
+namespace {
+
+constexpr int LOG_TILE = 11; // 2048 elements per workgroup
+constexpr int NT = 256;      // threads per workgroup
+constexpr int MAX_LOG_R = 9; // rows per tile ≤ 512 so that columns ≥ 4 (128-B runs)
+constexpr int OMEGAS_COUNT = 28;
+
+// fp_config::rou — primitive 2^28-th root of unity, standard form
+// (icicle/include/icicle/fields/snark_fields/bn254_scalar.h:68-69)
+const uint32_t ROU28[8] = {0x725b19f0, 0x9bd61b6e, 0x41112ed4, 0x402d111e, 0x8ef62abc, 0x00e0a7eb, 0xa58a7e85, 0x2a3c09f0};
+
+struct Domain {
+  fe* tw = nullptr; // tw[i] = root^i, Montgomery form, i in [0, N)
+  int log_n = -1;
+  fe root_std;
+  int device = -1;
+};
+std::mutex g_dom_mu;
+Domain g_dom;
+
+fe host_omega(int logn) // Fr::omega — modular_arithmetic.h:61-73 ; standard form in/out
+{
+  fe w;
+  memcpy(w.l, ROU28, 32);
+  w = Fr::to_mont(w);
+  for (int i = 0; i < OMEGAS_COUNT - logn; i++) w = Fr::sqr(w);
+  return Fr::from_mont(w);
+}
+
+__global__ void gen_twiddles_kernel(fe* tw, const fe* pw /* root^(2^j), Montgomery */, int log_n)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_n)) return;
+  fe acc = Fr::one_mont();
+  for (int j = 0; j < log_n; j++)
+    if ((i >> j) & 1) acc = Fr::mul(acc, pw[j]);
+  tw[i] = acc;
+}
+
+struct PassParams {
+  int log_r, log_c;
+  uint32_t tiles_per_group_log; // b -> b_hi = b >> log, b_lo = b & mask
+  uint64_t in_hi, in_lo, in_row, in_col;
+  uint64_t out_hi, out_lo, out_row, out_col;
+  uint32_t tw_mul;       // inter-pass twiddle exponent = k · (b_lo·C + c) · tw_mul ; 0 = none
+  uint32_t stage_stride; // ω_R^e = tw[e · stage_stride]
+  uint32_t n_mask;       // N − 1
+  int inverse;
+  int scale; // multiply by n^-1 (last pass of an inverse transform)
+  uint64_t batch_stride;
+  int load_rows_fastest; // global loads: consecutive threads walk rows (in_row == 1) instead of columns
+};
+
+__device__ __forceinline__ uint32_t tw_index(uint32_t e, uint32_t n_mask, int inverse)
+{
+  // ω^-e = ω^(N-e)
+  return inverse ? ((n_mask + 1 - e) & n_mask) : e;
+}
+
+__device__ __forceinline__ fe lds_get(const uint4* lo, const uint4* hi, int idx)
+{
+  uint4 a = lo[idx], b = hi[idx];
+  fe r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int idx, const fe& v)
+{
+  lo[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  hi[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ fe g_get(const fe* p)
+{
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  fe r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void g_put(fe* p, const fe& v)
+{
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// One pass: grid = (tiles, batch).  LDS: two uint4 planes of R·C entries + R/2 stage twiddles.
+__global__ __launch_bounds__(NT) void ntt_pass_kernel(const fe* __restrict__ in, fe* __restrict__ out, const fe* __restrict__ tw, PassParams p, fe ninv_mont)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int R = 1 << p.log_r, C = 1 << p.log_c, RC = R * C;
+  uint4* lo = reinterpret_cast<uint4*>(smem);
+  uint4* hi = lo + RC;
+  uint4* twlo = hi + RC; // R/2 entries
+  uint4* twhi = twlo + (R >> 1);
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t b_hi = b >> p.tiles_per_group_log, b_lo = b & ((1u << p.tiles_per_group_log) - 1);
+  const fe* src = in + (uint64_t)blockIdx.y * p.batch_stride + b_hi * p.in_hi + b_lo * p.in_lo;
+  fe* dst = out + (uint64_t)blockIdx.y * p.batch_stride + b_hi * p.out_hi + b_lo * p.out_lo;
+  const int tid = threadIdx.x;
+
+  // stage twiddles ω_R^e, e < R/2
+  for (int e = tid; e < (R >> 1); e += NT) {
+    fe w = g_get(tw + tw_index((uint32_t)e * p.stage_stride, p.n_mask, p.inverse));
+    lds_put(twlo, twhi, e, w);
+  }
+  // load tile: LDS index = r·C + c
+  for (int e = tid; e < RC; e += NT) {
+    int r, c;
+    if (p.load_rows_fastest) { r = e & (R - 1); c = e >> p.log_r; }
+    else { c = e & (C - 1); r = e >> p.log_c; }
+    fe v = g_get(src + (uint64_t)r * p.in_row + (uint64_t)c * p.in_col);
+    lds_put(lo, hi, (r << p.log_c) + c, v);
+  }
+  __syncthreads();
+
+  // radix-2 DIF stages over rows: natural order in → bit-reversed order out
+  const int nbf = RC >> 1;
+  for (int s = p.log_r - 1; s >= 0; s--) {
+    const int h = 1 << s; // half size
+    for (int q = tid; q < nbf; q += NT) {
+      const int c = q & (C - 1);
+      const int bf = q >> p.log_c;
+      const int j = bf & (h - 1);
+      const int i = ((bf >> s) << (s + 1)) + j;
+      const int ia = (i << p.log_c) + c, ib = ((i + h) << p.log_c) + c;
+      fe a = lds_get(lo, hi, ia), bb = lds_get(lo, hi, ib);
+      fe sum = Fr::add(a, bb);
+      fe dif = Fr::sub(a, bb);
+      const int e = j << (p.log_r - 1 - s);
+      if (e != 0) dif = Fr::mul(dif, lds_get(twlo, twhi, e));
+      lds_put(lo, hi, ia, sum);
+      lds_put(lo, hi, ib, dif);
+    }
+    __syncthreads();
+  }
+
+  // store: LDS row s holds k = bitrev(s)
+  for (int e = tid; e < RC; e += NT) {
+    const int c = e & (C - 1);
+    const int srow = e >> p.log_c;
+    const uint32_t k = __brev((uint32_t)srow) >> (32 - p.log_r);
+    fe v = lds_get(lo, hi, e);
+    if (p.tw_mul) {
+      const uint32_t t = (b_lo << p.log_c) + c;
+      const uint32_t ex = k * t * p.tw_mul;
+      if (ex) v = Fr::mul(v, g_get(tw + tw_index(ex, p.n_mask, p.inverse)));
+    }
+    if (p.scale) v = Fr::mul(v, ninv_mont);
+    g_put(dst + (uint64_t)k * p.out_row + (uint64_t)c * p.out_col, v);
+  }
+}
+
+// coset pre/post multiplication x[j] *= g^(±j) (NTTConfig.coset_gen ≠ 1)
+__global__ void coset_mul_kernel(fe* data, uint64_t n, int batch, const fe* gpow2 /* g^(±2^j), Montgomery */, int logn)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe acc = Fr::one_mont();
+  for (int j = 0; j < logn; j++)
+    if ((i >> j) & 1) acc = Fr::mul(acc, gpow2[j]);
+  for (int b = 0; b < batch; b++) {
+    fe v = g_get(data + (uint64_t)b * n + i);
+    g_put(data + (uint64_t)b * n + i, Fr::mul(v, acc));
+  }
+}
+
+int ilog2(uint64_t x)
+{
+  int l = 0;
+  while ((1ull << l) < x) l++;
+  return l;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ API
+ISNARK_API eIcicleError bn254_get_root_of_unity(uint64_t max_size, bn254_scalar_t* rou)
+{
+  // icicle/src/ntt.cpp:52-61
+  if (!rou) return ICICLE_INVALID_POINTER;
+  const int logn = ilog2(max_size);
+  if (logn > OMEGAS_COUNT) {
+    set_last_error("no root-of-unity of order 2^%d in the BN254 scalar field", logn);
+    return ICICLE_INVALID_ARGUMENT;
+  }
+  fe w;
+  if (logn == 0) w = Fr::one_std();
+  else w = host_omega(logn);
+  memcpy(rou->limbs, w.l, 32);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError bn254_ntt_init_domain(const bn254_scalar_t* primitive_root, const NTTInitDomainConfig* cfg)
+{
+  if (!primitive_root || !cfg) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  std::lock_guard<std::mutex> lk(g_dom_mu);
+  // the reference silently keeps an existing domain (cuda ntt.cuh:452, cpu_ntt_domain.h:69)
+  if (g_dom.tw) return ICICLE_SUCCESS;
+  fe root;
+  memcpy(root.l, primitive_root->limbs, 32);
+  fe rm = Fr::to_mont(root);
+  // order of the root: smallest k with root^(2^k) = 1
+  std::vector<fe> pw;
+  fe cur = rm;
+  int k = 0;
+  while (!Fr::eq(cur, Fr::one_mont())) {
+    pw.push_back(cur);
+    cur = Fr::sqr(cur);
+    if (++k > OMEGAS_COUNT) {
+      set_last_error("ntt_init_domain: not a 2^k-th root of unity (k <= %d)", OMEGAS_COUNT);
+      return ICICLE_INVALID_ARGUMENT;
+    }
+  }
+  hipStream_t s = (hipStream_t)cfg->stream;
+  const uint64_t N = 1ull << k;
+  fe* tw = nullptr;
+  fe* dpw = nullptr;
+  HIP_TRY(hipMalloc(&tw, N * sizeof(fe)), ICICLE_ALLOCATION_FAILED);
+  if (k > 0) {
+    HIP_TRY(hipMalloc(&dpw, k * sizeof(fe)), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMemcpyAsync(dpw, pw.data(), k * sizeof(fe), hipMemcpyHostToDevice, s), ICICLE_COPY_FAILED);
+  }
+  hipLaunchKernelGGL(gen_twiddles_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tw, dpw, k);
+  ICICLE_TRY(check_launch("gen_twiddles"));
+  HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED); // pw (host vector) and dpw lifetimes
+  if (dpw) (void)hipFree(dpw);
+  g_dom.tw = tw;
+  g_dom.log_n = k;
+  g_dom.root_std = root;
+  (void)hipGetDevice(&g_dom.device);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError bn254_ntt_release_domain(void)
+{
+  std::lock_guard<std::mutex> lk(g_dom_mu);
+  if (g_dom.tw) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g_dom.tw);
+  }
+  g_dom = Domain();
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError bn254_get_root_of_unity_from_domain(uint64_t logn, bn254_scalar_t* rou)
+{
+  if (!rou) return ICICLE_INVALID_POINTER;
+  std::lock_guard<std::mutex> lk(g_dom_mu);
+  if (!g_dom.tw || (int)logn > g_dom.log_n) {
+    set_last_error("get_root_of_unity_from_domain: domain not initialised or too small");
+    return ICICLE_INVALID_ARGUMENT;
+  }
+  fe w = Fr::to_mont(g_dom.root_std);
+  for (int i = 0; i < g_dom.log_n - (int)logn; i++) w = Fr::sqr(w);
+  w = Fr::from_mont(w);
+  memcpy(rou->limbs, w.l, 32);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir dir, const NTTConfig* cfg, bn254_scalar_t* output)
+{
+  if (!cfg || !input || !output) return ICICLE_INVALID_POINTER;
+  if (size <= 0 || (size & (size - 1))) {
+    set_last_error("ntt: size %d is not a power of two", size);
+    return ICICLE_INVALID_ARGUMENT;
+  }
+  if (cfg->ordering != kNN) {
+    set_last_error("ntt: only Ordering::kNN is implemented");
+    return ICICLE_API_NOT_IMPLEMENTED;
+  }
+  if (cfg->columns_batch) {
+    set_last_error("ntt: columns_batch is not implemented");
+    return ICICLE_API_NOT_IMPLEMENTED;
+  }
+  ICICLE_TRY(require_device());
+  const int logn = ilog2((uint64_t)size);
+  Domain dom;
+  {
+    std::lock_guard<std::mutex> lk(g_dom_mu);
+    dom = g_dom;
+  }
+  if (!dom.tw || logn > dom.log_n) {
+    // the reference throws here (ntt.cuh:669-674); a C ABI returns the code instead
+    set_last_error("ntt: size 2^%d exceeds the initialised domain (2^%d)", logn, dom.log_n);
+    return ICICLE_INVALID_ARGUMENT;
+  }
+  const int batch = cfg->batch_size > 0 ? cfg->batch_size : 1;
+  const uint64_t n = (uint64_t)size, total = n * batch;
+  hipStream_t s = (hipStream_t)cfg->stream;
+  const bool inverse = dir == kInverse;
+
+  Staged sin, sout;
+  ICICLE_TRY(sin.in(input, total * sizeof(fe), cfg->are_inputs_on_device, s));
+  ICICLE_TRY(sout.out(output, total * sizeof(fe), cfg->are_outputs_on_device, s));
+  const fe* d_in = sin.ptr<fe>();
+  fe* d_out = sout.ptr<fe>();
+
+  // coset generator (NTTConfig.coset_gen): forward evaluates on g·H (x_j *= g^j first), inverse
+  // interpolates from g·H (multiply by g^-j afterwards) — ntt.h:52-64, mixed_radix_ntt.cu:911-1017.
+  fe g;
+  memcpy(g.l, cfg->coset_gen.limbs, 32);
+  const bool has_coset = !Fr::eq(g, Fr::one_std());
+  fe* d_gpow = nullptr;
+  if (has_coset) {
+    fe gm = Fr::to_mont(g);
+    if (inverse) gm = Fr::inv(gm);
+    std::vector<fe> gp(logn > 0 ? logn : 1);
+    fe cur = gm;
+    for (int j = 0; j < logn; j++) { gp[j] = cur; cur = Fr::sqr(cur); }
+    HIP_TRY(hipMallocAsync((void**)&d_gpow, gp.size() * sizeof(fe), s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMemcpyAsync(d_gpow, gp.data(), gp.size() * sizeof(fe), hipMemcpyHostToDevice, s), ICICLE_COPY_FAILED);
+    HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED); // gp is a host temporary
+  }
+
+  // pass plan
+  int np, lr[3] = {0, 0, 0};
+  if (logn <= MAX_LOG_R) { np = 1; lr[0] = logn; }
+  else if (logn <= 2 * MAX_LOG_R) { np = 2; lr[0] = (logn + 1) / 2; lr[1] = logn / 2; }
+  else { np = 3; lr[0] = (logn + 2) / 3; lr[1] = (logn + 1) / 3; lr[2] = logn / 3; }
+
+  fe* scratch = nullptr;
+  const bool need_pre_coset = has_coset && !inverse;
+  if (np > 1 || need_pre_coset) HIP_TRY(hipMallocAsync((void**)&scratch, total * sizeof(fe), s), ICICLE_ALLOCATION_FAILED);
+  if (need_pre_coset) {
+    // x_j *= g^j into scratch, then transform from scratch
+    HIP_TRY(hipMemcpyAsync(scratch, d_in, total * sizeof(fe), hipMemcpyDeviceToDevice, s), ICICLE_COPY_FAILED);
+    hipLaunchKernelGGL(coset_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, n, batch, d_gpow, logn);
+    ICICLE_TRY(check_launch("coset_mul"));
+    d_in = scratch;
+  }
+
+  fe ninv = Fr::zero();
+  ninv.l[0] = 1;
+  if (inverse) {
+    fe nn = Fr::zero();
+    nn.l[0] = (uint32_t)n;
+    ninv = Fr::inv(Fr::to_mont(nn)); // n^-1 in Montgomery form
+  }
+  const uint32_t N = 1u << dom.log_n;
+  const uint32_t dom_stride = N >> logn; // ω_n = ω_N^dom_stride
+
+  uint64_t rem = n; // n_p : size of the sub-transform still to do at pass p
+  for (int pi = 0; pi < np; pi++) {
+    PassParams p;
+    memset(&p, 0, sizeof p);
+    const bool last = pi == np - 1;
+    p.log_r = lr[pi];
+    const uint64_t R = 1ull << p.log_r;
+    const uint64_t tail = rem / R; // n_{p+1}
+    int log_c = LOG_TILE - p.log_r;
+    p.inverse = inverse;
+    p.scale = last && inverse;
+    p.n_mask = N - 1;
+    p.stage_stride = N >> p.log_r;
+    p.batch_stride = n;
+    const fe* src = pi == 0 ? d_in : scratch;
+    fe* dst = last ? d_out : scratch;
+    uint64_t tiles;
+    if (!last) {
+      // in-place positions: pos = head·rem + j·tail + t ; tile = C consecutive t
+      if ((uint64_t)(1 << log_c) > tail) log_c = ilog2(tail);
+      p.log_c = log_c;
+      const uint64_t C = 1ull << log_c;
+      const uint64_t tpg = tail / C; // tiles per head
+      p.tiles_per_group_log = ilog2(tpg);
+      p.in_hi = rem; p.in_lo = C; p.in_row = tail; p.in_col = 1;
+      p.out_hi = rem; p.out_lo = C; p.out_row = tail; p.out_col = 1;
+      p.tw_mul = (uint32_t)((uint64_t)dom_stride * (n / rem)); // ω_rem^(k·t) = ω_N^(dom_stride·(n/rem)·k·t)
+      p.load_rows_fastest = 0;
+      tiles = (n / rem) * tpg;
+    } else {
+      // last pass: rows contiguous (tail == 1); columns walk the leading output digit k1
+      const uint64_t R1 = np == 1 ? 1 : (1ull << lr[0]);
+      if ((uint64_t)(1 << log_c) > R1) log_c = ilog2(R1);
+      p.log_c = log_c;
+      const uint64_t C = 1ull << log_c;
+      const uint64_t mid = n / (R1 * R);   // product of the middle radices (R2 for 3 passes, else 1)
+      const uint64_t tpg = R1 / C;         // tiles per middle index
+      p.tiles_per_group_log = ilog2(tpg);
+      p.in_lo = C * (n / R1); p.in_hi = R; p.in_row = 1; p.in_col = n / R1;
+      p.out_lo = C; p.out_hi = R1; p.out_row = R1 * mid; p.out_col = 1;
+      p.tw_mul = 0;
+      p.load_rows_fastest = 1;
+      tiles = tpg * mid;
+    }
+    const size_t lds = ((size_t)2 << (p.log_r + p.log_c)) * 16 + (size_t)(R >> 1) * 32 + 32;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(NT), lds, s, src, dst, dom.tw, p, ninv);
+    ICICLE_TRY(check_launch("ntt_pass"));
+    rem = tail;
+  }
+
+  if (has_coset && inverse) {
+    hipLaunchKernelGGL(coset_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_out, n, batch, d_gpow, logn);
+    ICICLE_TRY(check_launch("coset_mul"));
+  }
+  if (scratch) HIP_TRY(hipFreeAsync(scratch, s), ICICLE_DEALLOCATION_FAILED);
+  if (d_gpow) HIP_TRY(hipFreeAsync(d_gpow, s), ICICLE_DEALLOCATION_FAILED);
+  ICICLE_TRY(sout.finish());
+  return end_call(s, cfg->is_async);
+}

@@ -1,0 +1,349 @@
+// runtime.cpp — device / stream / memory C API (replaces icicle/src/runtime.cpp + the CUDA device
+// API icicle/backend/cuda/src/cuda_device_api.cu for device type "HIP").
+//
+// * one registered device type, "HIP" (alias "CUDA"); the active device is thread-local with a
+//   process-wide default (icicle/src/device_api.cpp:87-116);
+// * streams are hipStream_t, async allocation is hipMallocAsync (stream-ordered pool);
+// * every allocation made through this API is recorded so that icicle_is_active_device_memory()
+//   also answers for interior pointers (icicle/include/icicle/memory_tracker.h:11-55) — the Rust
+//   DeviceSlice checks this on every slice (wrappers/rust/icicle-runtime/src/memory.rs:120-125).
+#include <map>
+#include <mutex>
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace isnark {
+
+static thread_local char g_err[512] = "";
+void set_last_error(const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  if (getenv("ICICLE_SNARK_VERBOSE")) fprintf(stderr, "[icicle-snark-hip] %s\n", g_err);
+}
+
+static std::mutex g_mu;
+static std::map<uintptr_t, std::pair<size_t, int>> g_allocs; // base -> (size, device id)
+static int g_default_device = -1;                             // -1: none chosen yet
+static thread_local int t_device = -1;
+
+static bool type_ok(const char* t) { return strncmp(t, "HIP", 64) == 0 || strncmp(t, "CUDA", 64) == 0; }
+
+static int active_device()
+{
+  if (t_device >= 0) return t_device;
+  return g_default_device;
+}
+
+eIcicleError require_device()
+{
+  int d = active_device();
+  if (d < 0) {
+    // the reference falls back to a default device on a fresh thread (device_api.cpp:104-116)
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+      set_last_error("no HIP device available (this library has no CPU fallback)");
+      return ICICLE_INVALID_DEVICE;
+    }
+    d = 0;
+    g_default_device = 0;
+  }
+  if (t_device != d) {
+    HIP_TRY(hipSetDevice(d), ICICLE_INVALID_DEVICE);
+    t_device = d;
+  }
+  return ICICLE_SUCCESS;
+}
+
+static void track(void* p, size_t size)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_allocs[(uintptr_t)p] = {size, t_device};
+}
+static bool untrack(void* p)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_allocs.erase((uintptr_t)p) > 0;
+}
+// returns device id owning ptr or -1
+static int identify(const void* p)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_allocs.upper_bound((uintptr_t)p);
+  if (it == g_allocs.begin()) return -1;
+  --it;
+  if ((uintptr_t)p < it->first + it->second.first) return it->second.second;
+  return -1;
+}
+
+} // namespace isnark
+
+using namespace isnark;
+
+ISNARK_API const char* icicle_snark_last_error(void) { return g_err; }
+
+ISNARK_API eIcicleError icicle_load_backend(const char*, bool) { return ICICLE_SUCCESS; }
+ISNARK_API eIcicleError icicle_load_backend_from_env_or_default(void) { return ICICLE_SUCCESS; }
+
+ISNARK_API eIcicleError icicle_is_device_available(const IcicleDevice* dev)
+{
+  if (!dev || !type_ok(dev->type)) return ICICLE_INVALID_DEVICE;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || dev->id < 0 || dev->id >= n) return ICICLE_INVALID_DEVICE;
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_set_device(const IcicleDevice* dev)
+{
+  if (!dev || !type_ok(dev->type)) {
+    set_last_error("device type '%.63s' is not registered (only HIP)", dev ? dev->type : "(null)");
+    return ICICLE_INVALID_DEVICE;
+  }
+  ICICLE_TRY(icicle_is_device_available(dev));
+  HIP_TRY(hipSetDevice(dev->id), ICICLE_INVALID_DEVICE);
+  t_device = dev->id;
+  if (g_default_device < 0) g_default_device = dev->id;
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_set_default_device(const IcicleDevice* dev)
+{
+  ICICLE_TRY(icicle_set_device(dev));
+  g_default_device = dev->id;
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_get_active_device(IcicleDevice* dev)
+{
+  if (!dev) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  memset(dev->type, 0, sizeof dev->type);
+  strcpy(dev->type, "HIP");
+  dev->id = t_device;
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_get_registered_devices(char* output, size_t output_size)
+{
+  if (!output || output_size < 4) return ICICLE_INVALID_ARGUMENT;
+  strcpy(output, "HIP");
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_get_device_count(int* n)
+{
+  if (!n) return ICICLE_INVALID_POINTER;
+  HIP_TRY(hipGetDeviceCount(n), ICICLE_INVALID_DEVICE);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_is_host_memory(const void* ptr)
+{
+  return identify(ptr) < 0 ? ICICLE_SUCCESS : ICICLE_INVALID_POINTER;
+}
+
+ISNARK_API eIcicleError icicle_is_active_device_memory(const void* ptr)
+{
+  int d = identify(ptr);
+  if (d < 0) return ICICLE_INVALID_POINTER;
+  return d == active_device() ? ICICLE_SUCCESS : ICICLE_INVALID_POINTER;
+}
+
+ISNARK_API eIcicleError icicle_malloc(void** ptr, size_t size)
+{
+  if (!ptr) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMalloc(ptr, size), ICICLE_ALLOCATION_FAILED);
+  track(*ptr, size);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_malloc_async(void** ptr, size_t size, icicleStreamHandle stream)
+{
+  if (!ptr) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMallocAsync(ptr, size, (hipStream_t)stream), ICICLE_ALLOCATION_FAILED);
+  track(*ptr, size);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_free(void* ptr)
+{
+  if (!ptr) return ICICLE_SUCCESS;
+  // memory of a non-active device: switch, release, switch back (runtime.cpp:66-93)
+  int owner = identify(ptr);
+  if (owner < 0) return ICICLE_INVALID_POINTER;
+  int cur = active_device();
+  if (owner != cur) (void)hipSetDevice(owner);
+  untrack(ptr);
+  hipError_t e = hipFree(ptr);
+  if (owner != cur && cur >= 0) (void)hipSetDevice(cur);
+  if (e != hipSuccess) {
+    set_last_error("hipFree failed: %s", hipGetErrorString(e));
+    return ICICLE_DEALLOCATION_FAILED;
+  }
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_free_async(void* ptr, icicleStreamHandle stream)
+{
+  if (!ptr) return ICICLE_SUCCESS;
+  if (!untrack(ptr)) return ICICLE_INVALID_POINTER;
+  HIP_TRY(hipFreeAsync(ptr, (hipStream_t)stream), ICICLE_DEALLOCATION_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_get_available_memory(size_t* total, size_t* free_)
+{
+  if (!total || !free_) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMemGetInfo(free_, total), ICICLE_UNKNOWN_ERROR);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_memset(void* ptr, int value, size_t size)
+{
+  if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
+  HIP_TRY(hipMemset(ptr, value, size), ICICLE_UNKNOWN_ERROR);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_memset_async(void* ptr, int value, size_t size, icicleStreamHandle stream)
+{
+  if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
+  HIP_TRY(hipMemsetAsync(ptr, value, size, (hipStream_t)stream), ICICLE_UNKNOWN_ERROR);
+  return ICICLE_SUCCESS;
+}
+
+static hipMemcpyKind direction(void* dst, const void* src)
+{
+  bool d = identify(dst) >= 0, s = identify(src) >= 0;
+  if (d && s) return hipMemcpyDeviceToDevice;
+  if (d) return hipMemcpyHostToDevice;
+  if (s) return hipMemcpyDeviceToHost;
+  return hipMemcpyHostToHost;
+}
+
+ISNARK_API eIcicleError icicle_copy(void* dst, const void* src, size_t size)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMemcpy(dst, src, size, direction(dst, src)), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_copy_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMemcpyAsync(dst, src, size, direction(dst, src), (hipStream_t)stream), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_copy_to_host(void* dst, const void* src, size_t size)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_copy_to_host_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_copy_to_device(void* dst, const void* src, size_t size)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_copy_to_device_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+ISNARK_API eIcicleError icicle_create_stream(icicleStreamHandle* stream)
+{
+  if (!stream) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+  *stream = s;
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_destroy_stream(icicleStreamHandle stream)
+{
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_stream_synchronize(icicleStreamHandle stream)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream), ICICLE_SYNCHRONIZATION_FAILED);
+  return ICICLE_SUCCESS;
+}
+ISNARK_API eIcicleError icicle_device_synchronize(void)
+{
+  ICICLE_TRY(require_device());
+  HIP_TRY(hipDeviceSynchronize(), ICICLE_SYNCHRONIZATION_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+// ---- config extension: string-keyed int/bool bag (icicle/include/icicle/config_extension.h) ----
+struct ConfigExtension {
+  std::map<std::string, int> ints;
+  std::map<std::string, bool> bools;
+};
+ISNARK_API ConfigExtension* create_config_extension(void) { return new ConfigExtension(); }
+ISNARK_API void destroy_config_extension(ConfigExtension* ext) { delete ext; }
+ISNARK_API void config_extension_set_int(ConfigExtension* ext, const char* key, int value)
+{
+  if (ext && key) ext->ints[key] = value;
+}
+ISNARK_API void config_extension_set_bool(ConfigExtension* ext, const char* key, bool value)
+{
+  if (ext && key) ext->bools[key] = value;
+}
+// The reference throws on a null extension / missing key (config_extension.cpp:21-30); a C ABI must
+// not unwind, so these return 0 / false and record the error text.
+ISNARK_API int config_extension_get_int(const ConfigExtension* ext, const char* key)
+{
+  if (!ext || !key) { set_last_error("ConfigExtension is null"); return 0; }
+  auto it = ext->ints.find(key);
+  if (it == ext->ints.end()) { set_last_error("ConfigExtension: no int key '%s'", key); return 0; }
+  return it->second;
+}
+ISNARK_API bool config_extension_get_bool(const ConfigExtension* ext, const char* key)
+{
+  if (!ext || !key) { set_last_error("ConfigExtension is null"); return false; }
+  auto it = ext->bools.find(key);
+  if (it == ext->bools.end()) { set_last_error("ConfigExtension: no bool key '%s'", key); return false; }
+  return it->second;
+}
+ISNARK_API ConfigExtension* clone_config_extension(const ConfigExtension* ext)
+{
+  if (!ext) { set_last_error("ConfigExtension is null"); return nullptr; }
+  return new ConfigExtension(*ext);
+}
+
+namespace isnark {
+bool ext_get_int(const ConfigExtension* ext, const char* key, int* out)
+{
+  if (!ext) return false;
+  auto it = ext->ints.find(key);
+  if (it == ext->ints.end()) return false;
+  *out = it->second;
+  return true;
+}
+bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out)
+{
+  if (!ext) return false;
+  auto it = ext->bools.find(key);
+  if (it == ext->bools.end()) return false;
+  *out = it->second;
+  return true;
+}
+} // namespace isnark

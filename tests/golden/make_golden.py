@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from oracle/_ref — the reference's OWN sources compiled where they lie
+(`make -C oracle ref`; needs /root/reference, so this only runs in the build container).
+
+The reference repository holds no known-answer vectors for the Groth16 path, so these
+fixtures are outputs of the reference itself:
+
+  field.json     bn254_add/sub/mul/inv (icicle/src/fields/ffi_extern.cpp) on seeded inputs; the
+                 roots of unity bn254_get_root_of_unity(2^k), k = 0..28 (icicle/src/ntt.cpp:52-61)
+  curve.json     bn254_{g2_,}generator / mul_scalar / ecadd / ecsub / to_affine / eq
+                 (icicle/src/curves/ffi_extern.cpp), bn254_{g2_,}affine_convert_montgomery (CPU backend)
+  msm.json       Σ sᵢ·Pᵢ assembled ONLY from the reference's from_affine / mul_scalar / ecadd, for the
+                 reference's own test shapes: sizes {1,5,100}, affine-zero points, 0/1-skewed scalars
+                 (wrappers/rust/icicle-core/src/msm/tests.rs:24-95,254-302)
+  ntt.json       DFT by definition assembled ONLY from the reference's bn254_mul / bn254_add with
+                 ω = bn254_get_root_of_unity(n), n ∈ {4,16,64}; forward and inverse
+  groth16.json   one tiny end-to-end case (squaring chain N=6): zkey + wtns bytes, (r,s), the proof of
+                 the oracle pipeline — accepted by the reference pairing check
+                 (groth16_verify_helper, src/proof_helper.rs:319-372 on bn254_pairing)
+
+Data only: inputs and expected outputs as hex strings; no reference source text.
+"""
+import base64
+import importlib
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+import oracle as O  # noqa: E402
+import ref as R     # noqa: E402
+
+assert R.available(), "build oracle/_ref first: make -C oracle ref"
+S = importlib.import_module("icicle-snark_amd.synth")
+
+
+def hx(a):
+    return np.ascontiguousarray(a).tobytes().hex()
+
+
+def hi(x):
+    return int(x).to_bytes(32, "little").hex()
+
+
+def main():
+    rnd = random.Random(0xB17254)
+    rs = lambda: rnd.randrange(O.R_MOD)
+
+    # ------------------------------------------------------------------ field
+    cases = []
+    specials = [0, 1, 2, O.R_MOD - 1, O.R_MOD - 2, (1 << 253), (1 << 253) - 1]
+    pairs = [(a, b) for a in specials for b in specials[:4]] + [(rs(), rs()) for _ in range(40)]
+    for a, b in pairs:
+        cases.append(dict(a=hi(a), b=hi(b), add=hi(R.fr_bin("add", a, b)), sub=hi(R.fr_bin("sub", a, b)),
+                          mul=hi(R.fr_bin("mul", a, b)), inv_a=hi(R.fr_inv(a))))
+    field = dict(fr=cases, roots=[hi(R.get_root_of_unity(1 << k)) for k in range(29)])
+    json.dump(field, open(os.path.join(HERE, "field.json"), "w"), indent=0)
+
+    # ------------------------------------------------------------------ curve
+    curve = {}
+    for g in ("g1", "g2"):
+        G = R.ec(g, "generator")
+        ent = dict(generator=hx(G), cases=[])
+        P = G
+        for i in range(8):
+            k = [1, 2, 3, O.R_MOD - 1][i] if i < 4 else rs()
+            Q = R.ec(g, "mul_scalar", P, k)
+            ent["cases"].append(dict(
+                p=hx(P), k=hi(k), mul=hx(Q), mul_affine=hx(R.ec(g, "to_affine", Q)),
+                add=hx(R.ec(g, "ecadd", P, Q)), sub=hx(R.ec(g, "ecsub", P, Q)),
+                dbl=hx(R.ec(g, "ecadd", Q, Q))))
+            P = R.ec(g, "ecadd", Q, G)
+        zero = O.ec_zero(g)
+        ent["zero_affine"] = hx(R.ec(g, "to_affine", zero))
+        ent["p_minus_p"] = hx(R.ec(g, "ecsub", P, P))
+        pts = np.stack([R.ec(g, "to_affine", R.ec(g, "mul_scalar", G, rs())) for _ in range(4)])
+        ent["mont_in"] = hx(pts)
+        ent["to_mont"] = hx(R.convert_montgomery(g, pts, True))
+        ent["from_mont"] = hx(R.convert_montgomery(g, pts, False))
+        curve[g] = ent
+    json.dump(curve, open(os.path.join(HERE, "curve.json"), "w"), indent=0)
+
+    # ------------------------------------------------------------------ msm
+    msm = {}
+    for g in ("g1", "g2"):
+        G = R.ec(g, "generator")
+        ent = []
+        for (n, kind) in ((1, "random"), (5, "random"), (100, "random"), (100, "skewed"), (64, "repeated")):
+            base_pts = [R.ec(g, "to_affine", R.ec(g, "mul_scalar", G, rs())) for _ in range(min(n, 20))]
+            bases = np.stack([base_pts[i % len(base_pts)] for i in range(n)])  # repeats every 20, like rand_host_many
+            if n >= 5:
+                bases[1] = 0
+                bases[n - 1] = 0  # affine zero points (msm/tests.rs:49-52)
+            if kind == "skewed":      # mostly 0/1 scalars (msm/tests.rs:254-302)
+                sc = [rnd.choice([0, 0, 1, 1, 1, rs()]) for _ in range(n)]
+            elif kind == "repeated":  # identical scalar on identical points → doublings inside buckets
+                sc = [12345] * n
+            else:
+                sc = [rs() for _ in range(n)]
+                if n >= 5:
+                    sc[2], sc[3] = 0, O.R_MOD - 1
+            sca = O.ints_to_arr(sc)
+            res = R.msm_naive(g, sca, bases)
+            ent.append(dict(n=n, kind=kind, scalars=hx(sca), bases=hx(bases), result_affine=hx(R.ec(g, "to_affine", res))))
+        msm[g] = ent
+    json.dump(msm, open(os.path.join(HERE, "msm.json"), "w"), indent=0)
+
+    # ------------------------------------------------------------------ ntt
+    ntt = []
+    for n in (4, 16, 64):
+        x = O.ints_to_arr([rs() for _ in range(n)])
+        w = R.get_root_of_unity(n)
+        fwd = R.dft_naive(x, w)
+        winv = R.fr_inv(w)
+        ninv = R.fr_inv(n)
+        inv_raw = R.dft_naive(x, winv)
+        inv = O.ints_to_arr([R.fr_bin("mul", v, ninv) for v in O.arr_to_ints(inv_raw)])
+        ntt.append(dict(n=n, x=hx(x), forward=hx(fwd), inverse=hx(inv)))
+    json.dump(ntt, open(os.path.join(HERE, "ntt.json"), "w"), indent=0)
+
+    # ------------------------------------------------------------------ groth16 end to end
+    Gaff = {g: O.ec_to_affine(g, O.ec_generator(g)) for g in ("g1", "g2")}
+    fbm = lambda g, sc: O.fixed_base_mul(g, Gaff[g], sc)
+    r1, w = S.squaring_chain(6)
+    zkey, vk = S.setup(r1, fbm)
+    wtns = S.write_wtns(w)
+    out = []
+    for (r, s) in ((1, 1), (rs(), rs())):
+        proof, public = O.groth16_prove(zkey, wtns, r, s)
+        assert R.groth16_verify(proof, public, vk), "reference pairing check rejected the oracle proof"
+        out.append(dict(r=hi(r), s=hi(s), proof=proof, public=public))
+    vkj = dict(vk_alpha_1=hx(vk["vk_alpha_1"]), vk_beta_2=hx(vk["vk_beta_2"]), vk_gamma_2=hx(vk["vk_gamma_2"]),
+               vk_delta_2=hx(vk["vk_delta_2"]), IC=[hx(p) for p in vk["IC"]])
+    json.dump(dict(circuit="squaring_chain(6), a=3", zkey=base64.b64encode(zkey).decode(), wtns=base64.b64encode(wtns).decode(),
+                   vk=vkj, cases=out), open(os.path.join(HERE, "groth16.json"), "w"), indent=0)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

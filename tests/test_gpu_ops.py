@@ -1,0 +1,237 @@
+"""Parity tests proper (need an MI355X): the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs and against the committed golden vectors.  Bit-exact everywhere (integer work).
+Shapes follow the reference's own differential tests (wrappers/rust/icicle-core/src/{vec_ops,ntt,msm}/tests.rs)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unhex, unhex_int
+
+pytestmark = pytest.mark.gpu
+DIMS = {"g1": (2, 3), "g2": (4, 6)}
+
+
+def rand_fr(O, rng, n):
+    raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << 61) - 1)  # < 2^253 < r
+    return raw
+
+
+def test_runtime_memory_tracking(gpu):
+    K = gpu
+    d = K.DeviceVec(1024)
+    assert K.lib().icicle_is_active_device_memory(K._p(d)) == 0
+    assert K.lib().icicle_is_active_device_memory(K._p(d.slice(512, 64))) == 0   # interior pointer
+    host = np.zeros(4, dtype=np.uint64)
+    assert K.lib().icicle_is_active_device_memory(K._p(host)) != 0
+    assert K.lib().icicle_is_host_memory(K._p(host)) == 0
+    a = np.arange(128, dtype=np.uint64)
+    d.copy_from_host(a)
+    assert np.array_equal(d.to_host((128,)), a)
+    st = K.IcicleStream()
+    d2 = K.DeviceVec.from_host(a, st)
+    assert np.array_equal(d2.to_host((128,), stream=st), a)
+    st.destroy()
+    d.free(); d2.free()
+    assert K.lib().icicle_is_active_device_memory(K._p(d2)) != 0
+
+
+@pytest.mark.parametrize("n", [1, 5, 255, 4096, 100003])
+def test_vec_ops_all_residencies(gpu, O, n):
+    K = gpu
+    rng = np.random.default_rng(n)
+    a, b = rand_fr(O, rng, n), rand_fr(O, rng, n)
+    a[0] = 0
+    want = {"mul": O.fr_vector_mul(a, b), "sub": O.fr_vector_sub(a, b), "add": O.fr_vector_add(a, b)}
+    fn = {"mul": K.mul_scalars, "sub": K.sub_scalars, "add": K.add_scalars}
+    for op in want:
+        assert np.array_equal(fn[op](a, b), want[op]), op                      # host, host -> host
+        da, db = K.DeviceVec.from_host(a), K.DeviceVec.from_host(b)
+        out = K.DeviceVec(n * 32)
+        fn[op](da, db, out)                                                     # device -> device
+        assert np.array_equal(out.to_host((n, 4)), want[op]), op
+        assert np.array_equal(fn[op](da, b), want[op]), op                     # mixed -> host
+        st = K.IcicleStream()
+        fn[op](da, db, da, stream=st, is_async=True)                            # in place, async
+        st.synchronize(); st.destroy()
+        assert np.array_equal(da.to_host((n, 4)), want[op]), op
+        da.free(); db.free(); out.free()
+
+
+def test_scalar_montgomery(gpu, O):
+    K = gpu
+    rng = np.random.default_rng(5)
+    a = rand_fr(O, rng, 5000)
+    assert np.array_equal(K.scalar_convert_montgomery(a, True), O.fr_convert_montgomery(a, True))
+    assert np.array_equal(K.scalar_convert_montgomery(a, False), O.fr_convert_montgomery(a, False))
+    d = K.DeviceVec.from_host(a)
+    K.scalar_convert_montgomery(d, True)       # in place on device, like ScalarField::from_mont(&mut DeviceVec)
+    K.scalar_convert_montgomery(d, False)
+    assert np.array_equal(d.to_host(a.shape), a)
+    d.free()
+
+
+@pytest.mark.parametrize("grp", ["g1", "g2"])
+def test_point_montgomery_golden(gpu, grp):
+    K = gpu
+    g = load_golden("curve.json")[grp]
+    na = DIMS[grp][0]
+    pts = unhex(g["mont_in"], 4, na, 4)
+    assert np.array_equal(K.affine_convert_montgomery(grp, pts, True), unhex(g["to_mont"], 4, na, 4))
+    assert np.array_equal(K.affine_convert_montgomery(grp, pts, False), unhex(g["from_mont"], 4, na, 4))
+
+
+@pytest.fixture(scope="module")
+def domain(gpu):
+    K = gpu
+    K.release_domain()
+    K.initialize_domain(K.get_root_of_unity(1 << 20))
+    yield K
+    K.release_domain()
+
+
+def test_ntt_golden(domain):
+    K = domain
+    for c in load_golden("ntt.json"):
+        n = c["n"]
+        x = unhex(c["x"], n, 4)
+        assert np.array_equal(K.ntt(x, False), unhex(c["forward"], n, 4))
+        assert np.array_equal(K.ntt(x, True), unhex(c["inverse"], n, 4))
+
+
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 7, 9, 10, 11, 13, 16, 18, 19, 20])
+def test_ntt_vs_oracle(domain, O, logn):
+    """1-pass (≤2^9), 2-pass (2^10..2^18) and 3-pass (≥2^19) plans, batch 3, in place on device, async —
+    the prover's configuration (icicle_helper.rs:13-32) — forward, inverse and round trip."""
+    K = domain
+    n = 1 << logn
+    rng = np.random.default_rng(logn)
+    batch = 3 if logn <= 18 else 1
+    x = rand_fr(O, rng, batch * n)
+    want_f = O.fr_ntt(x, False, batch=batch, domain_log=20)
+    want_i = O.fr_ntt(x, True, batch=batch, domain_log=20)
+    assert np.array_equal(K.ntt(x, False, batch_size=batch), want_f)          # host in/out
+    st = K.IcicleStream()
+    d = K.DeviceVec.from_host(x, st)
+    K.ntt(d, True, batch_size=batch, stream=st, is_async=True)                 # in place on device
+    assert np.array_equal(d.to_host(x.shape, stream=st), want_i)
+    K.ntt(d, False, batch_size=batch, stream=st, is_async=True)                # round trip
+    assert np.array_equal(d.to_host(x.shape, stream=st), x)
+    st.destroy(); d.free()
+
+
+def test_ntt_out_of_place_and_errors(domain, O):
+    K = domain
+    rng = np.random.default_rng(99)
+    x = rand_fr(O, rng, 1 << 12)
+    d_in, d_out = K.DeviceVec.from_host(x), K.DeviceVec(x.nbytes)
+    K.ntt(d_in, False, out=d_out)
+    assert np.array_equal(d_out.to_host(x.shape), O.fr_ntt(x, False, domain_log=20))
+    assert np.array_equal(d_in.to_host(x.shape), x)
+    with pytest.raises(K.IcicleError):
+        K.ntt(x[:12], False)                       # not a power of two
+    with pytest.raises(K.IcicleError):
+        K.ntt(np.zeros((1 << 21, 4), dtype=np.uint64), False)   # larger than the domain
+    d_in.free(); d_out.free()
+
+
+def test_ntt_coset(domain, O):
+    """size-2n NTT = NTT(n) of evens ∥ coset-NTT(n): the reference's own identity test (ntt/tests.rs:99-166),
+    here in the form: coset NTT with g equals NTT of x_j·g^j."""
+    K = domain
+    rng = np.random.default_rng(4)
+    n = 1 << 10
+    x = rand_fr(O, rng, n)
+    g = O.fr_omega(11)
+    xs = O.arr_to_ints(x)
+    shifted = O.ints_to_arr([v * pow(g, j, O.R_MOD) % O.R_MOD for j, v in enumerate(xs)])
+    want = O.fr_ntt(shifted, False, domain_log=20)
+    got = K.ntt(x, False, coset_gen=O.ints_to_arr([g])[0])
+    assert np.array_equal(got, want)
+    back = K.ntt(got, True, coset_gen=O.ints_to_arr([g])[0])
+    assert np.array_equal(back, x)
+
+
+@pytest.mark.parametrize("grp", ["g1", "g2"])
+def test_msm_golden(gpu, O, grp):
+    K = gpu
+    na = DIMS[grp][0]
+    for c in load_golden("msm.json")[grp]:
+        n = c["n"]
+        sc, bases = unhex(c["scalars"], n, 4), unhex(c["bases"], n, na, 4)
+        want = unhex(c["result_affine"], na, 4)
+        for cc in (0, 5, 16):
+            res = K.msm(grp, sc, bases, c=cc)
+            assert np.array_equal(K.ec(grp, "to_affine", res), want), (grp, n, c["kind"], cc)
+
+
+def _bases(O, grp, rng, n, distinct=100):
+    G = O.ec_to_affine(grp, O.ec_generator(grp))
+    k = rand_fr(O, rng, min(n, distinct))
+    pts = O.fixed_base_mul(grp, G, k)
+    reps = (n + len(pts) - 1) // len(pts)
+    return np.concatenate([pts] * reps)[:n].copy()    # repeats like rand_host_many (projective.h:246-256)
+
+
+@pytest.mark.parametrize("grp,n", [("g1", 1), ("g1", 16), ("g1", 1000), ("g1", 1 << 14), ("g2", 1), ("g2", 1000), ("g2", 1 << 12)])
+def test_msm_vs_oracle_device_resident(gpu, O, grp, n):
+    """msm/tests.rs:24-95: scalars/points/result on device, async, two affine-zero points."""
+    K = gpu
+    rng = np.random.default_rng(n + (7 if grp == "g2" else 0))
+    sc, bases = rand_fr(O, rng, n), _bases(O, grp, rng, n)
+    if n > 2:
+        bases[1] = 0
+        bases[n - 1] = 0
+    want = O.ec_to_affine(grp, O.msm(grp, sc, bases))
+    st = K.IcicleStream()
+    d_s, d_b = K.DeviceVec.from_host(sc, st), K.DeviceVec.from_host(bases, st)
+    d_r = K.DeviceVec(32 * DIMS[grp][1], st)
+    K.msm(grp, d_s, d_b, out=d_r, stream=st, is_async=True)
+    res = d_r.to_host((DIMS[grp][1], 4), stream=st)
+    assert np.array_equal(K.ec(grp, "to_affine", res), want)
+    # Montgomery-form inputs (are_scalars_montgomery_form / are_points_montgomery_form)
+    K.scalar_convert_montgomery(d_s, True)
+    K.affine_convert_montgomery(grp, d_b, True)
+    res2 = K.msm(grp, d_s, d_b, scalars_mont=True, points_mont=True)
+    assert np.array_equal(K.ec(grp, "to_affine", res2), want)
+    st.destroy(); d_s.free(); d_b.free(); d_r.free()
+
+
+@pytest.mark.parametrize("grp", ["g1", "g2"])
+def test_msm_skewed_scalars(gpu, O, grp):
+    """msm/tests.rs:254-302: mostly 0/1 scalars (witness-like) → huge buckets, P+P doublings, large-bucket path."""
+    K = gpu
+    n = 20000 if grp == "g1" else 6000
+    rng = np.random.default_rng(21)
+    sc = rand_fr(O, rng, n)
+    kind = rng.integers(0, 10, size=n)
+    sc[kind < 4] = 0
+    sc[(kind >= 4) & (kind < 8)] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    sc[kind == 8] = O.ints_to_arr([O.R_MOD - 1])[0]
+    bases = _bases(O, grp, rng, n, distinct=50)
+    want = O.ec_to_affine(grp, O.msm(grp, sc, bases))
+    assert np.array_equal(K.ec(grp, "to_affine", K.msm(grp, sc, bases)), want)
+    assert np.array_equal(K.ec(grp, "to_affine", K.msm(grp, sc, bases, c=8)), want)
+
+
+def test_msm_degenerate(gpu, O):
+    K = gpu
+    rng = np.random.default_rng(2)
+    bases = _bases(O, "g1", rng, 8)
+    zero = np.zeros((8, 4), dtype=np.uint64)
+    res = K.msm("g1", zero, bases)
+    assert not K.ec("g1", "to_affine", res).any() and np.array_equal(res, O.ec_zero("g1"))   # (0,1,0)
+    # P − P
+    sc = O.ints_to_arr([5, O.R_MOD - 5])
+    b2 = np.stack([bases[0], bases[0]])
+    assert not K.ec("g1", "to_affine", K.msm("g1", sc, b2)).any()
+
+
+@pytest.mark.parametrize("grp", ["g1", "g2"])
+def test_generator_mul(gpu, O, grp):
+    K = gpu
+    rng = np.random.default_rng(8)
+    sc = rand_fr(O, rng, 300)
+    sc[0] = 0
+    sc[1] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    G = O.ec_to_affine(grp, O.ec_generator(grp))
+    assert np.array_equal(K.generator_mul(grp, sc), O.fixed_base_mul(grp, G, sc))
