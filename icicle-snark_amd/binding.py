@@ -125,7 +125,7 @@ def set_device(dev_type: str = "HIP", dev_id: int = 0):
     check(lib().icicle_set_device(C.byref(d)), f"set_device({dev_type},{dev_id})")
 
 
-def _p(a):
+def ptr_of(a):
     if a is None:
         return None
     if isinstance(a, np.ndarray):
@@ -193,17 +193,17 @@ class DeviceVec:
         a = np.ascontiguousarray(a)
         assert a.nbytes <= self.nbytes
         if stream is None:
-            check(lib().icicle_copy_to_device(C.c_void_p(self.ptr), _p(a), C.c_size_t(a.nbytes)), "copy_to_device")
+            check(lib().icicle_copy_to_device(C.c_void_p(self.ptr), ptr_of(a), C.c_size_t(a.nbytes)), "copy_to_device")
         else:
-            check(lib().icicle_copy_to_device_async(C.c_void_p(self.ptr), _p(a), C.c_size_t(a.nbytes), C.c_void_p(stream.handle)), "copy_to_device_async")
+            check(lib().icicle_copy_to_device_async(C.c_void_p(self.ptr), ptr_of(a), C.c_size_t(a.nbytes), C.c_void_p(stream.handle)), "copy_to_device_async")
 
     def to_host(self, shape, dtype=np.uint64, stream: IcicleStream | None = None) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
         if stream is None:
-            check(lib().icicle_copy_to_host(_p(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)), "copy_to_host")
+            check(lib().icicle_copy_to_host(ptr_of(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)), "copy_to_host")
         else:
-            check(lib().icicle_copy_to_host_async(_p(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), C.c_void_p(stream.handle)), "copy_to_host_async")
+            check(lib().icicle_copy_to_host_async(ptr_of(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), C.c_void_p(stream.handle)), "copy_to_host_async")
             stream.synchronize()
         return out
 
@@ -219,7 +219,7 @@ def _vec_op(name, a, b, out, n, stream, is_async):
     cfg.is_a_on_device, cfg.is_b_on_device, cfg.is_result_on_device = _on_dev(a), _on_dev(b), _on_dev(out)
     cfg.is_async = is_async
     cfg.stream = stream.handle if stream else None
-    check(getattr(lib(), name)(_p(a), _p(b), C.c_uint64(n), C.byref(cfg), _p(out)), name)
+    check(getattr(lib(), name)(ptr_of(a), ptr_of(b), C.c_uint64(n), C.byref(cfg), ptr_of(out)), name)
 
 
 def _n_of(a):
@@ -228,21 +228,21 @@ def _n_of(a):
 
 def mul_scalars(a, b, out=None, stream=None, is_async=False):
     if out is None:
-        out = np.empty_like(a)
+        out = np.empty((_n_of(a), 4), dtype=np.uint64)
     _vec_op("bn254_vector_mul", a, b, out, _n_of(a), stream, is_async)
     return out
 
 
 def sub_scalars(a, b, out=None, stream=None, is_async=False):
     if out is None:
-        out = np.empty_like(a)
+        out = np.empty((_n_of(a), 4), dtype=np.uint64)
     _vec_op("bn254_vector_sub", a, b, out, _n_of(a), stream, is_async)
     return out
 
 
 def add_scalars(a, b, out=None, stream=None, is_async=False):
     if out is None:
-        out = np.empty_like(a)
+        out = np.empty((_n_of(a), 4), dtype=np.uint64)
     _vec_op("bn254_vector_add", a, b, out, _n_of(a), stream, is_async)
     return out
 
@@ -254,7 +254,7 @@ def scalar_convert_montgomery(a, to_mont: bool, out=None, stream=None, is_async=
     cfg.is_a_on_device, cfg.is_result_on_device = _on_dev(a), _on_dev(out)
     cfg.is_async = is_async
     cfg.stream = stream.handle if stream else None
-    check(lib().bn254_scalar_convert_montgomery(_p(a), C.c_uint64(_n_of(a)), C.c_bool(to_mont), C.byref(cfg), _p(out)), "scalar_convert_montgomery")
+    check(lib().bn254_scalar_convert_montgomery(ptr_of(a), C.c_uint64(_n_of(a)), C.c_bool(to_mont), C.byref(cfg), ptr_of(out)), "scalar_convert_montgomery")
     return out
 
 
@@ -268,20 +268,20 @@ def affine_convert_montgomery(group: str, a, to_mont: bool, out=None, stream=Non
     cfg.is_async = is_async
     cfg.stream = stream.handle if stream else None
     name = "bn254_affine_convert_montgomery" if group == "g1" else "bn254_g2_affine_convert_montgomery"
-    check(getattr(lib(), name)(_p(a), C.c_uint64(n), C.c_bool(to_mont), C.byref(cfg), _p(out)), name)
+    check(getattr(lib(), name)(ptr_of(a), C.c_uint64(n), C.c_bool(to_mont), C.byref(cfg), ptr_of(out)), name)
     return out
 
 
 # --------------------------------------------------------------------------------------------- NTT
 def get_root_of_unity(max_size: int) -> np.ndarray:
     out = np.zeros(4, dtype=np.uint64)
-    check(lib().bn254_get_root_of_unity(C.c_uint64(max_size), _p(out)), "get_root_of_unity")
+    check(lib().bn254_get_root_of_unity(C.c_uint64(max_size), ptr_of(out)), "get_root_of_unity")
     return out
 
 
 def initialize_domain(root: np.ndarray, stream=None):
     cfg = NTTInitDomainConfig(stream.handle if stream else None, False, None)
-    check(lib().bn254_ntt_init_domain(_p(np.ascontiguousarray(root)), C.byref(cfg)), "ntt_init_domain")
+    check(lib().bn254_ntt_init_domain(ptr_of(np.ascontiguousarray(root)), C.byref(cfg)), "ntt_init_domain")
 
 
 def release_domain():
@@ -303,7 +303,7 @@ def ntt(inp, inverse: bool, out=None, batch_size=1, size=None, stream=None, is_a
         cg = np.ascontiguousarray(coset_gen, dtype=np.uint64).view(np.uint32)
         for i in range(8):
             cfg.coset_gen[i] = int(cg[i])
-    check(lib().bn254_ntt(_p(inp), C.c_int(size), C.c_int(1 if inverse else 0), C.byref(cfg), _p(out)), "ntt")
+    check(lib().bn254_ntt(ptr_of(inp), C.c_int(size), C.c_int(1 if inverse else 0), C.byref(cfg), ptr_of(out)), "ntt")
     return out
 
 
@@ -324,7 +324,7 @@ def msm(group: str, scalars, bases, out=None, stream=None, is_async=False, c=0, 
     cfg.stream = stream.handle if stream else None
     cfg.ext = ext
     name = "bn254_msm" if group == "g1" else "bn254_g2_msm"
-    check(getattr(lib(), name)(_p(scalars), _p(bases), C.c_int(size), C.byref(cfg), _p(out)), name)
+    check(getattr(lib(), name)(ptr_of(scalars), ptr_of(bases), C.c_int(size), C.byref(cfg), ptr_of(out)), name)
     return out
 
 
@@ -361,13 +361,13 @@ def a2i(a):
 
 def fr_op(op: str, a: int, b: int) -> int:
     out = np.zeros(4, dtype=np.uint64)
-    getattr(lib(), f"bn254_{op}")(_p(i2a(a)), _p(i2a(b)), _p(out))
+    getattr(lib(), f"bn254_{op}")(ptr_of(i2a(a)), ptr_of(i2a(b)), ptr_of(out))
     return a2i(out)
 
 
 def fr_inv(a: int) -> int:
     out = np.zeros(4, dtype=np.uint64)
-    lib().bn254_inv(_p(i2a(a)), _p(out))
+    lib().bn254_inv(ptr_of(i2a(a)), ptr_of(out))
     return a2i(out)
 
 
@@ -381,27 +381,27 @@ def ec(group: str, op: str, *args):
     na, npj = _DIMS[group]
     if op in ("ecadd", "ecsub"):
         out = np.zeros((npj, 4), dtype=np.uint64)
-        f(_p(np.ascontiguousarray(args[0])), _p(np.ascontiguousarray(args[1])), _p(out))
+        f(ptr_of(np.ascontiguousarray(args[0])), ptr_of(np.ascontiguousarray(args[1])), ptr_of(out))
     elif op == "mul_scalar":
         out = np.zeros((npj, 4), dtype=np.uint64)
-        f(_p(np.ascontiguousarray(args[0])), _p(i2a(args[1])), _p(out))
+        f(ptr_of(np.ascontiguousarray(args[0])), ptr_of(i2a(args[1])), ptr_of(out))
     elif op == "to_affine":
         out = np.zeros((na, 4), dtype=np.uint64)
-        f(_p(np.ascontiguousarray(args[0])), _p(out))
+        f(ptr_of(np.ascontiguousarray(args[0])), ptr_of(out))
     elif op == "from_affine":
         out = np.zeros((npj, 4), dtype=np.uint64)
-        f(_p(np.ascontiguousarray(args[0])), _p(out))
+        f(ptr_of(np.ascontiguousarray(args[0])), ptr_of(out))
     elif op == "generator":
         out = np.zeros((npj, 4), dtype=np.uint64)
-        f(_p(out))
+        f(ptr_of(out))
     else:
         raise ValueError(op)
     return out
 
 
 def ec_eq(group, a, b) -> bool:
-    return bool(getattr(lib(), _PRE[group] + "eq")(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b))))
+    return bool(getattr(lib(), _PRE[group] + "eq")(ptr_of(np.ascontiguousarray(a)), ptr_of(np.ascontiguousarray(b))))
 
 
 def ec_is_on_curve(group, a) -> bool:
-    return bool(getattr(lib(), _PRE[group] + "is_on_curve")(_p(np.ascontiguousarray(a))))
+    return bool(getattr(lib(), _PRE[group] + "is_on_curve")(ptr_of(np.ascontiguousarray(a))))

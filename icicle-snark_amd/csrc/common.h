@@ -35,12 +35,16 @@ eIcicleError require_device();
 // Stages a host-resident operand on the device for the lifetime of the object (the reference's
 // wrappers do the same per VecOpsConfig / NTTConfig / MSMConfig flags, e.g.
 // icicle/backend/cuda/src/field/cuda_vec_ops.cu:17-54).  Output operands are copied back by finish().
+//
+// This is the slow, convenience path (the prover passes device pointers everywhere).  It is kept
+// deliberately conservative: plain hipMalloc/hipFree and BLOCKING copies — H2D completes before the
+// kernel is enqueued, D2H runs after an explicit stream synchronisation.  (Stream-ordered pool
+// memory + asynchronous copies from/to pageable host memory were observed to race on this stack.)
 class Staged
 {
 public:
   Staged() {}
   ~Staged() { release(); }
-  // input operand
   eIcicleError in(const void* p, size_t bytes, bool on_device, hipStream_t s)
   {
     stream_ = s;
@@ -48,12 +52,11 @@ public:
       dev_ = const_cast<void*>(p);
       return ICICLE_SUCCESS;
     }
-    HIP_TRY(hipMallocAsync(&dev_, bytes, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMalloc(&dev_, bytes), ICICLE_ALLOCATION_FAILED);
     owned_ = true;
-    HIP_TRY(hipMemcpyAsync(dev_, p, bytes, hipMemcpyHostToDevice, s), ICICLE_COPY_FAILED);
+    HIP_TRY(hipMemcpy(dev_, p, bytes, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
     return ICICLE_SUCCESS;
   }
-  // output operand (alias_of: if the output host pointer equals an input host pointer reuse its staging)
   eIcicleError out(void* p, size_t bytes, bool on_device, hipStream_t s)
   {
     stream_ = s;
@@ -62,23 +65,28 @@ public:
       dev_ = p;
       return ICICLE_SUCCESS;
     }
-    HIP_TRY(hipMallocAsync(&dev_, bytes, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMalloc(&dev_, bytes), ICICLE_ALLOCATION_FAILED);
     owned_ = true;
     host_out_ = p;
     bytes_ = bytes;
     return ICICLE_SUCCESS;
   }
+  // a host-resident result is complete when the call returns, also for is_async calls
   eIcicleError finish()
   {
     if (host_out_) {
-      HIP_TRY(hipMemcpyAsync(host_out_, dev_, bytes_, hipMemcpyDeviceToHost, stream_), ICICLE_COPY_FAILED);
+      HIP_TRY(hipStreamSynchronize(stream_), ICICLE_SYNCHRONIZATION_FAILED);
+      HIP_TRY(hipMemcpy(host_out_, dev_, bytes_, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
       host_out_ = nullptr;
     }
     return ICICLE_SUCCESS;
   }
   void release()
   {
-    if (owned_ && dev_) (void)hipFreeAsync(dev_, stream_);
+    if (owned_ && dev_) {
+      (void)hipStreamSynchronize(stream_); // kernels reading a staged input may still be in flight
+      (void)hipFree(dev_);
+    }
     owned_ = false;
     dev_ = nullptr;
   }
@@ -95,6 +103,16 @@ private:
   bool owned_ = false;
   hipStream_t stream_ = nullptr;
 };
+
+// Workspace allocation for kernels' temporaries: a per-stream cache of device blocks.
+// ws_free() only marks the block reusable by LATER work on the SAME stream (in-order execution makes
+// that safe without any synchronisation); blocks are returned to the driver when their stream is
+// destroyed or the library unloads.  hipMallocAsync's stream-ordered pool is deliberately not used:
+// on this ROCm stack recycled pool blocks were observed to be handed out while earlier kernels on
+// the stream were still using them (nondeterministic MSM results; see DESIGN.md "Workspace arena").
+hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s);
+hipError_t ws_free(void* p, hipStream_t s);
+void ws_release_stream(hipStream_t s); // caller has synchronised the stream
 
 // finish an API call: synchronise unless the caller asked for async execution
 inline eIcicleError end_call(hipStream_t s, bool is_async)

@@ -93,6 +93,13 @@ __device__ __forceinline__ uint32_t digit(const uint32_t t[9], int w, const Geom
   return d < 0 ? ((uint32_t)(-d) | 0x80000000u) : (uint32_t)d;
 }
 
+// zero `n` u32 words (kernel instead of hipMemsetAsync: keeps every dependency on the compute queue)
+__global__ __launch_bounds__(256) void msm_zero_kernel(uint32_t* __restrict__ p, uint32_t n)
+{
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe* __restrict__ scalars, uint32_t L, Geom g, int mont, uint32_t* __restrict__ counts)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,18 +417,25 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   X *buckets = nullptr, *partials = nullptr;
   const int k_log = (c - 1) > 11 ? (c - 1) - 11 : 0;
   const uint32_t tpw = g.NB >> k_log; // reduce threads per window
-  const uint32_t rblock = tpw < 256 ? tpw : 256;
+  const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256; // LDS tree buffer ≤ 32 KiB
+  const uint32_t rblock = tpw < rb_max ? tpw : rb_max;
   const uint32_t bpw = tpw / rblock;
-  HIP_TRY(hipMallocAsync((void**)&counts, (size_t)nbuckets * 4 * 4 + 16, s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(ws_alloc((void**)&counts, (size_t)nbuckets * 4 * 4 + 16, s), ICICLE_ALLOCATION_FAILED);
   offsets = counts + nbuckets;
   cursor = offsets + nbuckets;
   n_large = cursor + nbuckets;
   large_list = n_large + 4;
-  HIP_TRY(hipMallocAsync((void**)&sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(hipMallocAsync((void**)&buckets, (size_t)nbuckets * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(hipMallocAsync((void**)&partials, (size_t)g.W * bpw * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nbuckets * 4, s), ICICLE_UNKNOWN_ERROR);
-  HIP_TRY(hipMemsetAsync(n_large, 0, 16, s), ICICLE_UNKNOWN_ERROR);
+  HIP_TRY(ws_alloc((void**)&sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(ws_alloc((void**)&buckets, (size_t)nbuckets * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(ws_alloc((void**)&partials, (size_t)g.W * bpw * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
+  {
+    // counts[nbuckets] and (three arrays further) n_large[4]
+    unsigned zb = (nbuckets + 255) / 256;
+    if (zb > 1024) zb = 1024;
+    hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, counts, nbuckets);
+    hipLaunchKernelGGL(msm_zero_kernel, dim3(1), dim3(64), 0, s, n_large, 4u);
+    ICICLE_TRY(check_launch("msm_zero"));
+  }
   // buckets never touched by step 4 (large ones are written by 4b; all others by 4): no memset needed
 
   hipEvent_t ev[4];
@@ -445,7 +459,7 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
 
   hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((nbuckets + 255) / 256), dim3(256), 0, s, sb.ptr<A>(), sorted, offsets, counts, nbuckets, large_thr, mont_pt, buckets);
   ICICLE_TRY(check_launch("msm_accumulate"));
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(512), dim3(256), 256 * sizeof(X), s, sb.ptr<A>(), sorted, offsets, counts, n_large, large_list, large_cap, mont_pt, buckets);
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(512), dim3(rb_max), rb_max * sizeof(X), s, sb.ptr<A>(), sorted, offsets, counts, n_large, large_list, large_cap, mont_pt, buckets);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   if (profile) (void)hipEventRecord(ev[2], s);
 
@@ -455,10 +469,10 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   ICICLE_TRY(check_launch("msm_tail"));
   if (profile) (void)hipEventRecord(ev[3], s);
 
-  HIP_TRY(hipFreeAsync(counts, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(hipFreeAsync(sorted, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(hipFreeAsync(buckets, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(hipFreeAsync(partials, s), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(ws_free(counts, s), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(ws_free(sorted, s), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(ws_free(buckets, s), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(ws_free(partials, s), ICICLE_DEALLOCATION_FAILED);
   ICICLE_TRY(sr.finish());
   if (profile) {
     HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
@@ -483,9 +497,9 @@ eIcicleError generator_mul_impl(const bn254_scalar_t* sc, uint64_t n, hipStream_
   X* table = nullptr;
   P* proj = nullptr;
   typename F::T* scratch = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&table, 32 * 255 * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(hipMallocAsync((void**)&proj, n * sizeof(P), s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(hipMallocAsync((void**)&scratch, n * sizeof(typename F::T), s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(ws_alloc((void**)&table, 32 * 255 * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(ws_alloc((void**)&proj, n * sizeof(P), s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(ws_alloc((void**)&scratch, n * sizeof(typename F::T), s), ICICLE_ALLOCATION_FAILED);
   A gm = C::aff_to_mont(gen_std);
   hipLaunchKernelGGL((fixed_base_table_kernel<C>), dim3(1), dim3(256), 0, s, gm, table);
   ICICLE_TRY(check_launch("fixed_base_table"));
@@ -495,9 +509,9 @@ eIcicleError generator_mul_impl(const bn254_scalar_t* sc, uint64_t n, hipStream_
   const uint64_t nthreads = (n + chunk - 1) / chunk;
   hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, proj, n, chunk, reinterpret_cast<A*>(out), scratch);
   ICICLE_TRY(check_launch("batch_to_affine"));
-  HIP_TRY(hipFreeAsync(table, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(hipFreeAsync(proj, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(hipFreeAsync(scratch, s), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(ws_free(table, s), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(ws_free(proj, s), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(ws_free(scratch, s), ICICLE_DEALLOCATION_FAILED);
   return ICICLE_SUCCESS;
 }
 

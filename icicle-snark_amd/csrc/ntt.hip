@@ -255,7 +255,7 @@ ISNARK_API eIcicleError bn254_ntt_init_domain(const bn254_scalar_t* primitive_ro
   HIP_TRY(hipMalloc(&tw, N * sizeof(fe)), ICICLE_ALLOCATION_FAILED);
   if (k > 0) {
     HIP_TRY(hipMalloc(&dpw, k * sizeof(fe)), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(hipMemcpyAsync(dpw, pw.data(), k * sizeof(fe), hipMemcpyHostToDevice, s), ICICLE_COPY_FAILED);
+    HIP_TRY(hipMemcpy(dpw, pw.data(), k * sizeof(fe), hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
   }
   hipLaunchKernelGGL(gen_twiddles_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tw, dpw, k);
   ICICLE_TRY(check_launch("gen_twiddles"));
@@ -344,9 +344,8 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
     std::vector<fe> gp(logn > 0 ? logn : 1);
     fe cur = gm;
     for (int j = 0; j < logn; j++) { gp[j] = cur; cur = Fr::sqr(cur); }
-    HIP_TRY(hipMallocAsync((void**)&d_gpow, gp.size() * sizeof(fe), s), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(hipMemcpyAsync(d_gpow, gp.data(), gp.size() * sizeof(fe), hipMemcpyHostToDevice, s), ICICLE_COPY_FAILED);
-    HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED); // gp is a host temporary
+    HIP_TRY(hipMalloc((void**)&d_gpow, gp.size() * sizeof(fe)), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMemcpy(d_gpow, gp.data(), gp.size() * sizeof(fe), hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
   }
 
   // pass plan
@@ -357,7 +356,7 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
 
   fe* scratch = nullptr;
   const bool need_pre_coset = has_coset && !inverse;
-  if (np > 1 || need_pre_coset) HIP_TRY(hipMallocAsync((void**)&scratch, total * sizeof(fe), s), ICICLE_ALLOCATION_FAILED);
+  if (np > 1 || need_pre_coset) HIP_TRY(ws_alloc((void**)&scratch, total * sizeof(fe), s), ICICLE_ALLOCATION_FAILED);
   if (need_pre_coset) {
     // x_j *= g^j into scratch, then transform from scratch
     HIP_TRY(hipMemcpyAsync(scratch, d_in, total * sizeof(fe), hipMemcpyDeviceToDevice, s), ICICLE_COPY_FAILED);
@@ -435,8 +434,11 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
     hipLaunchKernelGGL(coset_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_out, n, batch, d_gpow, logn);
     ICICLE_TRY(check_launch("coset_mul"));
   }
-  if (scratch) HIP_TRY(hipFreeAsync(scratch, s), ICICLE_DEALLOCATION_FAILED);
-  if (d_gpow) HIP_TRY(hipFreeAsync(d_gpow, s), ICICLE_DEALLOCATION_FAILED);
+  if (scratch) HIP_TRY(ws_free(scratch, s), ICICLE_DEALLOCATION_FAILED);
+  if (d_gpow) {
+    HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
+    HIP_TRY(hipFree(d_gpow), ICICLE_DEALLOCATION_FAILED);
+  }
   ICICLE_TRY(sout.finish());
   return end_call(s, cfg->is_async);
 }

@@ -3,12 +3,14 @@
 //
 // * one registered device type, "HIP" (alias "CUDA"); the active device is thread-local with a
 //   process-wide default (icicle/src/device_api.cpp:87-116);
-// * streams are hipStream_t, async allocation is hipMallocAsync (stream-ordered pool);
+// * streams are hipStream_t (non-blocking); allocations are plain hipMalloc, kernel temporaries come
+//   from a per-stream workspace arena (common.h);
 // * every allocation made through this API is recorded so that icicle_is_active_device_memory()
 //   also answers for interior pointers (icicle/include/icicle/memory_tracker.h:11-55) — the Rust
 //   DeviceSlice checks this on every slice (wrappers/rust/icicle-runtime/src/memory.rs:120-125).
 #include <map>
 #include <mutex>
+#include <vector>
 #include <stdarg.h>
 #include <string.h>
 
@@ -78,6 +80,66 @@ static int identify(const void* p)
   --it;
   if ((uintptr_t)p < it->first + it->second.first) return it->second.second;
   return -1;
+}
+
+// ---- workspace arena (see common.h) -------------------------------------------------------------
+struct WsBlock {
+  void* ptr;
+  size_t size;
+  bool in_use;
+};
+static std::mutex g_ws_mu;
+static std::map<hipStream_t, std::vector<WsBlock>> g_ws;
+
+hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s)
+{
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~(size_t)255;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto& v = g_ws[s];
+  int best = -1;
+  for (size_t i = 0; i < v.size(); i++)
+    if (!v[i].in_use && v[i].size >= bytes && (best < 0 || v[i].size < v[best].size)) best = (int)i;
+  // do not hand a huge block to a tiny request: keep fragmentation bounded
+  if (best >= 0 && v[best].size <= 4 * bytes + (1 << 20)) {
+    v[best].in_use = true;
+    *p = v[best].ptr;
+    return hipSuccess;
+  }
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) {
+    // drop cached free blocks of this stream and retry once
+    for (auto it = v.begin(); it != v.end();) {
+      if (!it->in_use) { (void)hipFree(it->ptr); it = v.erase(it); } else ++it;
+    }
+    e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return e;
+  }
+  v.push_back({q, bytes, true});
+  *p = q;
+  return hipSuccess;
+}
+
+hipError_t ws_free(void* p, hipStream_t s)
+{
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto& v = g_ws[s];
+  for (auto& b : v)
+    if (b.ptr == p) {
+      b.in_use = false;
+      return hipSuccess;
+    }
+  return hipErrorInvalidValue;
+}
+
+void ws_release_stream(hipStream_t s)
+{
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto it = g_ws.find(s);
+  if (it == g_ws.end()) return;
+  for (auto& b : it->second) (void)hipFree(b.ptr);
+  g_ws.erase(it);
 }
 
 } // namespace isnark
@@ -166,7 +228,10 @@ ISNARK_API eIcicleError icicle_malloc_async(void** ptr, size_t size, icicleStrea
 {
   if (!ptr) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(require_device());
-  HIP_TRY(hipMallocAsync(ptr, size, (hipStream_t)stream), ICICLE_ALLOCATION_FAILED);
+  // Plain hipMalloc: the returned block is usable at once on any stream, which satisfies the
+  // stream-ordered contract; the stream-ordered pool is avoided (see common.h, workspace arena).
+  (void)stream;
+  HIP_TRY(hipMalloc(ptr, size), ICICLE_ALLOCATION_FAILED);
   track(*ptr, size);
   return ICICLE_SUCCESS;
 }
@@ -193,7 +258,8 @@ ISNARK_API eIcicleError icicle_free_async(void* ptr, icicleStreamHandle stream)
 {
   if (!ptr) return ICICLE_SUCCESS;
   if (!untrack(ptr)) return ICICLE_INVALID_POINTER;
-  HIP_TRY(hipFreeAsync(ptr, (hipStream_t)stream), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream), ICICLE_SYNCHRONIZATION_FAILED);
+  HIP_TRY(hipFree(ptr), ICICLE_DEALLOCATION_FAILED);
   return ICICLE_SUCCESS;
 }
 
@@ -276,6 +342,9 @@ ISNARK_API eIcicleError icicle_create_stream(icicleStreamHandle* stream)
 }
 ISNARK_API eIcicleError icicle_destroy_stream(icicleStreamHandle stream)
 {
+  // the workspace blocks cached for this stream go back to the driver with it
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
+  ws_release_stream((hipStream_t)stream);
   HIP_TRY(hipStreamDestroy((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
   return ICICLE_SUCCESS;
 }

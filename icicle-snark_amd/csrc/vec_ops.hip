@@ -38,7 +38,7 @@ __device__ __forceinline__ void st_fe(fe* p, const fe& v)
 }
 
 template <class F, int OP>
-__global__ __launch_bounds__(256) void vec_kernel(const fe* __restrict__ a, const fe* __restrict__ b, fe* __restrict__ out, uint64_t n)
+__global__ __launch_bounds__(256) void vec_kernel(const fe* a, const fe* b, fe* out, uint64_t n) // no __restrict__: in-place use is part of the API
 {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

@@ -19,11 +19,11 @@ def rand_fr(O, rng, n):
 def test_runtime_memory_tracking(gpu):
     K = gpu
     d = K.DeviceVec(1024)
-    assert K.lib().icicle_is_active_device_memory(K._p(d)) == 0
-    assert K.lib().icicle_is_active_device_memory(K._p(d.slice(512, 64))) == 0   # interior pointer
+    assert K.lib().icicle_is_active_device_memory(K.ptr_of(d)) == 0
+    assert K.lib().icicle_is_active_device_memory(K.ptr_of(d.slice(512, 64))) == 0   # interior pointer
     host = np.zeros(4, dtype=np.uint64)
-    assert K.lib().icicle_is_active_device_memory(K._p(host)) != 0
-    assert K.lib().icicle_is_host_memory(K._p(host)) == 0
+    assert K.lib().icicle_is_active_device_memory(K.ptr_of(host)) != 0
+    assert K.lib().icicle_is_host_memory(K.ptr_of(host)) == 0
     a = np.arange(128, dtype=np.uint64)
     d.copy_from_host(a)
     assert np.array_equal(d.to_host((128,)), a)
@@ -32,7 +32,7 @@ def test_runtime_memory_tracking(gpu):
     assert np.array_equal(d2.to_host((128,), stream=st), a)
     st.destroy()
     d.free(); d2.free()
-    assert K.lib().icicle_is_active_device_memory(K._p(d2)) != 0
+    assert K.lib().icicle_is_active_device_memory(K.ptr_of(d2)) != 0
 
 
 @pytest.mark.parametrize("n", [1, 5, 255, 4096, 100003])
