@@ -405,3 +405,93 @@ def ec_eq(group, a, b) -> bool:
 
 def ec_is_on_curve(group, a) -> bool:
     return bool(getattr(lib(), _PRE[group] + "is_on_curve")(ptr_of(np.ascontiguousarray(a))))
+
+
+# --------------------------------------------------------------------------------------------- prover host
+COMMITMENTS_BYTES = 576
+
+
+class Timings(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("qap_ms", C.c_double), ("msm_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+class CircuitInfo(C.Structure):
+    _fields_ = [("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32), ("n_coef", C.c_uint32),
+                ("device_bytes", C.c_uint64)]
+
+
+class ProverError(RuntimeError):
+    pass
+
+
+def _pcheck(rc, what):
+    if rc != 0:
+        lib().groth16_last_error.restype = C.c_char_p
+        msg = lib().groth16_last_error()
+        raise ProverError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+class CacheManager:
+    """CacheManager — src/cache.rs:110-262 (include/groth16_prover.h)."""
+
+    def __init__(self):
+        lib().groth16_cache_manager_new.restype = C.c_void_p
+        self._h = C.c_void_p(lib().groth16_cache_manager_new())
+
+    def close(self):
+        if self._h:
+            lib().groth16_cache_manager_free(self._h)
+            self._h = None
+
+    def contains(self, key: str) -> bool:
+        return bool(lib().groth16_cache_contains(self._h, key.encode()))
+
+    def load(self, key: str, zkey: bytes, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1):
+        buf = (C.c_char * len(zkey)).from_buffer_copy(zkey) if not isinstance(zkey, np.ndarray) else None
+        p = buf if buf is not None else zkey.ctypes.data_as(C.c_void_p)
+        _pcheck(lib().groth16_cache_load(self._h, key.encode(), p, C.c_size_t(len(zkey)), device_id, shard_rank, shard_count), "cache_load")
+
+    def load_file(self, key: str, path: str, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1):
+        _pcheck(lib().groth16_cache_load_file(self._h, key.encode(), path.encode(), device_id, shard_rank, shard_count), "cache_load_file")
+
+    def evict(self, key: str):
+        lib().groth16_cache_evict(self._h, key.encode())
+
+    def info(self, key: str) -> CircuitInfo:
+        ci = CircuitInfo()
+        _pcheck(lib().groth16_cache_info(self._h, key.encode(), C.byref(ci)), "cache_info")
+        return ci
+
+    def commitments(self, key: str, wtns: bytes):
+        """groth16_commitments (incl. construct_r1cs) for this process's shard → (576-byte block, Timings)."""
+        out = (C.c_uint8 * COMMITMENTS_BYTES)()
+        tm = Timings()
+        _pcheck(lib().groth16_commitments(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), out, C.byref(tm)), "commitments")
+        return bytes(out), tm
+
+    def assemble(self, key: str, wtns: bytes, points: bytes, r: int | None = None, s: int | None = None):
+        pj, qj = C.create_string_buffer(1 << 14), C.create_string_buffer(1 << 20)
+        rb = int(r).to_bytes(32, "little") if r is not None else None
+        sb = int(s).to_bytes(32, "little") if s is not None else None
+        _pcheck(lib().groth16_assemble_proof(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), points, rb, sb,
+                                             pj, C.c_size_t(len(pj)), qj, C.c_size_t(len(qj))), "assemble_proof")
+        return pj.value.decode(), qj.value.decode()
+
+    def prove_mem(self, key: str, wtns: bytes, r: int | None = None, s: int | None = None):
+        pj, qj = C.create_string_buffer(1 << 14), C.create_string_buffer(1 << 20)
+        rb = int(r).to_bytes(32, "little") if r is not None else None
+        sb = int(s).to_bytes(32, "little") if s is not None else None
+        tm = Timings()
+        _pcheck(lib().groth16_prove_mem(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), rb, sb, pj, C.c_size_t(len(pj)),
+                                        qj, C.c_size_t(len(qj)), C.byref(tm)), "prove_mem")
+        return pj.value.decode(), qj.value.decode(), tm
+
+    def prove(self, witness: str, zkey: str, proof: str, public: str, device: str = "HIP"):
+        """groth16_prove — src/lib.rs:33-61"""
+        _pcheck(lib().groth16_prove(witness.encode(), zkey.encode(), proof.encode(), public.encode(), device.encode(), self._h), "groth16_prove")
+
+
+def sum_commitments(blocks: bytes, count: int) -> bytes:
+    out = (C.c_uint8 * COMMITMENTS_BYTES)()
+    _pcheck(lib().groth16_sum_commitments(blocks, count, out), "sum_commitments")
+    return bytes(out)

@@ -209,6 +209,17 @@ int ilog2(uint64_t x)
 
 } // namespace
 
+namespace isnark {
+// twiddle table ω_N^i (Montgomery form) of the current domain; nullptr when none (used by the prover
+// host for the coset keys)
+const fe* ntt_domain_table(int* log_n)
+{
+  std::lock_guard<std::mutex> lk(g_dom_mu);
+  if (log_n) *log_n = g_dom.log_n;
+  return g_dom.tw;
+}
+} // namespace isnark
+
 // ------------------------------------------------------------------------------------------------ API
 ISNARK_API eIcicleError bn254_get_root_of_unity(uint64_t max_size, bn254_scalar_t* rou)
 {

@@ -1,0 +1,700 @@
+// prover.cpp — the Groth16 prover host (C++ restatement of the reference's Rust host, which cannot be
+// built here: no Rust toolchain).  It drives the same C ABI the Rust host would (bn254_msm,
+// bn254_g2_msm, bn254_ntt, host curve FFI) plus this library's fused QAP kernels.
+//
+//   groth16_prove            ← src/lib.rs:33-61
+//   CacheManager / ZKeyCache ← src/cache.rs:58-72,110-262
+//   construct_r1cs           ← src/proof_helper.rs:31-170      (on the device here: prover/qap.hip)
+//   groth16_commitments      ← src/proof_helper.rs:172-241
+//   groth16_prove_helper     ← src/proof_helper.rs:243-317
+//   snarkjs containers       ← src/file_wrapper.rs:45-208, src/zkey.rs:47-85
+//   proof / public JSON      ← src/conversions.rs:30-56, src/file_wrapper.rs:105-113
+//
+// Deliberate differences from the reference host (SURVEY.md §3.1 "reference inefficiencies"):
+//  * A/B evaluation (sparse mat-vec) runs on the GPU from a CSR built once per zkey; there is no host
+//    gather, no serial host scatter-add and no D2H/H2D round trip of n_coef elements per proof;
+//  * zkey points stay in the Montgomery form the file already has (are_points_montgomery_form = true),
+//    so cache construction needs no conversion pass over ~1 GB of points;
+//  * the NTT domain is sized 2·domain_size so that the coset keys g^i (g = ω_2n, src/cache.rs:183-184,
+//    264-289) are read from the twiddle table instead of a separate array + CWD file cache.
+#include <chrono>
+#include <fcntl.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+
+#include "../../../include/groth16_prover.h"
+#include "../common.h"
+#include "../ec.h"
+#include "qap.h"
+
+using namespace bn254;
+using namespace isnark;
+
+namespace isnark {
+const fe* ntt_domain_table(int* log_n); // ntt.hip
+}
+
+namespace {
+
+thread_local char g_perr[512] = "";
+int fail(int code, const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_perr, sizeof g_perr, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define P_HIP(call)                                                                                                    \
+  do {                                                                                                                 \
+    hipError_t e__ = (call);                                                                                           \
+    if (e__ != hipSuccess) return fail((int)ICICLE_UNKNOWN_ERROR, "%s: %s", #call, hipGetErrorString(e__));            \
+  } while (0)
+#define P_ICICLE(call)                                                                                                 \
+  do {                                                                                                                 \
+    eIcicleError e__ = (call);                                                                                         \
+    if (e__ != ICICLE_SUCCESS) return fail((int)e__, "%s failed (%d): %s", #call, (int)e__, icicle_snark_last_error()); \
+  } while (0)
+
+enum { ERR_IO = -1, ERR_FORMAT = -2, ERR_ARG = -3, ERR_NOCACHE = -4 };
+
+// ------------------------------------------------------------------------------------------------ containers
+struct Section {
+  const uint8_t* p = nullptr;
+  uint64_t size = 0;
+  int count = 0;
+};
+// FileWrapper::read_bin_file — src/file_wrapper.rs:45-103
+int read_sections(const uint8_t* data, size_t len, const char* type, uint32_t max_version, std::vector<Section>& out)
+{
+  if (len < 12 || memcmp(data, type, 4) != 0) return fail(ERR_FORMAT, "Invalid File format (expected '%s')", type);
+  uint32_t version, nsec;
+  memcpy(&version, data + 4, 4);
+  memcpy(&nsec, data + 8, 4);
+  if (version > max_version) return fail(ERR_FORMAT, "Version not supported");
+  out.assign(nsec + 1 > 16 ? nsec + 1 : 16, Section());
+  size_t pos = 12;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > len) return fail(ERR_FORMAT, "truncated section table");
+    uint32_t ht;
+    uint64_t hl;
+    memcpy(&ht, data + pos, 4);
+    memcpy(&hl, data + pos + 4, 8);
+    pos += 12;
+    if (pos + hl > len) return fail(ERR_FORMAT, "section %u exceeds the file", ht);
+    if (ht < out.size()) {
+      out[ht].p = data + pos;
+      out[ht].size = hl;
+      out[ht].count++;
+    }
+    pos += hl;
+  }
+  return 0;
+}
+int unique_section(const std::vector<Section>& s, size_t id, const Section** sec)
+{
+  if (id >= s.size() || s[id].count == 0) return fail(ERR_FORMAT, "Missing section %zu", id);
+  if (s[id].count > 1) return fail(ERR_FORMAT, "Section Duplicated %zu", id);
+  *sec = &s[id];
+  return 0;
+}
+
+struct MappedFile {
+  const uint8_t* data = nullptr;
+  size_t len = 0;
+  int fd = -1;
+  ~MappedFile()
+  {
+    if (data) munmap((void*)data, len);
+    if (fd >= 0) close(fd);
+  }
+  int open_ro(const char* path)
+  {
+    fd = ::open(path, O_RDONLY); // the reference opens read-write although it only reads (file_wrapper.rs:50-54)
+    if (fd < 0) return fail(ERR_IO, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) return fail(ERR_IO, "cannot stat %s", path);
+    len = (size_t)st.st_size;
+    void* p = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (p == MAP_FAILED) return fail(ERR_IO, "cannot mmap %s", path);
+    data = (const uint8_t*)p;
+    return 0;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ cache
+struct Wtns {
+  uint32_t n8 = 0, n_witness = 0;
+  fe q;
+  const uint8_t* values = nullptr; // n_witness × 32 B standard form
+};
+// read_wtns_header + section 2 — src/file_wrapper.rs:169-177, src/proof_helper.rs:247-268
+int parse_wtns(const uint8_t* data, size_t len, Wtns& w)
+{
+  std::vector<Section> s;
+  if (int rc = read_sections(data, len, "wtns", 2, s)) return rc;
+  const Section *h, *v;
+  if (int rc = unique_section(s, 1, &h)) return rc;
+  if (int rc = unique_section(s, 2, &v)) return rc;
+  if (h->size < 8) return fail(ERR_FORMAT, "wtns header too short");
+  memcpy(&w.n8, h->p, 4);
+  if (w.n8 != 32 || h->size != 4 + 32 + 4) return fail(ERR_FORMAT, "wtns: unsupported field size %u", w.n8);
+  memcpy(w.q.l, h->p + 4, 32);
+  memcpy(&w.n_witness, h->p + 36, 4);
+  if (v->size != (uint64_t)w.n_witness * 32) return fail(ERR_FORMAT, "wtns: section 2 size mismatch");
+  w.values = v->p;
+  return 0;
+}
+
+struct Shard {
+  uint32_t lo = 0, hi = 0; // [lo, hi) of the full base array
+  void* d_points = nullptr;
+  uint32_t len() const { return hi - lo; }
+};
+
+struct ZKeyCache {
+  // header — src/zkey.rs:6-21
+  uint32_t n8q = 0, n8r = 0, n_vars = 0, n_public = 0, domain_size = 0, n_coef = 0;
+  fe q, r;
+  G1::P vk_alpha_1, vk_beta_1, vk_delta_1; // standard form projective (host)
+  G2::P vk_beta_2, vk_gamma_2, vk_delta_2;
+  // device
+  int device_id = 0, shard_rank = 0, shard_count = 1;
+  uint32_t* d_rowptr = nullptr; // 2n+1
+  uint32_t* d_cols = nullptr;   // n_coef
+  fe* d_vals = nullptr;         // n_coef, Montgomery form
+  Shard A, B1, B2, C, H;
+  fe* d_witness = nullptr; // n_vars
+  fe* d_vec = nullptr;     // 3n
+  uint8_t* d_results = nullptr; // 576 B
+  uint8_t* h_results = nullptr; // pinned
+  fe* h_witness = nullptr;      // pinned staging, n_vars
+  hipStream_t s_g1 = nullptr, s_g2 = nullptr;
+  hipEvent_t ev_witness = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t device_bytes = 0;
+
+  ~ZKeyCache()
+  {
+    (void)hipSetDevice(device_id);
+    if (s_g1) (void)hipStreamSynchronize(s_g1);
+    if (s_g2) (void)hipStreamSynchronize(s_g2);
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_results})
+      if (p) (void)hipFree(p);
+    if (h_results) (void)hipHostFree(h_results);
+    if (h_witness) (void)hipHostFree(h_witness);
+    if (s_g1) (void)icicle_destroy_stream(s_g1);
+    if (s_g2) (void)icicle_destroy_stream(s_g2);
+    if (ev_witness) (void)hipEventDestroy(ev_witness);
+    for (auto e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
+
+G1::P g1_from_mont_affine(const uint8_t* p)
+{
+  G1::A a;
+  memcpy(&a, p, 64);
+  if (G1::aff_is_zero(a)) return {Fq::zero(), Fq::one_std(), Fq::zero()};
+  return {Fq::from_mont(a.x), Fq::from_mont(a.y), Fq::one_std()};
+}
+G2::P g2_from_mont_affine(const uint8_t* p)
+{
+  G2::A a;
+  memcpy(&a, p, 128);
+  fe2 one = {Fq::one_std(), Fq::zero()};
+  if (G2::aff_is_zero(a)) return {Fq2Ops::zero(), one, Fq2Ops::zero()};
+  return {Fq2Ops::from_mont(a.x), Fq2Ops::from_mont(a.y), one};
+}
+
+int upload_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, int rank, int count, uint64_t& bytes)
+{
+  if (sec->size != (uint64_t)total * elem) return fail(ERR_FORMAT, "zkey: point section size mismatch");
+  sh.lo = (uint32_t)((uint64_t)total * rank / count);
+  sh.hi = (uint32_t)((uint64_t)total * (rank + 1) / count);
+  const size_t n = (size_t)sh.len() * elem;
+  P_HIP(hipMalloc(&sh.d_points, n ? n : 256));
+  if (n) P_HIP(hipMemcpy(sh.d_points, sec->p + (size_t)sh.lo * elem, n, hipMemcpyHostToDevice));
+  bytes += n;
+  return 0;
+}
+
+// CacheManager::compute — src/cache.rs:117-241
+int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out)
+{
+  if (count < 1 || rank < 0 || rank >= count) return fail(ERR_ARG, "bad shard %d/%d", rank, count);
+  IcicleDevice dev;
+  memset(&dev, 0, sizeof dev);
+  strcpy(dev.type, "HIP");
+  dev.id = device_id;
+  P_ICICLE(icicle_set_device(&dev));
+
+  std::vector<Section> s;
+  if (int rc = read_sections(data, len, "zkey", 2, s)) return rc;
+  const Section *s1, *s2, *s4, *s5, *s6, *s7, *s8, *s9;
+  if (int rc = unique_section(s, 1, &s1)) return rc;
+  uint32_t protocol = 0;
+  if (s1->size >= 4) memcpy(&protocol, s1->p, 4);
+  if (protocol != 1) return fail(ERR_FORMAT, "Protocol not supported"); // GROTH16_PROTOCOL_ID, file_wrapper.rs:12,196-207
+  if (int rc = unique_section(s, 2, &s2)) return rc;
+  if (int rc = unique_section(s, 4, &s4)) return rc;
+  if (int rc = unique_section(s, 5, &s5)) return rc;
+  if (int rc = unique_section(s, 6, &s6)) return rc;
+  if (int rc = unique_section(s, 7, &s7)) return rc;
+  if (int rc = unique_section(s, 8, &s8)) return rc;
+  if (int rc = unique_section(s, 9, &s9)) return rc;
+
+  std::unique_ptr<ZKeyCache> z(new ZKeyCache());
+  z->device_id = device_id;
+  z->shard_rank = rank;
+  z->shard_count = count;
+  // read_header_groth16 — src/zkey.rs:47-85
+  const uint8_t* h = s2->p;
+  if (s2->size < 4 + 32 + 4 + 32 + 12 + 3 * 64 + 3 * 128) return fail(ERR_FORMAT, "zkey header too short");
+  memcpy(&z->n8q, h, 4);
+  if (z->n8q != 32) return fail(ERR_FORMAT, "zkey: unsupported base field size");
+  memcpy(z->q.l, h + 4, 32);
+  memcpy(&z->n8r, h + 36, 4);
+  if (z->n8r != 32) return fail(ERR_FORMAT, "zkey: unsupported scalar field size");
+  memcpy(z->r.l, h + 40, 32);
+  memcpy(&z->n_vars, h + 72, 4);
+  memcpy(&z->n_public, h + 76, 4);
+  memcpy(&z->domain_size, h + 80, 4);
+  if (!Fq::eq(z->q, Fq::modulus()) || !Fr::eq(z->r, Fr::modulus())) return fail(ERR_FORMAT, "zkey: not a BN254 key");
+  const uint32_t n = z->domain_size;
+  if (n == 0 || (n & (n - 1))) return fail(ERR_FORMAT, "zkey: domain size %u is not a power of two", n);
+  if (z->n_public + 1 > z->n_vars) return fail(ERR_FORMAT, "zkey: n_public exceeds n_vars");
+  const uint8_t* pp = h + 84;
+  z->vk_alpha_1 = g1_from_mont_affine(pp);
+  z->vk_beta_1 = g1_from_mont_affine(pp + 64);
+  z->vk_beta_2 = g2_from_mont_affine(pp + 128);
+  z->vk_gamma_2 = g2_from_mont_affine(pp + 256);
+  z->vk_delta_1 = g1_from_mont_affine(pp + 384);
+  z->vk_delta_2 = g2_from_mont_affine(pp + 448);
+
+  // coefficients (section 4): {m:u32 c:u32 s:u32 value[32]} — src/cache.rs:126-166 (only byte 0 of m is read, :159)
+  const size_t rec = 12 + 32;
+  if (s4->size < 4 || (s4->size - 4) % rec) return fail(ERR_FORMAT, "zkey: coefficient section size");
+  const uint32_t n_coef = (uint32_t)((s4->size - 4) / rec);
+  z->n_coef = n_coef;
+  std::vector<uint32_t> rowptr(2 * (size_t)n + 2, 0), cols(n_coef ? n_coef : 1), order(n_coef ? n_coef : 1);
+  const uint8_t* cp = s4->p + 4;
+  for (uint32_t i = 0; i < n_coef; i++) {
+    const uint8_t* e = cp + (size_t)i * rec;
+    uint32_t c, sidx;
+    memcpy(&c, e + 4, 4);
+    memcpy(&sidx, e + 8, 4);
+    const uint32_t m = e[0];
+    if (m > 1 || c >= n || sidx >= z->n_vars) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", i);
+    rowptr[(size_t)m * n + c + 1]++;
+  }
+  for (size_t i = 0; i < 2 * (size_t)n; i++) rowptr[i + 1] += rowptr[i];
+  {
+    std::vector<uint32_t> cur(rowptr.begin(), rowptr.end() - 1);
+    std::vector<fe> vals(n_coef ? n_coef : 1);
+    for (uint32_t i = 0; i < n_coef; i++) {
+      const uint8_t* e = cp + (size_t)i * rec;
+      uint32_t c, sidx;
+      memcpy(&c, e + 4, 4);
+      memcpy(&sidx, e + 8, 4);
+      const uint32_t pos = cur[(size_t)e[0] * n + c]++;
+      cols[pos] = sidx;
+      memcpy(vals[pos].l, e + 12, 32);
+    }
+    P_HIP(hipMalloc((void**)&z->d_rowptr, (2 * (size_t)n + 1) * 4));
+    P_HIP(hipMalloc((void**)&z->d_cols, (size_t)(n_coef ? n_coef : 1) * 4));
+    P_HIP(hipMalloc((void**)&z->d_vals, (size_t)(n_coef ? n_coef : 1) * 32));
+    P_HIP(hipMemcpy(z->d_rowptr, rowptr.data(), (2 * (size_t)n + 1) * 4, hipMemcpyHostToDevice));
+    P_HIP(hipMemcpy(z->d_cols, cols.data(), (size_t)n_coef * 4, hipMemcpyHostToDevice));
+    P_HIP(hipMemcpy(z->d_vals, vals.data(), (size_t)n_coef * 32, hipMemcpyHostToDevice));
+    z->device_bytes += (2 * (size_t)n + 1) * 4 + (size_t)n_coef * 36;
+    // the file stores value·R² ; one from_mont (src/cache.rs:214) leaves value·R = Montgomery form of the coefficient
+    VecOpsConfig vc;
+    memset(&vc, 0, sizeof vc);
+    vc.is_a_on_device = vc.is_result_on_device = true;
+    vc.batch_size = 1;
+    P_ICICLE(bn254_scalar_convert_montgomery((const bn254_scalar_t*)z->d_vals, n_coef, false, &vc, (bn254_scalar_t*)z->d_vals));
+  }
+
+  // bases (sections 5-9), this process's point range only
+  if (int rc = upload_shard(z->A, s5, 64, z->n_vars, rank, count, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->B1, s6, 64, z->n_vars, rank, count, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->B2, s7, 128, z->n_vars, rank, count, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->C, s8, 64, z->n_vars - z->n_public - 1, rank, count, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->H, s9, 64, n, rank, count, z->device_bytes)) return rc;
+
+  P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
+  P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
+  P_HIP(hipMalloc((void**)&z->d_results, GROTH16_COMMITMENTS_BYTES));
+  P_HIP(hipHostMalloc((void**)&z->h_results, GROTH16_COMMITMENTS_BYTES));
+  P_HIP(hipHostMalloc((void**)&z->h_witness, (size_t)z->n_vars * 32));
+  z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
+  P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
+  for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
+  out = std::move(z);
+  return 0;
+}
+
+} // namespace
+
+struct Groth16CacheManager {
+  std::mutex mu;
+  std::map<std::string, std::unique_ptr<ZKeyCache>> cache;
+  uint32_t domain_n = 0; // domain_size the NTT domain was last initialised for (get_cache, src/cache.rs:242-256)
+};
+
+namespace {
+
+// get_cache — src/cache.rs:242-256: (re)initialise the NTT domain for this key.  Sized 2·domain_size here
+// (see file header); the reference sizes it from points_a.len() (a quirk).
+int ensure_domain(Groth16CacheManager* cm, const ZKeyCache* z)
+{
+  if (cm->domain_n == z->domain_size) {
+    int lg = 0;
+    if (ntt_domain_table(&lg) && (1u << lg) >= 2 * z->domain_size) return 0;
+  }
+  P_ICICLE(bn254_ntt_release_domain());
+  bn254_scalar_t root;
+  P_ICICLE(bn254_get_root_of_unity(2ull * z->domain_size, &root));
+  NTTInitDomainConfig ic;
+  memset(&ic, 0, sizeof ic);
+  P_ICICLE(bn254_ntt_init_domain(&root, &ic));
+  cm->domain_n = z->domain_size;
+  return 0;
+}
+
+double ms_since(std::chrono::steady_clock::time_point t0)
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int msm_call(bool g2, const fe* scalars, const void* points, uint32_t len, hipStream_t s, void* d_result)
+{
+  MSMConfig c;
+  memset(&c, 0, sizeof c);
+  c.stream = s;
+  c.precompute_factor = 1;
+  c.batch_size = 1;
+  c.are_points_shared_in_batch = true;
+  c.are_scalars_on_device = c.are_points_on_device = c.are_results_on_device = true;
+  c.are_points_montgomery_form = true; // zkey points are kept as stored
+  c.is_async = true;
+  if (g2) P_ICICLE(bn254_g2_msm((const bn254_scalar_t*)scalars, (const bn254_g2_affine_t*)points, (int)len, &c, (bn254_g2_projective_t*)d_result));
+  else P_ICICLE(bn254_msm((const bn254_scalar_t*)scalars, (const bn254_affine_t*)points, (int)len, &c, (bn254_projective_t*)d_result));
+  return 0;
+}
+
+ZKeyCache* find(Groth16CacheManager* cm, const char* key)
+{
+  auto it = cm->cache.find(key ? key : "");
+  return it == cm->cache.end() ? nullptr : it->second.get();
+}
+
+// ------------------------------------------------------------------------------------------------ JSON
+std::string to_decimal(const fe& v) // BigUint::to_str_radix(10) — src/conversions.rs:30-40
+{
+  uint32_t w[8];
+  memcpy(w, v.l, 32);
+  std::string out;
+  bool nz = true;
+  while (nz) {
+    uint64_t rem = 0;
+    nz = false;
+    for (int i = 7; i >= 0; i--) {
+      uint64_t cur = (rem << 32) | w[i];
+      w[i] = (uint32_t)(cur / 1000000000u);
+      rem = cur % 1000000000u;
+      if (w[i]) nz = true;
+    }
+    char buf[16];
+    snprintf(buf, sizeof buf, nz ? "%09u" : "%u", (unsigned)rem);
+    out.insert(0, buf);
+  }
+  return out;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ C API
+extern "C" {
+
+__attribute__((visibility("default"))) const char* groth16_last_error(void) { return g_perr; }
+
+__attribute__((visibility("default"))) Groth16CacheManager* groth16_cache_manager_new(void) { return new Groth16CacheManager(); }
+__attribute__((visibility("default"))) void groth16_cache_manager_free(Groth16CacheManager* cm) { delete cm; }
+
+__attribute__((visibility("default"))) int groth16_cache_contains(const Groth16CacheManager* cm, const char* key)
+{
+  return cm && cm->cache.count(key ? key : "") ? 1 : 0;
+}
+__attribute__((visibility("default"))) void groth16_cache_evict(Groth16CacheManager* cm, const char* key)
+{
+  if (cm) cm->cache.erase(key ? key : "");
+}
+
+__attribute__((visibility("default"))) int groth16_cache_load(Groth16CacheManager* cm, const char* key, const void* zkey, size_t zkey_len, int device_id, int shard_rank, int shard_count)
+{
+  if (!cm || !key || !zkey) return fail(ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(cm->mu);
+  if (cm->cache.count(key)) return 0;
+  std::unique_ptr<ZKeyCache> z;
+  if (int rc = build_cache((const uint8_t*)zkey, zkey_len, device_id, shard_rank, shard_count, z)) return rc;
+  cm->cache[key] = std::move(z);
+  return 0;
+}
+
+__attribute__((visibility("default"))) int groth16_cache_load_file(Groth16CacheManager* cm, const char* key, const char* zkey_path, int device_id, int shard_rank, int shard_count)
+{
+  if (!cm || !key || !zkey_path) return fail(ERR_ARG, "null argument");
+  if (groth16_cache_contains(cm, key)) return 0;
+  MappedFile f;
+  if (int rc = f.open_ro(zkey_path)) return rc;
+  return groth16_cache_load(cm, key, f.data, f.len, device_id, shard_rank, shard_count);
+}
+
+__attribute__((visibility("default"))) int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16CircuitInfo* info)
+{
+  if (!cm || !info) return fail(ERR_ARG, "null argument");
+  auto it = cm->cache.find(key ? key : "");
+  if (it == cm->cache.end()) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  const ZKeyCache* z = it->second.get();
+  info->n_vars = z->n_vars;
+  info->n_public = z->n_public;
+  info->domain_size = z->domain_size;
+  info->n_coef = z->n_coef;
+  info->device_bytes = z->device_bytes;
+  return 0;
+}
+
+__attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, uint8_t out_points[GROTH16_COMMITMENTS_BYTES], Groth16Timings* tm)
+{
+  if (!cm || !wtns || !out_points) return fail(ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(cm->mu);
+  ZKeyCache* z = find(cm, key);
+  if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  const auto t0 = std::chrono::steady_clock::now();
+  IcicleDevice dev;
+  memset(&dev, 0, sizeof dev);
+  strcpy(dev.type, "HIP");
+  dev.id = z->device_id;
+  P_ICICLE(icicle_set_device(&dev));
+  if (int rc = ensure_domain(cm, z)) return rc;
+
+  Wtns w;
+  if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
+  // src/proof_helper.rs:253-262
+  if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
+  if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
+
+  const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
+  hipStream_t g1 = z->s_g1, g2 = z->s_g2;
+  // witness → pinned staging → device (stream g1), B2 MSM (stream g2) waits on the upload only
+  memcpy(z->h_witness, w.values, (size_t)nv * 32);
+  P_HIP(hipEventRecord(z->ev[0], g1));
+  P_HIP(hipMemcpyAsync(z->d_witness, z->h_witness, (size_t)nv * 32, hipMemcpyHostToDevice, g1));
+  P_HIP(hipEventRecord(z->ev_witness, g1));
+  P_HIP(hipEventRecord(z->ev[1], g1));
+  P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));
+  uint8_t* R = z->d_results;
+  // commitment_b (G2) on its own stream — src/proof_helper.rs:206
+  if (int rc = msm_call(true, z->d_witness + z->B2.lo, z->B2.d_points, z->B2.len(), g2, R + 192)) return rc;
+
+  // construct_r1cs on stream g1
+  P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, g1));
+  NTTConfig nc;
+  memset(&nc, 0, sizeof nc);
+  nc.stream = g1;
+  nc.coset_gen.limbs[0] = 1;
+  nc.batch_size = 3;
+  nc.ordering = kNN;
+  nc.are_inputs_on_device = nc.are_outputs_on_device = true;
+  nc.is_async = true;
+  P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
+  int dom_log = 0;
+  const fe* tw = ntt_domain_table(&dom_log);
+  P_HIP(qap_coset_mul3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, g1));                                   // :121-141
+  P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kForward, &nc, (bn254_scalar_t*)z->d_vec)); // :145
+  P_HIP(qap_final(z->d_vec, n, g1));                                                                        // :154-167
+  P_HIP(hipEventRecord(z->ev[2], g1));
+
+  // groth16_commitments — src/proof_helper.rs:198-205 : A, B1, C, H on stream g1
+  if (int rc = msm_call(false, z->d_witness + z->A.lo, z->A.d_points, z->A.len(), g1, R + 0)) return rc;
+  if (int rc = msm_call(false, z->d_witness + z->B1.lo, z->B1.d_points, z->B1.len(), g1, R + 96)) return rc;
+  if (int rc = msm_call(false, z->d_witness + npub + 1 + z->C.lo, z->C.d_points, z->C.len(), g1, R + 384)) return rc;
+  if (int rc = msm_call(false, z->d_vec + n + z->H.lo, z->H.d_points, z->H.len(), g1, R + 480)) return rc;
+  // join g2 into g1, one D2H of all five results
+  P_HIP(hipEventRecord(z->ev_witness, g2));
+  P_HIP(hipStreamWaitEvent(g1, z->ev_witness, 0));
+  P_HIP(hipEventRecord(z->ev[3], g1));
+  P_HIP(hipMemcpyAsync(z->h_results, R, GROTH16_COMMITMENTS_BYTES, hipMemcpyDeviceToHost, g1));
+  P_HIP(hipStreamSynchronize(g1));
+  memcpy(out_points, z->h_results, GROTH16_COMMITMENTS_BYTES);
+  if (tm) {
+    float a = 0, b = 0, c = 0;
+    (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
+    (void)hipEventElapsedTime(&b, z->ev[1], z->ev[2]);
+    (void)hipEventElapsedTime(&c, z->ev[2], z->ev[3]);
+    tm->h2d_ms = a;
+    tm->qap_ms = b;
+    tm->msm_ms = c;
+    tm->total_ms = ms_since(t0);
+  }
+  return 0;
+}
+
+__attribute__((visibility("default"))) int groth16_sum_commitments(const uint8_t* blocks, int count, uint8_t out[GROTH16_COMMITMENTS_BYTES])
+{
+  if (!blocks || !out || count < 1) return fail(ERR_ARG, "bad argument");
+  uint8_t acc[GROTH16_COMMITMENTS_BYTES];
+  memcpy(acc, blocks, sizeof acc);
+  static const int off[5] = {0, 96, 192, 384, 480};
+  for (int k = 1; k < count; k++) {
+    const uint8_t* b = blocks + (size_t)k * GROTH16_COMMITMENTS_BYTES;
+    for (int j = 0; j < 5; j++) {
+      if (j == 2) bn254_g2_ecadd((const bn254_g2_projective_t*)(acc + off[j]), (const bn254_g2_projective_t*)(b + off[j]), (bn254_g2_projective_t*)(acc + off[j]));
+      else bn254_ecadd((const bn254_projective_t*)(acc + off[j]), (const bn254_projective_t*)(b + off[j]), (bn254_projective_t*)(acc + off[j]));
+    }
+  }
+  memcpy(out, acc, sizeof acc);
+  return 0;
+}
+
+__attribute__((visibility("default"))) int groth16_assemble_proof(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, const uint8_t points[GROTH16_COMMITMENTS_BYTES],
+                                                                  const uint8_t* r_in, const uint8_t* s_in, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap)
+{
+  if (!cm || !wtns || !points) return fail(ERR_ARG, "null argument");
+  ZKeyCache* z = find(cm, key);
+  if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  Wtns w;
+  if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
+  if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length");
+  typedef bn254_projective_t P1;
+  typedef bn254_g2_projective_t P2;
+  P1 pi_a, pi_b1, pi_c, pi_h, t1, t2;
+  P2 pi_b, u1;
+  memcpy(&pi_a, points, 96);
+  memcpy(&pi_b1, points + 96, 96);
+  memcpy(&pi_b, points + 192, 192);
+  memcpy(&pi_c, points + 384, 96);
+  memcpy(&pi_h, points + 480, 96);
+  bn254_scalar_t rs[2], r, s, rsprod;
+  if (!r_in || !s_in) bn254_generate_scalars(rs, 2); // ScalarCfg::generate_random(2) — src/proof_helper.rs:276
+  if (r_in) memcpy(&rs[0], r_in, 32);
+  if (s_in) memcpy(&rs[1], s_in, 32);
+  r = rs[0];
+  s = rs[1];
+  const P1* alpha1 = (const P1*)&z->vk_alpha_1;
+  const P1* beta1 = (const P1*)&z->vk_beta_1;
+  const P1* delta1 = (const P1*)&z->vk_delta_1;
+  const P2* beta2 = (const P2*)&z->vk_beta_2;
+  const P2* delta2 = (const P2*)&z->vk_delta_2;
+  // src/proof_helper.rs:280-283
+  bn254_mul_scalar(delta1, &r, &t1);            // δ1·r
+  bn254_ecadd(&pi_a, alpha1, &pi_a);
+  bn254_ecadd(&pi_a, &t1, &pi_a);               // pi_a = A + α1 + δ1·r
+  bn254_g2_mul_scalar(delta2, &s, &u1);
+  bn254_g2_ecadd(&pi_b, beta2, &pi_b);
+  bn254_g2_ecadd(&pi_b, &u1, &pi_b);            // pi_b = B2 + β2 + δ2·s
+  bn254_mul_scalar(delta1, &s, &t2);
+  bn254_ecadd(&pi_b1, beta1, &pi_b1);
+  bn254_ecadd(&pi_b1, &t2, &pi_b1);             // pi_b1 = B1 + β1 + δ1·s
+  bn254_ecadd(&pi_c, &pi_h, &pi_c);             // C + H
+  bn254_mul_scalar(&pi_a, &s, &t2);
+  bn254_ecadd(&pi_c, &t2, &pi_c);               // + pi_a·s
+  bn254_mul_scalar(&pi_b1, &r, &t2);
+  bn254_ecadd(&pi_c, &t2, &pi_c);               // + pi_b1·r
+  bn254_mul_scalar(&t1, &s, &t2);               // δ1·r·s
+  bn254_ecsub(&pi_c, &t2, &pi_c);
+  (void)rsprod;
+  bn254_affine_t a_aff, c_aff;
+  bn254_g2_affine_t b_aff;
+  bn254_to_affine(&pi_a, &a_aff);
+  bn254_g2_to_affine(&pi_b, &b_aff);
+  bn254_to_affine(&pi_c, &c_aff);
+  auto dec = [](const void* p) {
+    fe v;
+    memcpy(v.l, p, 32);
+    return to_decimal(v);
+  };
+  // serde_json::to_writer_pretty of a Value built with json!(proof): object keys sorted (BTreeMap), 2-space indent
+  std::string pj = "{\n  \"curve\": \"bn128\",\n";
+  pj += "  \"pi_a\": [\n    \"" + dec(&a_aff.x) + "\",\n    \"" + dec(&a_aff.y) + "\",\n    \"1\"\n  ],\n";
+  pj += "  \"pi_b\": [\n    [\n      \"" + dec(&b_aff.x.c0) + "\",\n      \"" + dec(&b_aff.x.c1) + "\"\n    ],\n    [\n      \"" + dec(&b_aff.y.c0) + "\",\n      \"" + dec(&b_aff.y.c1) +
+        "\"\n    ],\n    [\n      \"1\",\n      \"0\"\n    ]\n  ],\n";
+  pj += "  \"pi_c\": [\n    \"" + dec(&c_aff.x) + "\",\n    \"" + dec(&c_aff.y) + "\",\n    \"1\"\n  ],\n";
+  pj += "  \"protocol\": \"groth16\"\n}";
+  // public signals: witness[1..=n_public] as decimal strings — src/proof_helper.rs:297-307
+  std::string qj = z->n_public ? "[\n" : "[]";
+  for (uint32_t i = 1; i <= z->n_public; i++) {
+    qj += "  \"" + dec(w.values + (size_t)i * 32) + "\"";
+    qj += i == z->n_public ? "\n]" : ",\n";
+  }
+  int need = 0;
+  if (proof_json) {
+    if (pj.size() + 1 > proof_cap) need = (int)pj.size() + 1;
+    else memcpy(proof_json, pj.c_str(), pj.size() + 1);
+  }
+  if (public_json) {
+    if (qj.size() + 1 > public_cap) need = need > (int)qj.size() + 1 ? need : (int)qj.size() + 1;
+    else memcpy(public_json, qj.c_str(), qj.size() + 1);
+  }
+  if (need) return fail(need, "output buffer too small (need %d bytes)", need);
+  return 0;
+}
+
+__attribute__((visibility("default"))) int groth16_prove_mem(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, const uint8_t* r, const uint8_t* s, char* proof_json, size_t proof_cap,
+                                                             char* public_json, size_t public_cap, Groth16Timings* tm)
+{
+  uint8_t pts[GROTH16_COMMITMENTS_BYTES];
+  const auto t0 = std::chrono::steady_clock::now();
+  if (int rc = groth16_commitments(cm, key, wtns, wtns_len, pts, tm)) return rc;
+  int rc = groth16_assemble_proof(cm, key, wtns, wtns_len, pts, r, s, proof_json, proof_cap, public_json, public_cap);
+  if (tm) tm->total_ms = ms_since(t0);
+  return rc;
+}
+
+// groth16_prove — src/lib.rs:33-61
+__attribute__((visibility("default"))) int groth16_prove(const char* witness_path, const char* zkey_path, const char* proof_path, const char* public_path, const char* device, Groth16CacheManager* cm)
+{
+  if (!witness_path || !zkey_path || !proof_path || !public_path || !device || !cm) return fail(ERR_ARG, "null argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  // try_load_and_set_backend_device — src/lib.rs:25-31
+  IcicleDevice dev;
+  memset(&dev, 0, sizeof dev);
+  strncpy(dev.type, device, sizeof dev.type - 1);
+  dev.id = 0;
+  if (strcmp(device, "CPU") != 0) P_ICICLE(icicle_load_backend_from_env_or_default());
+  P_ICICLE(icicle_set_device(&dev)); // "CPU" (or anything but HIP/CUDA) fails here: no CPU fallback
+  const std::string key = std::string(zkey_path) + "_" + device; // src/lib.rs:44
+  if (!groth16_cache_contains(cm, key.c_str()))
+    if (int rc = groth16_cache_load_file(cm, key.c_str(), zkey_path, 0, 0, 1)) return rc;
+  MappedFile wf;
+  if (int rc = wf.open_ro(witness_path)) return rc;
+  std::vector<char> pj(4096), qj(256);
+  {
+    ZKeyCache* z = find(cm, key.c_str());
+    qj.resize(64 + (size_t)z->n_public * 84);
+  }
+  if (int rc = groth16_prove_mem(cm, key.c_str(), wf.data, wf.len, nullptr, nullptr, pj.data(), pj.size(), qj.data(), qj.size(), nullptr)) return rc;
+  for (int k = 0; k < 2; k++) {
+    const char* path = k ? public_path : proof_path;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(ERR_IO, "cannot write %s", path);
+    fputs(k ? qj.data() : pj.data(), f);
+    fclose(f);
+  }
+  printf("proof took: %.3fms\n", ms_since(t0)); // src/lib.rs:58
+  fflush(stdout);
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,92 @@
+/*
+ * groth16_prover.h — C API of the prover host that ships inside libicicle_snark_hip.so.
+ *
+ * The reference's host is Rust (src/lib.rs, src/proof_helper.rs, src/cache.rs); no Rust toolchain
+ * exists in this build environment, so the same host logic is provided in C++ behind this C API,
+ * with the reference's names and argument meaning:
+ *
+ *   groth16_prove(witness, zkey, proof, public, device, &mut CacheManager)   — src/lib.rs:33-61
+ *   CacheManager::{compute, get_cache, insert_cache, contains}                — src/cache.rs:110-262
+ *
+ * File formats are snarkjs `.zkey` / `.wtns` in, `proof.json` / `public.json` out
+ * (src/file_wrapper.rs:45-113, src/zkey.rs:47-85, src/conversions.rs:30-56).
+ * All functions return 0 on success, an eIcicleError code (> 0) for device errors and a negative
+ * value for I/O / format errors; groth16_last_error() gives the text.  Nothing unwinds across the ABI.
+ */
+#ifndef GROTH16_PROVER_H
+#define GROTH16_PROVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Groth16CacheManager Groth16CacheManager;
+
+/* CacheManager::default() / drop — src/cache.rs:110-115 */
+Groth16CacheManager* groth16_cache_manager_new(void);
+void groth16_cache_manager_free(Groth16CacheManager* cm);
+
+/* groth16_prove — src/lib.rs:33-61.  `device` is the reference's free-form device string; this
+ * library registers "HIP" (and the alias "CUDA"); anything else, including "CPU", is an error — there
+ * is no CPU fallback.  Blinding factors r, s are drawn at random (default build of the reference). */
+int groth16_prove(const char* witness_path, const char* zkey_path, const char* proof_path, const char* public_path,
+                  const char* device, Groth16CacheManager* cm);
+
+/* ---- finer-grained entry points used by bench.py / tests (same pipeline, memory in / memory out) ---- */
+
+/* Build (or find) the device-resident cache for a zkey image held in memory (CacheManager::compute,
+ * src/cache.rs:117-241).  `key` plays the role of "{zkey_path}_{device}" (src/lib.rs:44).
+ * shard_rank / shard_count: this process keeps only the points [rank·L/count, (rank+1)·L/count) of each of
+ * the five MSM bases (multi-GPU point-range sharding); 0 / 1 for a single GPU. */
+int groth16_cache_load(Groth16CacheManager* cm, const char* key, const void* zkey, size_t zkey_len, int device_id,
+                       int shard_rank, int shard_count);
+int groth16_cache_load_file(Groth16CacheManager* cm, const char* key, const char* zkey_path, int device_id,
+                            int shard_rank, int shard_count);
+int groth16_cache_contains(const Groth16CacheManager* cm, const char* key);
+void groth16_cache_evict(Groth16CacheManager* cm, const char* key);
+
+/* The five commitments of groth16_commitments (src/proof_helper.rs:172-241) for this process's shard,
+ * as standard-form projective points in the order A (G1, 96 B), B1 (G1, 96 B), B2 (G2, 192 B),
+ * C (G1, 96 B), H (G1, 96 B)  — 576 bytes.  Includes construct_r1cs (src/proof_helper.rs:31-170). */
+#define GROTH16_COMMITMENTS_BYTES 576
+typedef struct {
+  double h2d_ms;       /* witness upload */
+  double qap_ms;       /* construct_r1cs on the device (sparse mat-vec, 2 batched NTTs, pointwise) */
+  double msm_ms;       /* the five MSMs (two streams) */
+  double total_ms;     /* wall clock of the call */
+} Groth16Timings;
+int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len,
+                        uint8_t out_points[GROTH16_COMMITMENTS_BYTES], Groth16Timings* timings /* may be NULL */);
+
+/* Element-wise group sum of `count` commitment blocks (gathered from the shards): out = Σ_k blocks[k]. */
+int groth16_sum_commitments(const uint8_t* blocks, int count, uint8_t out_points[GROTH16_COMMITMENTS_BYTES]);
+
+/* Tail of groth16_prove_helper (src/proof_helper.rs:274-316): blinding with (r, s) — 32-byte little-endian
+ * standard-form scalars; NULL draws them at random; r = s = 1 reproduces the `no-randomness` feature —
+ * affine conversion and JSON rendering.  Outputs are NUL-terminated pretty-printed JSON texts identical
+ * in layout to serde_json::to_writer_pretty.  Returns the needed size (incl. NUL) if a buffer is too small. */
+int groth16_assemble_proof(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len,
+                           const uint8_t points[GROTH16_COMMITMENTS_BYTES], const uint8_t* r, const uint8_t* s,
+                           char* proof_json, size_t proof_cap, char* public_json, size_t public_cap);
+
+/* One-GPU convenience: commitments + assemble. */
+int groth16_prove_mem(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, const uint8_t* r,
+                      const uint8_t* s, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap,
+                      Groth16Timings* timings);
+
+/* sizes of the cached circuit */
+typedef struct {
+  uint32_t n_vars, n_public, domain_size, n_coef;
+  uint64_t device_bytes;
+} Groth16CircuitInfo;
+int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16CircuitInfo* info);
+
+const char* groth16_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
