@@ -15,7 +15,9 @@ HDRS := $(wildcard $(SRC)/*.h) $(wildcard $(SRC)/prover/*.h) include/icicle_snar
 
 LIB := $(LIBDIR)/libicicle_snark_hip.so
 
-all: $(LIB) links prove
+RCCL_LIB := $(LIBDIR)/libicicle_snark_rccl.so
+
+all: $(LIB) links prove $(RCCL_LIB)
 
 $(OBJDIR)/%.o: $(SRC)/% $(HDRS)
 	@mkdir -p $(dir $@)
@@ -29,6 +31,11 @@ $(LIB): $(OBJS)
 # (wrappers/rust/icicle-runtime/build.rs:52, icicle-bn254/build.rs:59-60): one library, three names.
 links: $(LIB)
 	@cd $(LIBDIR) && for n in icicle_device icicle_field_bn254 icicle_curve_bn254; do ln -sf libicicle_snark_hip.so lib$$n.so; done
+
+# multi-GPU exchange step (RCCL all-gather of the partial commitments); separate DSO
+$(RCCL_LIB): $(SRC)/comm/rccl_comm.cpp
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -O2 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -shared -o $@ $< -L/opt/rocm/lib -lrccl
 
 prove: $(LIB)
 	@if [ -f $(SRC)/prover/cli_main.cc ]; then \

@@ -92,6 +92,7 @@ bn254_affine_convert_montgomery bn254_g2_affine_convert_montgomery
 bn254_ntt bn254_ntt_init_domain bn254_ntt_release_domain bn254_get_root_of_unity bn254_get_root_of_unity_from_domain
 bn254_msm bn254_g2_msm
 icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
+icicle_snark_msm_profile
 """.split()
 
 _lib = None
@@ -334,6 +335,14 @@ def last_msm_timings():
     return list(out)
 
 
+def msm_profile(back: int = 0):
+    """(ms[4], dict geom) of the `back`-th most recent MSM; see include/icicle_snark_hip.h."""
+    ms = (C.c_float * 4)()
+    geom = (C.c_uint32 * 5)()
+    check(lib().icicle_snark_msm_profile(back, ms, geom), "msm_profile")
+    return list(ms), dict(L=geom[0], nbuckets=geom[1], c=geom[2], W=geom[3], is_g2=bool(geom[4]))
+
+
 def generator_mul(group: str, scalars: np.ndarray) -> np.ndarray:
     """out[i] = s[i]·G, affine standard form (extension; used by the zkey synthesiser)."""
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
@@ -462,11 +471,12 @@ class CacheManager:
         _pcheck(lib().groth16_cache_info(self._h, key.encode(), C.byref(ci)), "cache_info")
         return ci
 
-    def commitments(self, key: str, wtns: bytes):
-        """groth16_commitments (incl. construct_r1cs) for this process's shard → (576-byte block, Timings)."""
+    def commitments(self, key: str, wtns: bytes | None):
+        """groth16_commitments (incl. construct_r1cs) for this process's shard → (576-byte block, Timings).
+        wtns=None re-uses the witness already resident on the device."""
         out = (C.c_uint8 * COMMITMENTS_BYTES)()
         tm = Timings()
-        _pcheck(lib().groth16_commitments(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), out, C.byref(tm)), "commitments")
+        _pcheck(lib().groth16_commitments(self._h, key.encode(), wtns, C.c_size_t(len(wtns) if wtns else 0), out, C.byref(tm)), "commitments")
         return bytes(out), tm
 
     def assemble(self, key: str, wtns: bytes, points: bytes, r: int | None = None, s: int | None = None):

@@ -1,0 +1,107 @@
+// rccl_comm.cpp — the one exchange step of the multi-GPU prover: every rank holds the
+// five partial commitments of its point-range shard (576 B); an RCCL all-gather over xGMI gives every
+// rank all blocks, which are then summed with the curve's group law (RCCL has no EC-add reduction op, so
+// this is an all-gather of raw bytes + local adds, not an all-reduce).  Built as a separate small DSO
+// (libicicle_snark_rccl.so) so that the single-GPU library carries no RCCL dependency.
+//
+// Process model: one process per GPU (torch.distributed / torchrun provides rank, world size and the
+// rendezvous used to broadcast the ncclUniqueId); the collective itself runs on this library's HIP runtime.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define API extern "C" __attribute__((visibility("default")))
+
+namespace {
+thread_local char g_err[256] = "";
+struct Comm {
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  uint8_t* d_in = nullptr;
+  uint8_t* d_out = nullptr;
+  uint8_t* h_pin = nullptr;
+  size_t cap = 0;
+  int world = 1;
+};
+int fail(const char* what, int code)
+{
+  snprintf(g_err, sizeof g_err, "%s failed (%d)", what, code);
+  return code ? code : -1;
+}
+} // namespace
+
+API const char* icicle_snark_rccl_last_error(void) { return g_err; }
+
+// rank 0 creates the id (128 bytes) and shares it with the other ranks out of band
+API int icicle_snark_rccl_unique_id(uint8_t out[NCCL_UNIQUE_ID_BYTES])
+{
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail("ncclGetUniqueId", (int)r);
+  memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+API int icicle_snark_rccl_init(const uint8_t id_bytes[NCCL_UNIQUE_ID_BYTES], int rank, int world, int device_id, size_t max_bytes_per_rank, void** out)
+{
+  if (hipSetDevice(device_id) != hipSuccess) return fail("hipSetDevice", -1);
+  Comm* c = new Comm();
+  c->world = world;
+  c->cap = max_bytes_per_rank;
+  ncclUniqueId id;
+  memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank", (int)r); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate", -1);
+  if (hipMalloc((void**)&c->d_in, max_bytes_per_rank) != hipSuccess) return fail("hipMalloc", -1);
+  if (hipMalloc((void**)&c->d_out, max_bytes_per_rank * world) != hipSuccess) return fail("hipMalloc", -1);
+  if (hipHostMalloc((void**)&c->h_pin, max_bytes_per_rank * (world + 1)) != hipSuccess) return fail("hipHostMalloc", -1);
+  *out = c;
+  return 0;
+}
+
+// all-gather `bytes` bytes per rank: host block in → host blocks out (rank order)
+API int icicle_snark_rccl_allgather(void* comm, const void* in, size_t bytes, void* out)
+{
+  Comm* c = (Comm*)comm;
+  if (!c || bytes > c->cap) return fail("allgather: bad arguments", -1);
+  memcpy(c->h_pin, in, bytes);
+  if (hipMemcpyAsync(c->d_in, c->h_pin, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail("H2D", -1);
+  ncclResult_t r = ncclAllGather(c->d_in, c->d_out, bytes, ncclUint8, c->comm, c->stream);
+  if (r != ncclSuccess) return fail("ncclAllGather", (int)r);
+  if (hipMemcpyAsync(c->h_pin + c->cap, c->d_out, bytes * c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return fail("D2H", -1);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("sync", -1);
+  memcpy(out, c->h_pin + c->cap, bytes * c->world);
+  return 0;
+}
+
+// max over ranks of one double (used for the benchmark's max-over-ranks timing)
+API int icicle_snark_rccl_allreduce_max(void* comm, double* value)
+{
+  Comm* c = (Comm*)comm;
+  if (!c) return fail("allreduce: null comm", -1);
+  memcpy(c->h_pin, value, 8);
+  if (hipMemcpyAsync(c->d_in, c->h_pin, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail("H2D", -1);
+  ncclResult_t r = ncclAllReduce(c->d_in, c->d_out, 1, ncclDouble, ncclMax, c->comm, c->stream);
+  if (r != ncclSuccess) return fail("ncclAllReduce", (int)r);
+  if (hipMemcpyAsync(c->h_pin, c->d_out, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return fail("D2H", -1);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("sync", -1);
+  memcpy(value, c->h_pin, 8);
+  return 0;
+}
+
+API int icicle_snark_rccl_destroy(void* comm)
+{
+  Comm* c = (Comm*)comm;
+  if (!c) return 0;
+  (void)hipStreamSynchronize(c->stream);
+  ncclCommDestroy(c->comm);
+  (void)hipFree(c->d_in);
+  (void)hipFree(c->d_out);
+  (void)hipHostFree(c->h_pin);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}

@@ -41,6 +41,18 @@ using namespace bn254;
 using namespace isnark;
 
 namespace isnark {
+// ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,
+// never synchronised here) + geometry, read back by icicle_snark_msm_profile() after the caller synced.
+struct MsmProfile {
+  hipEvent_t ev[4]; // start, before accumulate, after accumulate, end
+  uint32_t L, nbuckets;
+  int c, W, is_g2;
+  bool valid;
+};
+constexpr int MSM_PROFILE_RING = 32;
+extern MsmProfile g_msm_ring[MSM_PROFILE_RING];
+extern uint64_t g_msm_seq;
+MsmProfile* msm_profile_next(uint64_t* seq);
 extern thread_local float g_last_msm_ms[4];
 bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
 bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);
@@ -438,10 +450,15 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   }
   // buckets never touched by step 4 (large ones are written by 4b; all others by 4): no memset needed
 
-  hipEvent_t ev[4];
-  if (profile)
-    for (auto& e : ev) (void)hipEventCreate(&e);
-  if (profile) (void)hipEventRecord(ev[0], s);
+  uint64_t pseq = 0;
+  MsmProfile* prof = msm_profile_next(&pseq);
+  hipEvent_t* ev = prof->ev;
+  prof->L = L;
+  prof->nbuckets = nbuckets;
+  prof->c = c;
+  prof->W = g.W;
+  prof->is_g2 = sizeof(A) > 64;
+  (void)hipEventRecord(ev[0], s);
 
   const int mont_sc = cfg->are_scalars_montgomery_form, mont_pt = cfg->are_points_montgomery_form;
   const unsigned lgrid = (L + 255) / 256;
@@ -455,19 +472,20 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, ss.ptr<fe>(), L, g, mont_sc, cursor, sorted);
     ICICLE_TRY(check_launch("msm_scatter"));
   }
-  if (profile) (void)hipEventRecord(ev[1], s);
+  (void)hipEventRecord(ev[1], s);
 
   hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((nbuckets + 255) / 256), dim3(256), 0, s, sb.ptr<A>(), sorted, offsets, counts, nbuckets, large_thr, mont_pt, buckets);
   ICICLE_TRY(check_launch("msm_accumulate"));
+  (void)hipEventRecord(ev[2], s);
   hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(512), dim3(rb_max), rb_max * sizeof(X), s, sb.ptr<A>(), sorted, offsets, counts, n_large, large_list, large_cap, mont_pt, buckets);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
-  if (profile) (void)hipEventRecord(ev[2], s);
 
   hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(bpw, g.W), dim3(rblock), rblock * sizeof(X), s, buckets, g.NB, k_log, partials);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials, g.W, (int)bpw, c, sr.ptr<P>());
   ICICLE_TRY(check_launch("msm_tail"));
-  if (profile) (void)hipEventRecord(ev[3], s);
+  (void)hipEventRecord(ev[3], s);
+  prof->valid = true;
 
   HIP_TRY(ws_free(counts, s), ICICLE_DEALLOCATION_FAILED);
   HIP_TRY(ws_free(sorted, s), ICICLE_DEALLOCATION_FAILED);
@@ -480,7 +498,6 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     (void)hipEventElapsedTime(&g_last_msm_ms[1], ev[1], ev[2]);
     (void)hipEventElapsedTime(&g_last_msm_ms[2], ev[2], ev[3]);
     (void)hipEventElapsedTime(&g_last_msm_ms[3], ev[0], ev[3]);
-    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   return end_call(s, cfg->is_async);
 }

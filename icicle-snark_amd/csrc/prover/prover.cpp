@@ -180,6 +180,7 @@ struct ZKeyCache {
   hipStream_t s_g1 = nullptr, s_g2 = nullptr;
   hipEvent_t ev_witness = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t device_bytes = 0;
+  bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
 
   ~ZKeyCache()
   {
@@ -477,10 +478,11 @@ __attribute__((visibility("default"))) int groth16_cache_info(const Groth16Cache
 
 __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, uint8_t out_points[GROTH16_COMMITMENTS_BYTES], Groth16Timings* tm)
 {
-  if (!cm || !wtns || !out_points) return fail(ERR_ARG, "null argument");
+  if (!cm || !out_points) return fail(ERR_ARG, "null argument");
   std::lock_guard<std::mutex> lk(cm->mu);
   ZKeyCache* z = find(cm, key);
   if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  if (!wtns && !z->witness_resident) return fail(ERR_ARG, "no witness given and none resident on the device");
   const auto t0 = std::chrono::steady_clock::now();
   IcicleDevice dev;
   memset(&dev, 0, sizeof dev);
@@ -489,18 +491,20 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_ICICLE(icicle_set_device(&dev));
   if (int rc = ensure_domain(cm, z)) return rc;
 
-  Wtns w;
-  if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
-  // src/proof_helper.rs:253-262
-  if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
-  if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
-
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
   hipStream_t g1 = z->s_g1, g2 = z->s_g2;
-  // witness → pinned staging → device (stream g1), B2 MSM (stream g2) waits on the upload only
-  memcpy(z->h_witness, w.values, (size_t)nv * 32);
+  if (wtns) {
+    Wtns w;
+    if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
+    // src/proof_helper.rs:253-262
+    if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
+    if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
+    // witness → pinned staging → device (stream g1), B2 MSM (stream g2) waits on the upload only
+    memcpy(z->h_witness, w.values, (size_t)nv * 32);
+  }
   P_HIP(hipEventRecord(z->ev[0], g1));
-  P_HIP(hipMemcpyAsync(z->d_witness, z->h_witness, (size_t)nv * 32, hipMemcpyHostToDevice, g1));
+  if (wtns) P_HIP(hipMemcpyAsync(z->d_witness, z->h_witness, (size_t)nv * 32, hipMemcpyHostToDevice, g1));
+  z->witness_resident = true;
   P_HIP(hipEventRecord(z->ev_witness, g1));
   P_HIP(hipEventRecord(z->ev[1], g1));
   P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));

@@ -1,0 +1,120 @@
+"""Multi-GPU decomposition of the prover: point-range sharding of the five MSM bases + one exchange step.
+
+One process per GPU (torchrun / torch.distributed gives rank, world size and the rendezvous).  Every rank
+builds a cache holding only its slice [rank·L/W, (rank+1)·L/W) of each base array (C++: upload_shard in
+csrc/prover/prover.cpp — `shard_range` below is the same arithmetic), runs the replicated QAP/NTT front end
+and its five partial MSMs, then all ranks all-gather their 576-byte commitment blocks and sum them with
+the group law.  The data-path collective is RCCL over xGMI (csrc/comm/rccl_comm.cpp) driven by this
+library's own HIP runtime; torch.distributed (gloo) is only the control plane that broadcasts the
+ncclUniqueId and provides barriers.  `GlooExchange` is the CPU stand-in used by the world_size-2 tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import binding as K
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RCCL_LIB_PATH = os.path.join(_HERE, "lib", "libicicle_snark_rccl.so")
+
+
+def shard_range(total: int, rank: int, world: int):
+    return total * rank // world, total * (rank + 1) // world
+
+
+class LocalExchange:
+    """world size 1"""
+    world, rank = 1, 0
+
+    def allgather(self, block: bytes) -> bytes:
+        return block
+
+    def max(self, x: float) -> float:
+        return x
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class GlooExchange:
+    """torch.distributed (any initialised backend) on host tensors — CPU tests and control plane."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def allgather(self, block: bytes) -> bytes:
+        import torch
+        t = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return b"".join(bytes(o.numpy()) for o in outs)
+
+    def max(self, x: float) -> float:
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        pass
+
+
+class RcclExchange:
+    """RCCL all-gather on this library's HIP runtime; the id travels over the torch.distributed control plane."""
+
+    def __init__(self, device_id: int, max_bytes: int = 4096):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise ImportError(f"{RCCL_LIB_PATH} is missing: run `make`")
+        self.lib = C.CDLL(RCCL_LIB_PATH)
+        self.lib.icicle_snark_rccl_last_error.restype = C.c_char_p
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            self._check(self.lib.icicle_snark_rccl_unique_id(buf), "unique_id")
+            ident = [bytes(buf)]
+        dist.broadcast_object_list(ident, src=0)
+        self.comm = C.c_void_p()
+        self._check(self.lib.icicle_snark_rccl_init(ident[0], self.rank, self.world, device_id, C.c_size_t(max_bytes), C.byref(self.comm)), "init")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"rccl {what}: {self.lib.icicle_snark_rccl_last_error().decode()}")
+
+    def allgather(self, block: bytes) -> bytes:
+        out = (C.c_uint8 * (len(block) * self.world))()
+        self._check(self.lib.icicle_snark_rccl_allgather(self.comm, block, C.c_size_t(len(block)), out), "allgather")
+        return bytes(out)
+
+    def max(self, x: float) -> float:
+        v = C.c_double(x)
+        self._check(self.lib.icicle_snark_rccl_allreduce_max(self.comm, C.byref(v)), "allreduce_max")
+        return v.value
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        if self.comm:
+            self.lib.icicle_snark_rccl_destroy(self.comm)
+            self.comm = None
+
+
+def sharded_prove(cm, key: str, wtns, exch, r=None, s=None, wtns_for_public=None):
+    """one prove across exch.world GPUs: partial commitments → all-gather → group sum → blinding + JSON."""
+    blk, tm = cm.commitments(key, wtns)
+    if exch.world > 1:
+        blk = K.sum_commitments(exch.allgather(blk), exch.world)
+    proof, public = cm.assemble(key, wtns_for_public if wtns is None else wtns, blk, r, s)
+    return proof, public, tm

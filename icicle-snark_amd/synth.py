@@ -173,14 +173,59 @@ def write_wtns(witness) -> bytes:
     return b"wtns" + struct.pack("<II", 2, 2) + _section(1, hdr) + _section(2, body)
 
 
+def _toxic(seed):
+    pr = _Prng(seed)
+    return tuple(pr.fr() for _ in range(5))  # tau, alpha, beta, gamma, delta
+
+
+def _finish(m, npub, n, a_tau, b_tau, c_s, ic_s, h_s, mcs, vals_r2, toxic, fixed_base_mul, points_to_mont):
+    """Common tail of setup(): scalar arrays (numpy (k,4) u64, standard form) → points → zkey bytes."""
+    tau, alpha, beta, gamma, delta = toxic
+    head = ints_to_arr([alpha, beta, delta])
+    g1 = fixed_base_mul("g1", np.concatenate([head, ic_s, a_tau, b_tau, c_s, h_s]))
+    g2 = fixed_base_mul("g2", np.concatenate([ints_to_arr([beta, gamma, delta]), b_tau]))
+    vk_alpha_1, vk_beta_1, vk_delta_1 = g1[0], g1[1], g1[2]
+    o = 3
+    IC = g1[o:o + npub + 1]; o += npub + 1
+    A = g1[o:o + m]; o += m
+    B1 = g1[o:o + m]; o += m
+    Cp = g1[o:o + m - npub - 1]; o += m - npub - 1
+    H = g1[o:o + n]
+    vk_beta_2, vk_gamma_2, vk_delta_2 = g2[0], g2[1], g2[2]
+    B2 = g2[3:]
+    if points_to_mont is None:
+        def points_to_mont(arr):
+            flat = arr_to_ints(arr.reshape(-1, 4))
+            return ints_to_arr([v * MONT_R % Q_MOD for v in flat]).reshape(arr.shape)
+    pm = lambda arr: np.ascontiguousarray(points_to_mont(np.ascontiguousarray(arr))).tobytes()
+
+    hdr = struct.pack("<I", 32) + Q_MOD.to_bytes(32, "little") + struct.pack("<I", 32) + R_MOD.to_bytes(32, "little")
+    hdr += struct.pack("<III", m, npub, n)
+    hdr += pm(vk_alpha_1) + pm(vk_beta_1) + pm(vk_beta_2) + pm(vk_gamma_2) + pm(vk_delta_1) + pm(vk_delta_2)
+    ncoef = mcs.shape[0]
+    rec = np.zeros((ncoef, 44), dtype=np.uint8)
+    rec[:, 0:12] = np.ascontiguousarray(mcs, dtype=np.uint32).view(np.uint8).reshape(-1, 12)
+    rec[:, 12:44] = np.ascontiguousarray(vals_r2, dtype=np.uint64).view(np.uint8).reshape(-1, 32)
+    sec4 = struct.pack("<I", ncoef) + rec.tobytes()
+    body = _section(1, struct.pack("<I", 1)) + _section(2, hdr) + _section(3, pm(IC)) + _section(4, sec4)
+    body += _section(5, pm(A)) + _section(6, pm(B1)) + _section(7, pm(B2)) + _section(8, pm(Cp)) + _section(9, pm(H))
+    body += _section(10, struct.pack("<I", 0))
+    zkey = b"zkey" + struct.pack("<II", 1, 10) + body
+    vk = dict(vk_alpha_1=vk_alpha_1, vk_beta_2=vk_beta_2, vk_gamma_2=vk_gamma_2, vk_delta_2=vk_delta_2,
+              IC=[IC[i] for i in range(npub + 1)], n_public=npub)
+    return zkey, vk
+
+
 def setup(r1cs: R1CS, fixed_base_mul, points_to_mont=None, seed: int = SEED):
     """Groth16 setup with toxic waste (τ, α, β, γ, δ) = first five outputs of the fixed-seed PRNG.
-    Returns (zkey_bytes, vk dict with standard-form affine numpy points).
+    Returns (zkey_bytes, vk dict with standard-form affine numpy points).  Generic (any R1CS), pure Python
+    field arithmetic — fine up to ~10^5 constraints; setup_squaring_chain() is the vectorised path for the
+    benchmark sizes.
 
     points_to_mont(arr_u64[..., 4]) -> same shape: optional fast Fq std→Montgomery converter for the big
     point arrays (the HIP library's or the oracle's); defaults to pure Python."""
-    pr = _Prng(seed)
-    tau, alpha, beta, gamma, delta = (pr.fr() for _ in range(5))
+    toxic = _toxic(seed)
+    tau, alpha, beta, gamma, delta = toxic
     m, npub, nc = r1cs.n_vars, r1cs.n_public, r1cs.n_constraints
     n = 1
     while n < nc + npub + 1:
@@ -204,53 +249,78 @@ def setup(r1cs: R1CS, fixed_base_mul, points_to_mont=None, seed: int = SEED):
     comb = [(beta * a_tau[i] + alpha * b_tau[i] + c_tau[i]) % R_MOD for i in range(m)]
     ic_s = [comb[i] * ginv % R_MOD for i in range(npub + 1)]
     c_s = [comb[i] * dinv % R_MOD for i in range(npub + 1, m)]
-    # H basis
     g = omega(logn + 1)
     Lc = lagrange_at(n, logn, tau * pow(g, -1, R_MOD) % R_MOD)
     zt = (pow(tau, n, R_MOD) - 1) * pow((-2 * delta) % R_MOD, -1, R_MOD) % R_MOD
     h_s = [x * zt % R_MOD for x in Lc]
-
-    # one fixed-base batch for G1, one for G2
-    g1_scalars = [alpha, beta, delta] + ic_s + a_tau + b_tau + c_s + h_s
-    g1 = fixed_base_mul("g1", ints_to_arr(g1_scalars))
-    g2 = fixed_base_mul("g2", ints_to_arr([beta, gamma, delta] + b_tau))
-    o = 0
-    vk_alpha_1, vk_beta_1, vk_delta_1 = g1[0], g1[1], g1[2]; o = 3
-    IC = g1[o:o + npub + 1]; o += npub + 1
-    A = g1[o:o + m]; o += m
-    B1 = g1[o:o + m]; o += m
-    Cp = g1[o:o + m - npub - 1]; o += m - npub - 1
-    H = g1[o:o + n]
-    vk_beta_2, vk_gamma_2, vk_delta_2 = g2[0], g2[1], g2[2]
-    B2 = g2[3:]
-
-    if points_to_mont is None:
-        def points_to_mont(arr):
-            flat = arr_to_ints(arr.reshape(-1, 4))
-            return ints_to_arr([v * MONT_R % Q_MOD for v in flat]).reshape(arr.shape)
-    pm = lambda arr: np.ascontiguousarray(points_to_mont(np.ascontiguousarray(arr))).tobytes()
-
-    hdr = struct.pack("<I", 32) + Q_MOD.to_bytes(32, "little") + struct.pack("<I", 32) + R_MOD.to_bytes(32, "little")
-    hdr += struct.pack("<III", m, npub, n)
-    hdr += pm(vk_alpha_1) + pm(vk_beta_1) + pm(vk_beta_2) + pm(vk_gamma_2) + pm(vk_delta_1) + pm(vk_delta_2)
     R2 = MONT_R * MONT_R % R_MOD
-    rec = np.zeros((len(coeffs), 44), dtype=np.uint8)
-    mcs = np.array([(c[0], c[1], c[2]) for c in coeffs], dtype=np.uint32)
-    rec[:, 0:12] = mcs.view(np.uint8).reshape(-1, 12)
+    mcs = np.array([(c[0], c[1], c[2]) for c in coeffs], dtype=np.uint32).reshape(-1, 3)
     cache = {}
-    vals = bytearray()
     for c in coeffs:
-        v = c[3]
-        if v not in cache:
-            cache[v] = (v * R2 % R_MOD).to_bytes(32, "little")
-        vals += cache[v]
-    rec[:, 12:44] = np.frombuffer(bytes(vals), dtype=np.uint8).reshape(-1, 32)
-    sec4 = struct.pack("<I", len(coeffs)) + rec.tobytes()
+        if c[3] not in cache:
+            cache[c[3]] = (c[3] * R2 % R_MOD).to_bytes(32, "little")
+    vals = np.frombuffer(b"".join(cache[c[3]] for c in coeffs), dtype=np.uint64).reshape(-1, 4)
+    _e = lambda xs: ints_to_arr(xs) if len(xs) else np.zeros((0, 4), dtype=np.uint64)
+    return _finish(m, npub, n, _e(a_tau), _e(b_tau), _e(c_s), _e(ic_s), _e(h_s), mcs, vals, toxic, fixed_base_mul, points_to_mont)
 
-    body = _section(1, struct.pack("<I", 1)) + _section(2, hdr) + _section(3, pm(IC)) + _section(4, sec4)
-    body += _section(5, pm(A)) + _section(6, pm(B1)) + _section(7, pm(B2)) + _section(8, pm(Cp)) + _section(9, pm(H))
-    body += _section(10, struct.pack("<I", 0))
-    zkey = b"zkey" + struct.pack("<II", 1, 10) + body
-    vk = dict(vk_alpha_1=vk_alpha_1, vk_beta_2=vk_beta_2, vk_gamma_2=vk_gamma_2, vk_delta_2=vk_delta_2,
-              IC=[IC[i] for i in range(npub + 1)], n_public=npub)
-    return zkey, vk
+
+def squaring_chain_witness(N: int, a: int = 3):
+    w = [0] * (N + 2)
+    w[0], w[2] = 1, a % R_MOD
+    v = w[2]
+    for j in range(N):
+        v = v * v % R_MOD
+        w[3 + j if j < N - 1 else 1] = v
+    return w
+
+
+def setup_squaring_chain(N: int, vec, fixed_base_mul, points_to_mont=None, seed: int = SEED):
+    """Vectorised setup for benchmark/<N>: byte-identical to setup(squaring_chain(N)[0], …) (tested), with all
+    O(n) field work delegated to `vec`, an object offering (numpy (k,4) u64 standard-form arrays):
+        vec.mul(a, b), vec.add(a, b)      element-wise Fr
+        vec.intt(a)                        inverse NTT, natural order, size len(a) (power of two)
+    Uses  [L_j(y)]_j = iNTT([y^k]_k)  — the Lagrange basis at y is the inverse DFT of the powers of y."""
+    toxic = _toxic(seed)
+    tau, alpha, beta, gamma, delta = toxic
+    m, npub, nc = N + 2, 1, N
+    n = 1
+    while n < nc + npub + 1:
+        n <<= 1
+    logn = n.bit_length() - 1
+    one = ints_to_arr([1])
+
+    def bcast(x, k):
+        return np.broadcast_to(ints_to_arr([x]), (k, 4)).copy()
+
+    def powers(y):
+        p = one.copy()
+        step, k = y % R_MOD, 1
+        while k < n:
+            p = np.concatenate([p, vec.mul(p, bcast(step, k))])
+            step = step * step % R_MOD
+            k <<= 1
+        return p
+
+    L = vec.intt(powers(tau))
+    g = omega(logn + 1)
+    Lc = vec.intt(powers(tau * pow(g, -1, R_MOD) % R_MOD))
+    z = lambda k: np.zeros((k, 4), dtype=np.uint64)
+    a_tau, b_tau, c_tau = z(m), z(m), z(m)
+    a_tau[2:2 + N] = L[0:N]
+    a_tau[0], a_tau[1] = L[N], L[N + 1]
+    b_tau[2:2 + N] = L[0:N]
+    c_tau[3:3 + N - 1] = L[0:N - 1]
+    c_tau[1] = L[N - 1]
+    comb = vec.add(vec.add(vec.mul(a_tau, bcast(beta, m)), vec.mul(b_tau, bcast(alpha, m))), c_tau)
+    ic_s = vec.mul(comb[0:2].copy(), bcast(pow(gamma, -1, R_MOD), 2))
+    c_s = vec.mul(comb[2:].copy(), bcast(pow(delta, -1, R_MOD), m - 2))
+    zt = (pow(tau, n, R_MOD) - 1) * pow((-2 * delta) % R_MOD, -1, R_MOD) % R_MOD
+    h_s = vec.mul(Lc, bcast(zt, n))
+    j = np.arange(N, dtype=np.uint32)
+    mcs = np.concatenate([
+        np.stack([np.zeros(N, np.uint32), j, j + 2], axis=1),
+        np.stack([np.ones(N, np.uint32), j, j + 2], axis=1),
+        np.array([[0, N, 0], [0, N + 1, 1]], dtype=np.uint32)])
+    R2 = MONT_R * MONT_R % R_MOD
+    vals = bcast(R2, 2 * N + 2)
+    return _finish(m, npub, n, a_tau, b_tau, c_s, ic_s, h_s, mcs, vals, toxic, fixed_base_mul, points_to_mont)

@@ -50,7 +50,9 @@ void groth16_cache_evict(Groth16CacheManager* cm, const char* key);
 
 /* The five commitments of groth16_commitments (src/proof_helper.rs:172-241) for this process's shard,
  * as standard-form projective points in the order A (G1, 96 B), B1 (G1, 96 B), B2 (G2, 192 B),
- * C (G1, 96 B), H (G1, 96 B)  — 576 bytes.  Includes construct_r1cs (src/proof_helper.rs:31-170). */
+ * C (G1, 96 B), H (G1, 96 B)  — 576 bytes.  Includes construct_r1cs (src/proof_helper.rs:31-170).
+ * wtns == NULL re-uses the witness uploaded by the previous call for this key (inputs already resident in
+ * HBM — what bench.py times); otherwise the witness is staged through pinned memory and uploaded first. */
 #define GROTH16_COMMITMENTS_BYTES 576
 typedef struct {
   double h2d_ms;       /* witness upload */

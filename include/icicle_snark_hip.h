@@ -222,6 +222,10 @@ eIcicleError icicle_snark_g2_generator_mul(const bn254_scalar_t* s, uint64_t n, 
  * [0] recode+sort, [1] bucket accumulation, [2] bucket reduction, [3] total.  Valid only when the
  * environment variable ICICLE_SNARK_PROFILE=1 is set (adds stream synchronisation). */
 eIcicleError icicle_snark_last_msm_timings(float out_ms[4]);
+/* HIP-event profile of the `back`-th most recent MSM of this process (0 = latest); the caller must have
+ * synchronised that MSM's stream.  out_ms = {recode+sort, bucket-accumulation kernel, large buckets +
+ * reduction + tail, total}; geom = {L, nbuckets, c, W, is_g2}. */
+eIcicleError icicle_snark_msm_profile(int back, float out_ms[4], uint32_t geom[5]);
 
 #ifdef __cplusplus
 }
