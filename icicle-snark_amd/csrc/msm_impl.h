@@ -34,37 +34,17 @@
 #include <string.h>
 #include <vector>
 
-#include "common.h"
 #include "ec.h"
+#include "msm_plan.h"
 
 using namespace bn254;
 using namespace isnark;
 
 namespace isnark {
-// ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,
-// never synchronised here) + geometry, read back by icicle_snark_msm_profile() after the caller synced.
-struct MsmProfile {
-  hipEvent_t ev[4]; // start, before accumulate, after accumulate, end
-  uint32_t L, nbuckets;
-  int c, W, is_g2;
-  bool valid;
-};
-constexpr int MSM_PROFILE_RING = 32;
-extern MsmProfile g_msm_ring[MSM_PROFILE_RING];
-extern uint64_t g_msm_seq;
-MsmProfile* msm_profile_next(uint64_t* seq);
 extern thread_local float g_last_msm_ms[4];
-bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
-bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);
 }
 
 namespace {
-
-struct Geom {
-  int c, W;
-  uint32_t NB;     // buckets per window = 2^(c-1)
-  uint32_t H[9];   // Σ_w 2^(c·w + c − 1)
-};
 
 __device__ __forceinline__ fe ld_fe(const fe* p)
 {
@@ -76,106 +56,16 @@ __device__ __forceinline__ fe ld_fe(const fe* p)
   return r;
 }
 
-// scalar → t = s' + H (9 limbs), neg = (s was replaced by r − s)
-__device__ __forceinline__ void recode(const fe* scalars, uint32_t i, const Geom& g, int mont, uint32_t t[9], uint32_t& neg)
-{
-  fe s = ld_fe(scalars + i);
-  if (mont) s = Fr::from_mont(s);
-  neg = (s.l[7] >> 29) & 1; // bit 253
-  if (neg) s = Fr::neg(s);
-  uint64_t c = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    c += (uint64_t)s.l[k] + g.H[k];
-    t[k] = (uint32_t)c;
-    c >>= 32;
-  }
-  t[8] = (uint32_t)c + g.H[8];
-}
-// signed digit of window w: returns 0 for a zero digit, else (mag) with sign in bit 31
-__device__ __forceinline__ uint32_t digit(const uint32_t t[9], int w, const Geom& g)
-{
-  const int bit = w * g.c;
-  const int limb = bit >> 5, off = bit & 31;
-  uint64_t v = t[limb];
-  if (limb < 8) v |= (uint64_t)t[limb + 1] << 32;
-  const uint32_t raw = (uint32_t)(v >> off) & ((1u << g.c) - 1);
-  const int32_t d = (int32_t)raw - (int32_t)g.NB;
-  if (d == 0) return 0;
-  return d < 0 ? ((uint32_t)(-d) | 0x80000000u) : (uint32_t)d;
-}
-
-// zero `n` u32 words (kernel instead of hipMemsetAsync: keeps every dependency on the compute queue)
-__global__ __launch_bounds__(256) void msm_zero_kernel(uint32_t* __restrict__ p, uint32_t n)
-{
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
-}
-
-__global__ __launch_bounds__(256) void msm_hist_kernel(const fe* __restrict__ scalars, uint32_t L, Geom g, int mont, uint32_t* __restrict__ counts)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L) return;
-  uint32_t t[9], neg;
-  recode(scalars, i, g, mont, t, neg);
-  for (int w = 0; w < g.W; w++) {
-    const uint32_t d = digit(t, w, g);
-    if (d) atomicAdd(&counts[(uint32_t)w * g.NB + ((d & 0x7fffffffu) - 1)], 1u);
-  }
-}
-
-__global__ __launch_bounds__(256) void msm_scatter_kernel(const fe* __restrict__ scalars, uint32_t L, Geom g, int mont, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L) return;
-  uint32_t t[9], neg;
-  recode(scalars, i, g, mont, t, neg);
-  for (int w = 0; w < g.W; w++) {
-    const uint32_t d = digit(t, w, g);
-    if (d) {
-      const uint32_t pos = atomicAdd(&cursor[(uint32_t)w * g.NB + ((d & 0x7fffffffu) - 1)], 1u);
-      const uint32_t sign = (d >> 31) ^ neg;
-      sorted[pos] = i | (sign << 31);
-    }
-  }
-}
-
-// exclusive scan of m counters by one workgroup of 1024 threads; also finds buckets above `thr`
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                                          uint32_t thr, uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list, uint32_t large_cap)
-{
-  __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t chunk = (m + 1023) / 1024;
-  const uint32_t lo = tid * chunk, hi = min(lo + chunk, m);
-  uint32_t s = 0;
-  for (uint32_t k = lo; k < hi; k++) s += counts[k];
-  part[tid] = s;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[tid] - s;
-  for (uint32_t k = lo; k < hi; k++) {
-    const uint32_t cnt = counts[k];
-    offsets[k] = run;
-    cursor[k] = run;
-    if (cnt > thr) {
-      const uint32_t p = atomicAdd(n_large, 1u);
-      if (p < large_cap) large_list[p] = k;
-    }
-    run += cnt;
-  }
-}
-
 template <class C>
-__device__ __forceinline__ typename C::A load_base(const typename C::A* bases, uint32_t e, int pts_mont, bool& is_zero)
+__device__ __forceinline__ typename C::A load_base(const typename C::A* bases, uint32_t e, uint32_t skip_below, int pts_mont, bool& is_zero)
 {
   typedef typename C::A A;
-  A p = bases[e & 0x7fffffffu];
+  const uint32_t idx = e & 0x7fffffffu;
+  if (idx < skip_below) { // scalar present in the shared sort but outside this base set (C MSM)
+    is_zero = true;
+    return A();
+  }
+  A p = bases[idx - skip_below];
   is_zero = C::aff_is_zero(p);
   if (!pts_mont) p = C::aff_to_mont(p);
   if (e >> 31) p = C::aff_neg(p);
@@ -184,7 +74,7 @@ __device__ __forceinline__ typename C::A load_base(const typename C::A* bases, u
 
 template <class C>
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ counts, uint32_t nbuckets, uint32_t large_thr, int pts_mont, typename C::X* __restrict__ buckets)
+                                                              const uint32_t* __restrict__ counts, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, int pts_mont, typename C::X* __restrict__ buckets)
 {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
@@ -194,7 +84,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A
   typename C::X acc = C::x_zero();
   for (uint32_t k = 0; k < cnt; k++) {
     bool z;
-    typename C::A p = load_base<C>(bases, sorted[off + k], pts_mont, z);
+    typename C::A p = load_base<C>(bases, sorted[off + k], skip_below, pts_mont, z);
     if (!z) C::x_madd(acc, p);
   }
   buckets[b] = acc;
@@ -219,18 +109,18 @@ __device__ __forceinline__ typename C::X block_reduce(typename C::X v, typename 
 template <class C>
 __global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                                     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint32_t* __restrict__ large_list,
-                                                                    uint32_t large_cap, int pts_mont, typename C::X* __restrict__ buckets)
+                                                                    uint32_t skip_below, int pts_mont, typename C::X* __restrict__ buckets)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
-  const uint32_t nl = min(*n_large, large_cap);
+  const uint32_t nl = *n_large;
   for (uint32_t li = blockIdx.x; li < nl; li += gridDim.x) {
     const uint32_t b = large_list[li];
     const uint32_t cnt = counts[b], off = offsets[b];
     typename C::X acc = C::x_zero();
     for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
       bool z;
-      typename C::A p = load_base<C>(bases, sorted[off + k], pts_mont, z);
+      typename C::A p = load_base<C>(bases, sorted[off + k], skip_below, pts_mont, z);
       if (!z) C::x_madd(acc, p);
     }
     acc = block_reduce<C>(acc, sh, blockDim.x);
@@ -364,15 +254,61 @@ __global__ __launch_bounds__(64) void batch_to_affine_kernel(const typename C::P
   }
 }
 
-int ilog2_ceil(uint64_t x)
+
+struct ReduceShape {
+  int k_log;
+  uint32_t tpw, rblock, bpw;
+};
+template <class X>
+ReduceShape reduce_shape(const MsmGeom& g)
 {
-  int l = 0;
-  while ((1ull << l) < x) l++;
-  return l;
+  ReduceShape r;
+  r.k_log = (g.c - 1) > 11 ? (g.c - 1) - 11 : 0;
+  r.tpw = g.NB >> r.k_log;                               // reduce threads per window
+  const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256;   // LDS tree buffer ≤ 32 KiB
+  r.rblock = r.tpw < rb_max ? r.tpw : rb_max;
+  r.bpw = r.tpw / r.rblock;
+  return r;
 }
 
+// stages 4, 4b, 5 for one base set
+template <class C>
+eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, hipStream_t s, typename C::X* d_partials, MsmProfile* prof)
+{
+  typedef typename C::X X;
+  const MsmGeom& g = pl->g;
+  const ReduceShape rs = reduce_shape<X>(g);
+  X* buckets = nullptr;
+  HIP_TRY(ws_alloc((void**)&buckets, (size_t)pl->nbuckets * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
+  if (prof) (void)hipEventRecord(prof->ev[1], s);
+  hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->nbuckets, pl->large_thr, skip_below, mont_pt, buckets);
+  ICICLE_TRY(check_launch("msm_accumulate"));
+  if (prof) (void)hipEventRecord(prof->ev[2], s);
+  const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(512), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_list, skip_below, mont_pt, buckets);
+  ICICLE_TRY(check_launch("msm_accumulate_large"));
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.W), dim3(rs.rblock), rs.rblock * sizeof(X), s, buckets, g.NB, rs.k_log, d_partials);
+  ICICLE_TRY(check_launch("msm_bucket_reduce"));
+  HIP_TRY(ws_free(buckets, s), ICICLE_DEALLOCATION_FAILED);
+  return ICICLE_SUCCESS;
+}
 
+// host tail: Σ partials per window, Horner, standard-form projective (identity → (0,1,0))
+template <class C>
+typename C::P msm_host_tail(const typename C::X* part, uint32_t W, uint32_t bpw, int c)
+{
+  typedef typename C::X X;
+  X acc = C::x_zero();
+  for (int w = (int)W - 1; w >= 0; w--) {
+    for (int j = 0; j < c; j++) acc = C::x_dbl(acc);
+    X ws = C::x_zero();
+    for (uint32_t k = 0; k < bpw; k++) ws = C::x_add(ws, part[(size_t)w * bpw + k]);
+    acc = C::x_add(acc, ws);
+  }
+  return C::p_from_mont(C::x_to_projective(acc));
+}
 
+// the extern "C" entry (bn254_msm / bn254_g2_msm): sort + bucket stages + device tail
 template <class C, class AT, class PT>
 eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_size, const MSMConfig* cfg, PT* results)
 {
@@ -396,108 +332,34 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   ICICLE_TRY(sb.in(bases, (size_t)L * sizeof(A), cfg->are_points_on_device, s));
   ICICLE_TRY(sr.out(results, sizeof(P), cfg->are_results_on_device, s));
 
-  // window size: as the reference, ≈ log2(L) − 4 (cuda_msm.cuh:45-48), capped so that bucket
-  // magnitudes fit 15 bits + sign.
-  Geom g;
-  int c = cfg->c > 0 ? cfg->c : ilog2_ceil(L ? L : 1) - 4;
-  if (c < 4) c = 4;
-  if (c > 16) c = 16;
-  g.c = c;
-  g.W = 254 / c + 1;
-  g.NB = 1u << (c - 1);
-  {
-    uint32_t H[10] = {0};
-    for (int w = 0; w < g.W; w++) {
-      const int bit = w * c + c - 1;
-      H[bit >> 5] |= 1u << (bit & 31);
-    }
-    memcpy(g.H, H, sizeof g.H);
-  }
-  const uint32_t nbuckets = g.NB * (uint32_t)g.W;
-  const uint64_t nentries = (uint64_t)L * g.W;
-
-  // large-bucket threshold (the reference: large_bucket_factor(10) × average, cuda_msm.cuh:205-220)
   int lbf = 10;
   ext_get_int(cfg->ext, "large_bucket_factor", &lbf);
-  uint64_t avg = L / g.NB + 1;
-  uint32_t large_thr = (uint32_t)(avg * (uint64_t)lbf);
-  if (large_thr < 512) large_thr = 512;
-  const uint32_t large_cap = nbuckets; // the list can hold every bucket: no overflow case
-
-  // workspace (stream-ordered pool)
-  uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *sorted = nullptr, *n_large = nullptr, *large_list = nullptr;
-  X *buckets = nullptr, *partials = nullptr;
-  const int k_log = (c - 1) > 11 ? (c - 1) - 11 : 0;
-  const uint32_t tpw = g.NB >> k_log; // reduce threads per window
-  const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256; // LDS tree buffer ≤ 32 KiB
-  const uint32_t rblock = tpw < rb_max ? tpw : rb_max;
-  const uint32_t bpw = tpw / rblock;
-  HIP_TRY(ws_alloc((void**)&counts, (size_t)nbuckets * 4 * 4 + 16, s), ICICLE_ALLOCATION_FAILED);
-  offsets = counts + nbuckets;
-  cursor = offsets + nbuckets;
-  n_large = cursor + nbuckets;
-  large_list = n_large + 4;
-  HIP_TRY(ws_alloc((void**)&sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(ws_alloc((void**)&buckets, (size_t)nbuckets * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(ws_alloc((void**)&partials, (size_t)g.W * bpw * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  {
-    // counts[nbuckets] and (three arrays further) n_large[4]
-    unsigned zb = (nbuckets + 255) / 256;
-    if (zb > 1024) zb = 1024;
-    hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, counts, nbuckets);
-    hipLaunchKernelGGL(msm_zero_kernel, dim3(1), dim3(64), 0, s, n_large, 4u);
-    ICICLE_TRY(check_launch("msm_zero"));
-  }
-  // buckets never touched by step 4 (large ones are written by 4b; all others by 4): no memset needed
-
-  uint64_t pseq = 0;
-  MsmProfile* prof = msm_profile_next(&pseq);
-  hipEvent_t* ev = prof->ev;
+  MsmProfile* prof = msm_profile_next();
+  SortPlan pl;
+  (void)hipEventRecord(prof->ev[0], s);
+  ICICLE_TRY(msm_sort_run(ss.ptr<fe>(), L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl));
   prof->L = L;
-  prof->nbuckets = nbuckets;
-  prof->c = c;
-  prof->W = g.W;
+  prof->nbuckets = pl.nbuckets;
+  prof->c = pl.g.c;
+  prof->W = pl.g.W;
   prof->is_g2 = sizeof(A) > 64;
-  (void)hipEventRecord(ev[0], s);
-
-  const int mont_sc = cfg->are_scalars_montgomery_form, mont_pt = cfg->are_points_montgomery_form;
-  const unsigned lgrid = (L + 255) / 256;
-  if (L) {
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(lgrid), dim3(256), 0, s, ss.ptr<fe>(), L, g, mont_sc, counts);
-    ICICLE_TRY(check_launch("msm_hist"));
-  }
-  hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, s, counts, nbuckets, offsets, cursor, large_thr, n_large, large_list, large_cap);
-  ICICLE_TRY(check_launch("msm_scan"));
-  if (L) {
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, ss.ptr<fe>(), L, g, mont_sc, cursor, sorted);
-    ICICLE_TRY(check_launch("msm_scatter"));
-  }
-  (void)hipEventRecord(ev[1], s);
-
-  hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((nbuckets + 255) / 256), dim3(256), 0, s, sb.ptr<A>(), sorted, offsets, counts, nbuckets, large_thr, mont_pt, buckets);
-  ICICLE_TRY(check_launch("msm_accumulate"));
-  (void)hipEventRecord(ev[2], s);
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(512), dim3(rb_max), rb_max * sizeof(X), s, sb.ptr<A>(), sorted, offsets, counts, n_large, large_list, large_cap, mont_pt, buckets);
-  ICICLE_TRY(check_launch("msm_accumulate_large"));
-
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(bpw, g.W), dim3(rblock), rblock * sizeof(X), s, buckets, g.NB, k_log, partials);
-  ICICLE_TRY(check_launch("msm_bucket_reduce"));
-  hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials, g.W, (int)bpw, c, sr.ptr<P>());
+  const ReduceShape rs = reduce_shape<X>(pl.g);
+  X* partials = nullptr;
+  HIP_TRY(ws_alloc((void**)&partials, (size_t)pl.g.W * rs.bpw * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
+  ICICLE_TRY(msm_buckets_run<C>(&pl, sb.ptr<A>(), cfg->are_points_montgomery_form, 0, s, partials, prof));
+  hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials, pl.g.W, (int)rs.bpw, pl.g.c, sr.ptr<P>());
   ICICLE_TRY(check_launch("msm_tail"));
-  (void)hipEventRecord(ev[3], s);
+  (void)hipEventRecord(prof->ev[3], s);
   prof->valid = true;
-
-  HIP_TRY(ws_free(counts, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(ws_free(sorted, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(ws_free(buckets, s), ICICLE_DEALLOCATION_FAILED);
   HIP_TRY(ws_free(partials, s), ICICLE_DEALLOCATION_FAILED);
+  msm_sort_release(&pl);
   ICICLE_TRY(sr.finish());
   if (profile) {
     HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
-    (void)hipEventElapsedTime(&g_last_msm_ms[0], ev[0], ev[1]);
-    (void)hipEventElapsedTime(&g_last_msm_ms[1], ev[1], ev[2]);
-    (void)hipEventElapsedTime(&g_last_msm_ms[2], ev[2], ev[3]);
-    (void)hipEventElapsedTime(&g_last_msm_ms[3], ev[0], ev[3]);
+    (void)hipEventElapsedTime(&g_last_msm_ms[0], prof->ev[0], prof->ev[1]);
+    (void)hipEventElapsedTime(&g_last_msm_ms[1], prof->ev[1], prof->ev[2]);
+    (void)hipEventElapsedTime(&g_last_msm_ms[2], prof->ev[2], prof->ev[3]);
+    (void)hipEventElapsedTime(&g_last_msm_ms[3], prof->ev[0], prof->ev[3]);
   }
   return end_call(s, cfg->is_async);
 }
@@ -533,4 +395,3 @@ eIcicleError generator_mul_impl(const bn254_scalar_t* sc, uint64_t n, hipStream_
 }
 
 } // namespace
-

@@ -1,0 +1,64 @@
+// msm_plan.h — shared declarations of the MSM pipeline stages (sort plan, profile ring).
+//
+// The pipeline is split so that a caller holding several base sets for ONE scalar vector (Groth16:
+// A, B1, B2 and C are all multiplied by the witness, src/proof_helper.rs:198-206) sorts the scalars'
+// digits once and runs only the bucket stages per base set.
+#pragma once
+#include "common.h"
+#include "ff.h"
+
+namespace isnark {
+
+struct MsmGeom {
+  int c, W;
+  uint32_t NB;   // buckets per window = 2^(c-1)
+  uint32_t H[9]; // Σ_w 2^(c·w + c − 1)
+};
+
+// Result of the recode + counting-sort stage for one scalar vector (device arrays, workspace arena).
+struct SortPlan {
+  MsmGeom g;
+  uint32_t L = 0, nbuckets = 0, large_thr = 0;
+  uint32_t* ws = nullptr;      // base of the u32 workspace below
+  uint32_t* counts = nullptr;  // [nbuckets] entries per bucket (bucket = w·NB + |digit| − 1)
+  uint32_t* offsets = nullptr; // [nbuckets] exclusive prefix sum
+  uint32_t* n_large = nullptr; // [1]  number of buckets with more than large_thr entries
+  uint32_t* large_list = nullptr; // [nbuckets]
+  uint32_t* sorted = nullptr;  // [L·W] (index within the scalar vector) | sign << 31, grouped by bucket
+  hipStream_t stream = nullptr;
+};
+
+// geometry for a length-L MSM (c_cfg > 0 forces the window size)
+MsmGeom msm_geometry(uint32_t L, int c_cfg);
+// recode → histogram → scan → scatter on stream s.  Workspace comes from the arena of stream s and is
+// returned by msm_sort_release (which only marks it reusable by later work on that stream).
+eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl);
+void msm_sort_release(SortPlan* pl);
+
+// ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,
+// never synchronised here) + geometry, read back by icicle_snark_msm_profile() after the caller synced.
+struct MsmProfile {
+  hipEvent_t ev[4]; // start (sort), before accumulate, after accumulate, end
+  uint32_t L, nbuckets;
+  int c, W, is_g2;
+  bool valid;
+};
+constexpr int MSM_PROFILE_RING = 32;
+MsmProfile* msm_profile_next();
+
+// Bucket stages for one base set on stream s (may differ from the plan's stream; the caller orders them):
+// accumulate (+ large buckets) → per-window reduction.  Writes W·bpw XYZZ partial sums (Montgomery form) to
+// d_partials (device, caller-provided, ≥ msm_partials_bytes()).  Entries whose scalar index is < skip_below
+// are ignored and the base index is (scalar index − skip_below): lets the C MSM (witness[n_public+1..])
+// share the witness sort.
+size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bpw);
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
+eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
+// host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective
+void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out);
+void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out);
+
+bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
+bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);
+
+} // namespace isnark

@@ -1,0 +1,274 @@
+// msm_sort.hip — stage 1-3 of the MSM pipeline (see msm_impl.h): signed-digit recoding of the scalars and
+// a counting sort of (point index | sign) by (window, bucket).
+//
+//  recode      s ↦ digits d_w ∈ [−2^(c−1), 2^(c−1)) with Σ d_w 2^(cw) = s: scalars with bit 253 set are
+//              negated first (s ← r − s, sign flipped), then t = s + H with H = Σ_w 2^(cw+c−1) makes
+//              d_w = ((t >> cw) & (2^c − 1)) − 2^(c−1) independent per window (W = ⌊254/c⌋ + 1 windows, the
+//              top one cannot overflow).  Signed digits halve the bucket count of the reference's unsigned
+//              digits (cuda_msm.cuh:166-203).
+//  histogram   one global atomic per non-zero digit into counts[w·NB + |d| − 1]            (2 MiB of counters at c = 16: L2-resident)
+//  scan        exclusive prefix sum, three small kernels (block sums / top / finish) + list of large buckets
+//  scatter     second pass over the scalars; returning atomic on a cursor copy gives each entry its slot.
+//              The order inside a bucket is arbitrary — addition is commutative, results are not affected.
+// HBM traffic: 2 × 32 B per scalar read, 4 B per digit written (the key is implicit in the position): the
+// reference moves 8-byte (key, value) pairs through three CUB radix sorts + RLE + scan (cuda_msm.cuh:401-485, :561-636).
+#include <mutex>
+#include <string.h>
+
+#include "msm_plan.h"
+
+using namespace bn254;
+
+namespace isnark {
+
+static MsmProfile g_msm_ring[MSM_PROFILE_RING];
+static uint64_t g_msm_seq = 0;
+static std::mutex g_msm_prof_mu;
+
+MsmProfile* msm_profile_next()
+{
+  std::lock_guard<std::mutex> lk(g_msm_prof_mu);
+  MsmProfile* p = &g_msm_ring[g_msm_seq % MSM_PROFILE_RING];
+  if (!p->ev[0])
+    for (auto& e : p->ev) (void)hipEventCreate(&e);
+  p->valid = false;
+  g_msm_seq++;
+  return p;
+}
+
+namespace {
+
+__device__ __forceinline__ fe ld_fe(const fe* p)
+{
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  fe r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+
+// scalar → t = s' + H (9 limbs), neg = (s was replaced by r − s)
+__device__ __forceinline__ void recode(const fe* scalars, uint32_t i, const MsmGeom& g, int mont, uint32_t t[9], uint32_t& neg)
+{
+  fe s = ld_fe(scalars + i);
+  if (mont) s = Fr::from_mont(s);
+  neg = (s.l[7] >> 29) & 1; // bit 253
+  if (neg) s = Fr::neg(s);
+  uint64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    c += (uint64_t)s.l[k] + g.H[k];
+    t[k] = (uint32_t)c;
+    c >>= 32;
+  }
+  t[8] = (uint32_t)c + g.H[8];
+}
+// signed digit of window w: 0 for a zero digit, else |d| with the sign in bit 31
+__device__ __forceinline__ uint32_t digit(const uint32_t t[9], int w, const MsmGeom& g)
+{
+  const int bit = w * g.c;
+  const int limb = bit >> 5, off = bit & 31;
+  uint64_t v = t[limb];
+  if (limb < 8) v |= (uint64_t)t[limb + 1] << 32;
+  const uint32_t raw = (uint32_t)(v >> off) & ((1u << g.c) - 1);
+  const int32_t d = (int32_t)raw - (int32_t)g.NB;
+  if (d == 0) return 0;
+  return d < 0 ? ((uint32_t)(-d) | 0x80000000u) : (uint32_t)d;
+}
+
+// zero `n` u32 words (a kernel instead of hipMemsetAsync keeps every dependency on the compute queue)
+__global__ __launch_bounds__(256) void msm_zero_kernel(uint32_t* __restrict__ p, uint32_t n)
+{
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void msm_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, uint32_t* __restrict__ counts)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  uint32_t t[9], neg;
+  recode(scalars, i, g, mont, t, neg);
+  for (int w = 0; w < g.W; w++) {
+    const uint32_t d = digit(t, w, g);
+    if (d) atomicAdd(&counts[(uint32_t)w * g.NB + ((d & 0x7fffffffu) - 1)], 1u);
+  }
+}
+
+__global__ __launch_bounds__(256) void msm_scatter_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  uint32_t t[9], neg;
+  recode(scalars, i, g, mont, t, neg);
+  for (int w = 0; w < g.W; w++) {
+    const uint32_t d = digit(t, w, g);
+    if (d) {
+      const uint32_t pos = atomicAdd(&cursor[(uint32_t)w * g.NB + ((d & 0x7fffffffu) - 1)], 1u);
+      const uint32_t sign = (d >> 31) ^ neg;
+      sorted[pos] = i | (sign << 31);
+    }
+  }
+}
+
+// ---- exclusive scan of m counters: 2048 per workgroup (256 threads × 8) --------------------------
+constexpr int SCAN_T = 256, SCAN_E = 8, SCAN_B = SCAN_T * SCAN_E;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* sh, uint32_t* total)
+{
+  const uint32_t tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < SCAN_T; d <<= 1) {
+    uint32_t x = tid >= d ? sh[tid - d] : 0;
+    __syncthreads();
+    sh[tid] += x;
+    __syncthreads();
+  }
+  if (total) *total = sh[SCAN_T - 1];
+  return sh[tid] - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void msm_scan_sums_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ bsum)
+{
+  __shared__ uint32_t sh[SCAN_T];
+  const uint32_t base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_E;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_E; k++)
+    if (base + k < m) s += counts[base + k];
+  uint32_t total;
+  block_exclusive_scan(s, sh, &total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(SCAN_T) void msm_scan_top_kernel(uint32_t* bsum, uint32_t nblocks)
+{
+  __shared__ uint32_t sh[SCAN_T];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nblocks; base += SCAN_T) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblocks ? bsum[i] : 0;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, sh, &total);
+    if (i < nblocks) bsum[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(SCAN_T) void msm_scan_finish_kernel(const uint32_t* __restrict__ counts, uint32_t m, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ offsets,
+                                                                  uint32_t* __restrict__ cursor, uint32_t thr, uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list)
+{
+  __shared__ uint32_t sh[SCAN_T];
+  const uint32_t base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_E;
+  uint32_t v[SCAN_E], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_E; k++) {
+    v[k] = base + k < m ? counts[base + k] : 0;
+    s += v[k];
+  }
+  uint32_t run = bsum[blockIdx.x] + block_exclusive_scan(s, sh, nullptr);
+#pragma unroll
+  for (int k = 0; k < SCAN_E; k++) {
+    if (base + k < m) {
+      offsets[base + k] = run;
+      cursor[base + k] = run;
+      if (v[k] > thr) large_list[atomicAdd(n_large, 1u)] = base + k;
+      run += v[k];
+    }
+  }
+}
+
+int ilog2_ceil(uint64_t x)
+{
+  int l = 0;
+  while ((1ull << l) < x) l++;
+  return l;
+}
+
+} // namespace
+
+MsmGeom msm_geometry(uint32_t L, int c_cfg)
+{
+  // window size: as the reference, ≈ log2(L) − 4 (cuda_msm.cuh:45-48), capped so that bucket magnitudes fit
+  // 15 bits + sign
+  MsmGeom g;
+  int c = c_cfg > 0 ? c_cfg : ilog2_ceil(L ? L : 1) - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  g.c = c;
+  g.W = 254 / c + 1;
+  g.NB = 1u << (c - 1);
+  uint32_t H[10] = {0};
+  for (int w = 0; w < g.W; w++) {
+    const int bit = w * c + c - 1;
+    H[bit >> 5] |= 1u << (bit & 31);
+  }
+  memcpy(g.H, H, sizeof g.H);
+  return g;
+}
+
+eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl)
+{
+  pl->g = msm_geometry(L, c_cfg);
+  const MsmGeom& g = pl->g;
+  pl->L = L;
+  pl->stream = s;
+  const uint32_t nb = g.NB * (uint32_t)g.W;
+  pl->nbuckets = nb;
+  // large-bucket threshold (the reference: large_bucket_factor(10) × average, cuda_msm.cuh:205-220)
+  const uint64_t avg = L / g.NB + 1;
+  uint32_t thr = (uint32_t)(avg * (uint64_t)(lbf > 0 ? lbf : 10));
+  if (thr < 512) thr = 512;
+  pl->large_thr = thr;
+  const uint32_t nblocks = (nb + SCAN_B - 1) / SCAN_B;
+  const uint64_t nentries = (uint64_t)L * g.W;
+  // layout: counts | offsets | cursor | large_list | n_large[4] | bsum[nblocks]
+  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 4 + 4 + nblocks) * 4, s), ICICLE_ALLOCATION_FAILED);
+  pl->counts = pl->ws;
+  pl->offsets = pl->counts + nb;
+  uint32_t* cursor = pl->offsets + nb;
+  pl->large_list = cursor + nb;
+  pl->n_large = pl->large_list + nb;
+  uint32_t* bsum = pl->n_large + 4;
+  HIP_TRY(ws_alloc((void**)&pl->sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
+
+  unsigned zb = (nb + 255) / 256;
+  if (zb > 1024) zb = 1024;
+  hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, nb);
+  hipLaunchKernelGGL(msm_zero_kernel, dim3(1), dim3(64), 0, s, pl->n_large, 4u);
+  const unsigned lgrid = (L + 255) / 256;
+  if (L) hipLaunchKernelGGL(msm_hist_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, pl->counts);
+  hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum);
+  hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
+  hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list);
+  if (L) hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
+  return check_launch("msm_sort");
+}
+
+void msm_sort_release(SortPlan* pl)
+{
+  if (pl->ws) (void)ws_free(pl->ws, pl->stream);
+  if (pl->sorted) (void)ws_free(pl->sorted, pl->stream);
+  pl->ws = pl->sorted = nullptr;
+}
+
+} // namespace isnark
+
+// Profile of the `back`-th most recent MSM (0 = latest) issued by this process.  The caller must have
+// synchronised the MSM's stream.  out_ms = {recode+sort, bucket accumulation kernel, large buckets +
+// reduction (+ device tail), total}; geom = {L, nbuckets, c, W, is_g2}.  When several base sets share one
+// sort, only the first of them carries the sort time.
+ISNARK_API eIcicleError icicle_snark_msm_profile(int back, float out_ms[4], uint32_t geom[5])
+{
+  using namespace isnark;
+  if (!out_ms || !geom || back < 0 || back >= MSM_PROFILE_RING || (uint64_t)back >= g_msm_seq) return ICICLE_INVALID_ARGUMENT;
+  const MsmProfile& p = g_msm_ring[(g_msm_seq - 1 - back) % MSM_PROFILE_RING];
+  if (!p.valid) return ICICLE_INVALID_ARGUMENT;
+  if (hipEventElapsedTime(&out_ms[0], p.ev[0], p.ev[1]) != hipSuccess) return ICICLE_UNKNOWN_ERROR;
+  (void)hipEventElapsedTime(&out_ms[1], p.ev[1], p.ev[2]);
+  (void)hipEventElapsedTime(&out_ms[2], p.ev[2], p.ev[3]);
+  (void)hipEventElapsedTime(&out_ms[3], p.ev[0], p.ev[3]);
+  geom[0] = p.L; geom[1] = p.nbuckets; geom[2] = (uint32_t)p.c; geom[3] = (uint32_t)p.W; geom[4] = (uint32_t)p.is_g2;
+  return ICICLE_SUCCESS;
+}

@@ -33,6 +33,7 @@
 #include "../../../include/groth16_prover.h"
 #include "../common.h"
 #include "../ec.h"
+#include "../msm_plan.h"
 #include "qap.h"
 
 using namespace bn254;
@@ -154,6 +155,8 @@ int parse_wtns(const uint8_t* data, size_t len, Wtns& w)
   return 0;
 }
 
+constexpr size_t PARTIALS_STRIDE = 64 * 16 * 256; // ≥ W·bpw·sizeof(XYZZ) for any geometry (W ≤ 64, bpw ≤ 16, G2 256 B)
+
 struct Shard {
   uint32_t lo = 0, hi = 0; // [lo, hi) of the full base array
   void* d_points = nullptr;
@@ -174,11 +177,11 @@ struct ZKeyCache {
   Shard A, B1, B2, C, H;
   fe* d_witness = nullptr; // n_vars
   fe* d_vec = nullptr;     // 3n
-  uint8_t* d_results = nullptr; // 576 B
-  uint8_t* h_results = nullptr; // pinned
+  uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
+  uint8_t* h_partials = nullptr; // pinned mirror
   fe* h_witness = nullptr;      // pinned staging, n_vars
   hipStream_t s_g1 = nullptr, s_g2 = nullptr;
-  hipEvent_t ev_witness = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_g2done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
 
@@ -187,13 +190,15 @@ struct ZKeyCache {
     (void)hipSetDevice(device_id);
     if (s_g1) (void)hipStreamSynchronize(s_g1);
     if (s_g2) (void)hipStreamSynchronize(s_g2);
-    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_results})
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_partials})
       if (p) (void)hipFree(p);
-    if (h_results) (void)hipHostFree(h_results);
+    if (h_partials) (void)hipHostFree(h_partials);
     if (h_witness) (void)hipHostFree(h_witness);
     if (s_g1) (void)icicle_destroy_stream(s_g1);
     if (s_g2) (void)icicle_destroy_stream(s_g2);
     if (ev_witness) (void)hipEventDestroy(ev_witness);
+    if (ev_sort) (void)hipEventDestroy(ev_sort);
+    if (ev_g2done) (void)hipEventDestroy(ev_g2done);
     for (auto e : ev)
       if (e) (void)hipEventDestroy(e);
   }
@@ -215,11 +220,11 @@ G2::P g2_from_mont_affine(const uint8_t* p)
   return {Fq2Ops::from_mont(a.x), Fq2Ops::from_mont(a.y), one};
 }
 
-int upload_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, int rank, int count, uint64_t& bytes)
+int upload_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint32_t lo, uint32_t hi, uint64_t& bytes)
 {
   if (sec->size != (uint64_t)total * elem) return fail(ERR_FORMAT, "zkey: point section size mismatch");
-  sh.lo = (uint32_t)((uint64_t)total * rank / count);
-  sh.hi = (uint32_t)((uint64_t)total * (rank + 1) / count);
+  sh.lo = lo;
+  sh.hi = hi;
   const size_t n = (size_t)sh.len() * elem;
   P_HIP(hipMalloc(&sh.d_points, n ? n : 256));
   if (n) P_HIP(hipMemcpy(sh.d_points, sec->p + (size_t)sh.lo * elem, n, hipMemcpyHostToDevice));
@@ -325,21 +330,29 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   }
 
   // bases (sections 5-9), this process's point range only
-  if (int rc = upload_shard(z->A, s5, 64, z->n_vars, rank, count, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->B1, s6, 64, z->n_vars, rank, count, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->B2, s7, 128, z->n_vars, rank, count, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->C, s8, 64, z->n_vars - z->n_public - 1, rank, count, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->H, s9, 64, n, rank, count, z->device_bytes)) return rc;
+  // A, B1, B2 share the witness range [wlo, whi); C (= witness[n_public+1..]) takes the part of that SAME
+  // witness range it covers, so that one digit sort of witness[wlo:whi] serves all four MSMs.
+  const uint32_t wlo = (uint32_t)((uint64_t)z->n_vars * rank / count), whi = (uint32_t)((uint64_t)z->n_vars * (rank + 1) / count);
+  const uint32_t skip = z->n_public + 1;
+  const uint32_t clo = (wlo > skip ? wlo : skip) - skip, chi = (whi > skip ? whi : skip) - skip;
+  const uint32_t hlo = (uint32_t)((uint64_t)n * rank / count), hhi = (uint32_t)((uint64_t)n * (rank + 1) / count);
+  if (int rc = upload_shard(z->A, s5, 64, z->n_vars, wlo, whi, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->B1, s6, 64, z->n_vars, wlo, whi, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->B2, s7, 128, z->n_vars, wlo, whi, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->C, s8, 64, z->n_vars - skip, clo, chi, z->device_bytes)) return rc;
+  if (int rc = upload_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes)) return rc;
 
   P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
-  P_HIP(hipMalloc((void**)&z->d_results, GROTH16_COMMITMENTS_BYTES));
-  P_HIP(hipHostMalloc((void**)&z->h_results, GROTH16_COMMITMENTS_BYTES));
+  P_HIP(hipMalloc((void**)&z->d_partials, 5 * PARTIALS_STRIDE));
+  P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE));
   P_HIP(hipHostMalloc((void**)&z->h_witness, (size_t)z->n_vars * 32));
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_g2done, hipEventDisableTiming));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
   out = std::move(z);
   return 0;
@@ -376,22 +389,6 @@ int ensure_domain(Groth16CacheManager* cm, const ZKeyCache* z)
 double ms_since(std::chrono::steady_clock::time_point t0)
 {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-}
-
-int msm_call(bool g2, const fe* scalars, const void* points, uint32_t len, hipStream_t s, void* d_result)
-{
-  MSMConfig c;
-  memset(&c, 0, sizeof c);
-  c.stream = s;
-  c.precompute_factor = 1;
-  c.batch_size = 1;
-  c.are_points_shared_in_batch = true;
-  c.are_scalars_on_device = c.are_points_on_device = c.are_results_on_device = true;
-  c.are_points_montgomery_form = true; // zkey points are kept as stored
-  c.is_async = true;
-  if (g2) P_ICICLE(bn254_g2_msm((const bn254_scalar_t*)scalars, (const bn254_g2_affine_t*)points, (int)len, &c, (bn254_g2_projective_t*)d_result));
-  else P_ICICLE(bn254_msm((const bn254_scalar_t*)scalars, (const bn254_affine_t*)points, (int)len, &c, (bn254_projective_t*)d_result));
-  return 0;
 }
 
 ZKeyCache* find(Groth16CacheManager* cm, const char* key)
@@ -507,12 +504,27 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   z->witness_resident = true;
   P_HIP(hipEventRecord(z->ev_witness, g1));
   P_HIP(hipEventRecord(z->ev[1], g1));
-  P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));
-  uint8_t* R = z->d_results;
-  // commitment_b (G2) on its own stream — src/proof_helper.rs:206
-  if (int rc = msm_call(true, z->d_witness + z->B2.lo, z->B2.d_points, z->B2.len(), g2, R + 192)) return rc;
 
-  // construct_r1cs on stream g1
+  // ---- stream g2: ONE digit sort of witness[wlo:whi] (shared by A, B1, B2, C), then the G2 bucket stages
+  P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));
+  const uint32_t wlo = z->A.lo, wlen = z->A.len(), skip = npub + 1;
+  SortPlan plan_w, plan_h;
+  MsmProfile* prof[5]; // A, B1, B2, C, H
+  for (auto& p : prof) p = msm_profile_next();
+  (void)hipEventRecord(prof[2]->ev[0], g2);
+  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 10, 0, g2, &plan_w));
+  P_HIP(hipEventRecord(z->ev_sort, g2));
+  auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
+    p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
+  };
+  uint8_t* DP = z->d_partials;
+  fill(prof[2], plan_w, 1);
+  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 1, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2])); // commitment_b — src/proof_helper.rs:206
+  (void)hipEventRecord(prof[2]->ev[3], g2);
+  prof[2]->valid = true;
+  P_HIP(hipEventRecord(z->ev_g2done, g2));
+
+  // ---- stream g1: construct_r1cs (src/proof_helper.rs:31-170) on the device
   P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, g1));
   NTTConfig nc;
   memset(&nc, 0, sizeof nc);
@@ -530,18 +542,42 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_HIP(qap_final(z->d_vec, n, g1));                                                                        // :154-167
   P_HIP(hipEventRecord(z->ev[2], g1));
 
-  // groth16_commitments — src/proof_helper.rs:198-205 : A, B1, C, H on stream g1
-  if (int rc = msm_call(false, z->d_witness + z->A.lo, z->A.d_points, z->A.len(), g1, R + 0)) return rc;
-  if (int rc = msm_call(false, z->d_witness + z->B1.lo, z->B1.d_points, z->B1.len(), g1, R + 96)) return rc;
-  if (int rc = msm_call(false, z->d_witness + npub + 1 + z->C.lo, z->C.d_points, z->C.len(), g1, R + 384)) return rc;
-  if (int rc = msm_call(false, z->d_vec + n + z->H.lo, z->H.d_points, z->H.len(), g1, R + 480)) return rc;
-  // join g2 into g1, one D2H of all five results
-  P_HIP(hipEventRecord(z->ev_witness, g2));
-  P_HIP(hipStreamWaitEvent(g1, z->ev_witness, 0));
+  // ---- stream g1: groth16_commitments — src/proof_helper.rs:198-205 : A, B1, C (shared sort), then H
+  P_HIP(hipStreamWaitEvent(g1, z->ev_sort, 0));
+  const uint32_t skip_below = skip > wlo ? skip - wlo : 0; // C ignores witness[0..=n_public]
+  const int order[3] = {0, 1, 3};
+  const Shard* sh3[3] = {&z->A, &z->B1, &z->C};
+  for (int k = 0; k < 3; k++) {
+    MsmProfile* p = prof[order[k]];
+    fill(p, plan_w, 0);
+    (void)hipEventRecord(p->ev[0], g1);
+    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 1, k == 2 ? skip_below : 0, g1, DP + order[k] * PARTIALS_STRIDE, p));
+    (void)hipEventRecord(p->ev[3], g1);
+    p->valid = true;
+  }
+  (void)hipEventRecord(prof[4]->ev[0], g1);
+  P_ICICLE(msm_sort_run(z->d_vec + n + z->H.lo, z->H.len(), 0, 10, 0, g1, &plan_h));
+  fill(prof[4], plan_h, 0);
+  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 1, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4]));
+  (void)hipEventRecord(prof[4]->ev[3], g1);
+  prof[4]->valid = true;
+  // join g2 into g1, one D2H of all partial sums, host tails (window sums → Horner)
+  P_HIP(hipStreamWaitEvent(g1, z->ev_g2done, 0));
   P_HIP(hipEventRecord(z->ev[3], g1));
-  P_HIP(hipMemcpyAsync(z->h_results, R, GROTH16_COMMITMENTS_BYTES, hipMemcpyDeviceToHost, g1));
+  uint32_t Ww = 0, bw1 = 0, bw2 = 0, Wh = 0, bh = 0;
+  const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Ww, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
+  const size_t sizes[5] = {by1, by1, by2, by1, byh};
+  for (int k = 0; k < 5; k++) P_HIP(hipMemcpyAsync(z->h_partials + k * PARTIALS_STRIDE, DP + k * PARTIALS_STRIDE, sizes[k], hipMemcpyDeviceToHost, g1));
   P_HIP(hipStreamSynchronize(g1));
-  memcpy(out_points, z->h_results, GROTH16_COMMITMENTS_BYTES);
+  P_HIP(hipStreamSynchronize(g2));
+  msm_sort_release(&plan_w);
+  msm_sort_release(&plan_h);
+  const uint8_t* HP = z->h_partials;
+  msm_g1_host_tail(HP + 0 * PARTIALS_STRIDE, Ww, bw1, plan_w.g.c, (bn254_projective_t*)(out_points + 0));
+  msm_g1_host_tail(HP + 1 * PARTIALS_STRIDE, Ww, bw1, plan_w.g.c, (bn254_projective_t*)(out_points + 96));
+  msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, bw2, plan_w.g.c, (bn254_g2_projective_t*)(out_points + 192));
+  msm_g1_host_tail(HP + 3 * PARTIALS_STRIDE, Ww, bw1, plan_w.g.c, (bn254_projective_t*)(out_points + 384));
+  msm_g1_host_tail(HP + 4 * PARTIALS_STRIDE, Wh, bh, plan_h.g.c, (bn254_projective_t*)(out_points + 480));
   if (tm) {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
