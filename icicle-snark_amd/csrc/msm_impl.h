@@ -74,10 +74,12 @@ __device__ __forceinline__ typename C::A load_base(const typename C::A* bases, u
 
 template <class C>
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ counts, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, int pts_mont, typename C::X* __restrict__ buckets)
+                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, int pts_mont,
+                                                              typename C::X* __restrict__ buckets)
 {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbuckets) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  const uint32_t b = order[t]; // neighbouring lanes own buckets of (nearly) equal size
   const uint32_t cnt = counts[b];
   if (cnt > large_thr) return; // step 4b
   const uint32_t off = offsets[b];
@@ -281,7 +283,7 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   X* buckets = nullptr;
   HIP_TRY(ws_alloc((void**)&buckets, (size_t)pl->nbuckets * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);
-  hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->nbuckets, pl->large_thr, skip_below, mont_pt, buckets);
+  hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, mont_pt, buckets);
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;

@@ -24,6 +24,7 @@ struct SortPlan {
   uint32_t* offsets = nullptr; // [nbuckets] exclusive prefix sum
   uint32_t* n_large = nullptr; // [1]  number of buckets with more than large_thr entries
   uint32_t* large_list = nullptr; // [nbuckets]
+  uint32_t* order = nullptr;   // [nbuckets] bucket ids by decreasing entry count (wave-uniform trip counts)
   uint32_t* sorted = nullptr;  // [L·W] (index within the scalar vector) | sign << 31, grouped by bucket
   hipStream_t stream = nullptr;
 };

@@ -179,6 +179,48 @@ __global__ __launch_bounds__(SCAN_T) void msm_scan_finish_kernel(const uint32_t*
   }
 }
 
+// ---- order buckets by decreasing size (counting sort on min(count, ORDER_BINS-1)) ----------------
+// One thread accumulates one bucket; buckets of a wave should hold the same number of points or the
+// wave runs for its largest bucket (random digits: Poisson sizes, a quarter of the lanes idle —
+// SQ_THREAD_CYCLES_VALU / (64·SQ_ACTIVE_INST_VALU) = 0.77 before this ordering).  The reference sorts
+// bucket sizes with two more CUB radix sorts (cuda_msm.cuh:606-630); sizes are small integers, so a
+// counting sort is enough.
+constexpr int ORDER_BINS = 2048;
+__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ size_hist)
+{
+  __shared__ uint32_t sh[ORDER_BINS];
+  for (int i = threadIdx.x; i < ORDER_BINS; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < m; b += stride) atomicAdd(&sh[min(counts[b], (uint32_t)ORDER_BINS - 1)], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < ORDER_BINS; i += blockDim.x)
+    if (sh[i]) atomicAdd(&size_hist[i], sh[i]);
+}
+// exclusive scan in DESCENDING key order: start[k] = number of buckets with a larger key
+__global__ __launch_bounds__(256) void msm_size_scan_kernel(uint32_t* size_hist /* in: hist, out: start */)
+{
+  __shared__ uint32_t sh[SCAN_T];
+  const int per = ORDER_BINS / SCAN_T; // 8 keys per thread, thread 0 owns the largest keys
+  uint32_t v[8], s = 0;
+  for (int k = 0; k < per; k++) {
+    v[k] = size_hist[ORDER_BINS - 1 - (threadIdx.x * per + k)];
+    s += v[k];
+  }
+  uint32_t run = block_exclusive_scan(s, sh, nullptr);
+  for (int k = 0; k < per; k++) {
+    size_hist[ORDER_BINS - 1 - (threadIdx.x * per + k)] = run;
+    run += v[k];
+  }
+}
+__global__ __launch_bounds__(256) void msm_size_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ size_cursor, uint32_t* __restrict__ order)
+{
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= m) return;
+  const uint32_t pos = atomicAdd(&size_cursor[min(counts[b], (uint32_t)ORDER_BINS - 1)], 1u);
+  order[pos] = b;
+}
+
 int ilog2_ceil(uint64_t x)
 {
   int l = 0;
@@ -223,26 +265,35 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->large_thr = thr;
   const uint32_t nblocks = (nb + SCAN_B - 1) / SCAN_B;
   const uint64_t nentries = (uint64_t)L * g.W;
-  // layout: counts | offsets | cursor | large_list | n_large[4] | bsum[nblocks]
-  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 4 + 4 + nblocks) * 4, s), ICICLE_ALLOCATION_FAILED);
+  // layout: counts | offsets | cursor | large_list | order | n_large[4] | bsum[nblocks] | size_hist[ORDER_BINS]
+  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 5 + 4 + nblocks + ORDER_BINS) * 4, s), ICICLE_ALLOCATION_FAILED);
   pl->counts = pl->ws;
   pl->offsets = pl->counts + nb;
   uint32_t* cursor = pl->offsets + nb;
   pl->large_list = cursor + nb;
-  pl->n_large = pl->large_list + nb;
+  pl->order = pl->large_list + nb;
+  pl->n_large = pl->order + nb;
   uint32_t* bsum = pl->n_large + 4;
+  uint32_t* size_hist = bsum + nblocks;
   HIP_TRY(ws_alloc((void**)&pl->sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
 
   unsigned zb = (nb + 255) / 256;
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, nb);
   hipLaunchKernelGGL(msm_zero_kernel, dim3(1), dim3(64), 0, s, pl->n_large, 4u);
+  hipLaunchKernelGGL(msm_zero_kernel, dim3(ORDER_BINS / 256), dim3(256), 0, s, size_hist, (uint32_t)ORDER_BINS);
   const unsigned lgrid = (L + 255) / 256;
   if (L) hipLaunchKernelGGL(msm_hist_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, pl->counts);
   hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum);
   hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
   hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list);
   if (L) hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
+  // bucket ids by decreasing size
+  unsigned hb = (nb + 255) / 256;
+  if (hb > 512) hb = 512;
+  hipLaunchKernelGGL(msm_size_hist_kernel, dim3(hb), dim3(256), 0, s, pl->counts, nb, size_hist);
+  hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SCAN_T), 0, s, size_hist);
+  hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, pl->counts, nb, size_hist, pl->order);
   return check_launch("msm_sort");
 }
 

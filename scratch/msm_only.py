@@ -1,0 +1,17 @@
+import sys, importlib
+sys.path.insert(0, ".")
+import numpy as np
+K = importlib.import_module("icicle-snark_amd")
+K.set_device("HIP", 0)
+grp = sys.argv[1] if len(sys.argv) > 1 else "g1"
+logn = int(sys.argv[2]) if len(sys.argv) > 2 else 21
+n = 1 << logn
+rng = np.random.default_rng(0)
+sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+sc[:, 3] &= np.uint64((1 << 61) - 1)
+pts = K.generator_mul(grp, sc[::-1].copy())
+d_s, d_b = K.DeviceVec.from_host(sc), K.DeviceVec.from_host(pts)
+for rep in range(3):
+    res = K.msm(grp, d_s, d_b)
+    ms, geom = K.msm_profile(0)
+    print(grp, geom, "sort %.2f acc %.2f rest %.2f total %.2f ms" % tuple(ms), flush=True)
