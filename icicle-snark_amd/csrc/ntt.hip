@@ -9,9 +9,10 @@
 //    batch of size-R sub-transforms done entirely in LDS.  A workgroup owns a tile of R rows × C
 //    columns (R·C = 2048 elements = 64 KiB of the CU's 160 KiB LDS, two workgroups per CU), the
 //    C columns being C consecutive elements in memory, so global traffic is runs of C·32 B.
-//  * inside the tile: radix-2 DIF stages over the rows, one __syncthreads per stage; the tile is
-//    kept as two uint4 planes (limbs 0-3 / 4-7) so that consecutive lanes read consecutive 16-B
-//    LDS slots (no bank conflicts for ds_read_b128 / ds_write_b128).
+//  * inside the tile: DIF rounds of radix 8 over the rows (eight operands per thread in registers,
+//    three radix-2 stages per LDS round trip and per __syncthreads); the tile is kept as two uint4
+//    planes (limbs 0-3 / 4-7) so that consecutive lanes read consecutive 16-B LDS slots (no bank
+//    conflicts for ds_read_b128 / ds_write_b128).
 //  * the inter-pass twiddle ω_n^(k·t), the final 1/n of the inverse transform and the
 //    natural-order permutation are fused into the pass that produces the data — there is no
 //    separate digit-reverse or normalise pass (the reference runs both:
@@ -118,8 +119,73 @@ __device__ __forceinline__ void g_put(fe* p, const fe& v)
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-// One pass: grid = (tiles, batch).  LDS: two uint4 planes of R·C entries + R/2 stage twiddles.
-__global__ __launch_bounds__(NT) void ntt_pass_kernel(const fe* __restrict__ in, fe* __restrict__ out, const fe* __restrict__ tw, PassParams p, fe ninv_mont)
+// radix-2^Q decimation-in-frequency butterfly on 2^Q elements held in registers.  Element k sits at row
+// base + k·(M >> Q) of a size-M sub-transform whose first row is a multiple of M; j = base mod (M >> Q).
+// Twiddles ω_R^e come from the LDS table (e < R/2): ω_Ms^x = ω_R^(x·R/Ms).  Written out stage by stage so
+// that every register index is a compile-time constant (a looped form was left rolled by the compiler and
+// spilled the operands to scratch).
+#define NTT_BF(a, b, e)                                                                                        \
+  {                                                                                                            \
+    const fe s_ = Fr::add(x[a], x[b]);                                                                         \
+    const fe d_ = Fr::sub(x[a], x[b]);                                                                         \
+    x[a] = s_;                                                                                                 \
+    x[b] = Fr::mul(d_, lds_get(twlo, twhi, (e)));                                                              \
+  }
+template <int Q>
+__device__ __forceinline__ void dif_butterfly(fe (&x)[1 << Q], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi);
+
+template <>
+__device__ __forceinline__ void dif_butterfly<3>(fe (&x)[8], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi)
+{
+  const int g = 1 << (log_m - 3);
+  const int s0 = log_r - log_m, s1 = s0 + 1, s2 = s0 + 2;
+  NTT_BF(0, 4, j << s0) NTT_BF(1, 5, (j + g) << s0) NTT_BF(2, 6, (j + 2 * g) << s0) NTT_BF(3, 7, (j + 3 * g) << s0)
+  NTT_BF(0, 2, j << s1) NTT_BF(1, 3, (j + g) << s1) NTT_BF(4, 6, j << s1) NTT_BF(5, 7, (j + g) << s1)
+  NTT_BF(0, 1, j << s2) NTT_BF(2, 3, j << s2) NTT_BF(4, 5, j << s2) NTT_BF(6, 7, j << s2)
+}
+template <>
+__device__ __forceinline__ void dif_butterfly<2>(fe (&x)[4], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi)
+{
+  const int g = 1 << (log_m - 2);
+  const int s0 = log_r - log_m, s1 = s0 + 1;
+  NTT_BF(0, 2, j << s0) NTT_BF(1, 3, (j + g) << s0)
+  NTT_BF(0, 1, j << s1) NTT_BF(2, 3, j << s1)
+}
+template <>
+__device__ __forceinline__ void dif_butterfly<1>(fe (&x)[2], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi)
+{
+  NTT_BF(0, 1, j << (log_r - log_m))
+}
+#undef NTT_BF
+
+// one round of radix-2^Q butterflies over the whole tile: 8 >> Q groups per thread
+template <int Q>
+__device__ __forceinline__ void dif_round(uint4* lo, uint4* hi, const uint4* twlo, const uint4* twhi, int log_m, int log_r, int log_c, int tid)
+{
+  const int C = 1 << log_c;
+  const int log_g = log_m - Q; // groups per sub-transform = M >> Q
+#pragma unroll
+  for (int u = 0; u < (8 >> Q); u++) {
+    const int gi = tid * (8 >> Q) + u;
+    const int c = gi & (C - 1);
+    const int rest = gi >> log_c;
+    const int j = rest & ((1 << log_g) - 1);
+    const int blk = rest >> log_g;
+    const int base_row = (blk << log_m) + j;
+    fe x[1 << Q];
+#pragma unroll
+    for (int k = 0; k < (1 << Q); k++) x[k] = lds_get(lo, hi, ((base_row + (k << log_g)) << log_c) + c);
+    dif_butterfly<Q>(x, j, log_m, log_r, twlo, twhi);
+#pragma unroll
+    for (int k = 0; k < (1 << Q); k++) lds_put(lo, hi, ((base_row + (k << log_g)) << log_c) + c, x[k]);
+  }
+}
+
+// One pass: grid = (tiles, batch); the tile always holds 2048 elements = 8 per thread (smaller transforms
+// are padded by idle threads).  LDS: two uint4 planes of R·C entries + R/2 stage twiddles.
+// The size-R sub-transforms run as ⌈log R / 3⌉ rounds of radix-8 (then one radix-4 / radix-2 round) with the
+// eight operands of a butterfly in registers — one LDS round trip and one barrier per THREE radix-2 stages.
+__global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ in, fe* __restrict__ out, const fe* __restrict__ tw, PassParams p, fe ninv_mont)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int R = 1 << p.log_r, C = 1 << p.log_c, RC = R * C;
@@ -139,50 +205,99 @@ __global__ __launch_bounds__(NT) void ntt_pass_kernel(const fe* __restrict__ in,
     fe w = g_get(tw + tw_index((uint32_t)e * p.stage_stride, p.n_mask, p.inverse));
     lds_put(twlo, twhi, e, w);
   }
-  // load tile: LDS index = r·C + c
-  for (int e = tid; e < RC; e += NT) {
-    int r, c;
-    if (p.load_rows_fastest) { r = e & (R - 1); c = e >> p.log_r; }
-    else { c = e & (C - 1); r = e >> p.log_c; }
-    fe v = g_get(src + (uint64_t)r * p.in_row + (uint64_t)c * p.in_col);
-    lds_put(lo, hi, (r << p.log_c) + c, v);
+  // load tile: LDS index = r·C + c.  All of a thread's loads are issued before the first LDS store.
+  if (RC == NT * 8) {
+    fe v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = tid + u * NT;
+      int r, c;
+      if (p.load_rows_fastest) { r = e & (R - 1); c = e >> p.log_r; }
+      else { c = e & (C - 1); r = e >> p.log_c; }
+      v[u] = g_get(src + (uint64_t)r * p.in_row + (uint64_t)c * p.in_col);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = tid + u * NT;
+      int r, c;
+      if (p.load_rows_fastest) { r = e & (R - 1); c = e >> p.log_r; }
+      else { c = e & (C - 1); r = e >> p.log_c; }
+      lds_put(lo, hi, (r << p.log_c) + c, v[u]);
+    }
+  } else {
+    for (int e = tid; e < RC; e += NT) {
+      int r, c;
+      if (p.load_rows_fastest) { r = e & (R - 1); c = e >> p.log_r; }
+      else { c = e & (C - 1); r = e >> p.log_c; }
+      lds_put(lo, hi, (r << p.log_c) + c, g_get(src + (uint64_t)r * p.in_row + (uint64_t)c * p.in_col));
+    }
   }
   __syncthreads();
 
-  // radix-2 DIF stages over rows: natural order in → bit-reversed order out
-  const int nbf = RC >> 1;
-  for (int s = p.log_r - 1; s >= 0; s--) {
-    const int h = 1 << s; // half size
-    for (int q = tid; q < nbf; q += NT) {
-      const int c = q & (C - 1);
-      const int bf = q >> p.log_c;
-      const int j = bf & (h - 1);
-      const int i = ((bf >> s) << (s + 1)) + j;
-      const int ia = (i << p.log_c) + c, ib = ((i + h) << p.log_c) + c;
-      fe a = lds_get(lo, hi, ia), bb = lds_get(lo, hi, ib);
-      fe sum = Fr::add(a, bb);
-      fe dif = Fr::sub(a, bb);
-      const int e = j << (p.log_r - 1 - s);
-      if (e != 0) dif = Fr::mul(dif, lds_get(twlo, twhi, e));
-      lds_put(lo, hi, ia, sum);
-      lds_put(lo, hi, ib, dif);
+  if (RC == NT * 8) {
+    // natural order in → bit-reversed order out, three radix-2 stages per round
+    int log_m = p.log_r;
+    while (log_m >= 3) {
+      dif_round<3>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
+      __syncthreads();
+      log_m -= 3;
     }
-    __syncthreads();
+    if (log_m == 2) {
+      dif_round<2>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
+      __syncthreads();
+    } else if (log_m == 1) {
+      dif_round<1>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
+      __syncthreads();
+    }
+  } else {
+    // small transforms (tile smaller than 2048 elements): plain radix-2 stages
+    const int nbf = RC >> 1;
+    for (int s = p.log_r - 1; s >= 0; s--) {
+      const int h = 1 << s;
+      for (int q = tid; q < nbf; q += NT) {
+        const int c = q & (C - 1);
+        const int bf = q >> p.log_c;
+        const int j = bf & (h - 1);
+        const int i = ((bf >> s) << (s + 1)) + j;
+        const int ia = (i << p.log_c) + c, ib = ((i + h) << p.log_c) + c;
+        fe a = lds_get(lo, hi, ia), bb = lds_get(lo, hi, ib);
+        fe sum = Fr::add(a, bb);
+        fe dif = Fr::sub(a, bb);
+        const int e = j << (p.log_r - 1 - s);
+        if (e != 0) dif = Fr::mul(dif, lds_get(twlo, twhi, e));
+        lds_put(lo, hi, ia, sum);
+        lds_put(lo, hi, ib, dif);
+      }
+      __syncthreads();
+    }
   }
 
-  // store: LDS row s holds k = bitrev(s)
-  for (int e = tid; e < RC; e += NT) {
-    const int c = e & (C - 1);
-    const int srow = e >> p.log_c;
-    const uint32_t k = __brev((uint32_t)srow) >> (32 - p.log_r);
-    fe v = lds_get(lo, hi, e);
-    if (p.tw_mul) {
-      const uint32_t t = (b_lo << p.log_c) + c;
-      const uint32_t ex = k * t * p.tw_mul;
-      if (ex) v = Fr::mul(v, g_get(tw + tw_index(ex, p.n_mask, p.inverse)));
+  // store: LDS row s holds k = bitrev(s); inter-pass twiddle and 1/n fused here
+  for (int e0 = tid; e0 < RC; e0 += NT * 4) {
+    fe v[4], w[4];
+    uint32_t kk[4], ex[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * NT;
+      ex[u] = 0;
+      if (e < RC) {
+        const int c = e & (C - 1);
+        kk[u] = __brev((uint32_t)(e >> p.log_c)) >> (32 - p.log_r);
+        if (p.tw_mul) ex[u] = kk[u] * ((b_lo << p.log_c) + c) * p.tw_mul;
+        if (ex[u]) w[u] = g_get(tw + tw_index(ex[u], p.n_mask, p.inverse));
+      }
     }
-    if (p.scale) v = Fr::mul(v, ninv_mont);
-    g_put(dst + (uint64_t)k * p.out_row + (uint64_t)c * p.out_col, v);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * NT;
+      if (e < RC) {
+        const int c = e & (C - 1);
+        fe x = lds_get(lo, hi, e);
+        if (ex[u]) x = Fr::mul(x, w[u]);
+        if (p.scale) x = Fr::mul(x, ninv_mont);
+        g_put(dst + (uint64_t)kk[u] * p.out_row + (uint64_t)c * p.out_col, x);
+      }
+    }
   }
 }
 
@@ -363,7 +478,7 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
   int np, lr[3] = {0, 0, 0};
   if (logn <= MAX_LOG_R) { np = 1; lr[0] = logn; }
   else if (logn <= 2 * MAX_LOG_R) { np = 2; lr[0] = (logn + 1) / 2; lr[1] = logn / 2; }
-  else { np = 3; lr[0] = (logn + 2) / 3; lr[1] = (logn + 1) / 3; lr[2] = logn / 3; }
+  else { np = 3; lr[0] = MAX_LOG_R; lr[1] = (logn - MAX_LOG_R + 1) / 2; lr[2] = (logn - MAX_LOG_R) / 2; } // 9 bits = three radix-8 rounds
 
   fe* scratch = nullptr;
   const bool need_pre_coset = has_coset && !inverse;
