@@ -216,6 +216,44 @@ struct Fp {
     }
     return reduce_once(r); // a·b·R^-1 < 2p < 2^255: nothing left in acc
   }
+  // (a·b + c·d)·R^-1 mod p in ONE reduction: both products are summed into the same column accumulators
+  // (a·b + c·d < 2p² < p·R/2, so the Montgomery quotient still leaves a value < 2p).  192 multiply-adds
+  // instead of 272 for two multiplies and an addition; used by the Fq2 multiply (ec.h).
+  static __device__ __forceinline__ fe mul2sum(const fe& a, const fe& b, const fe& c, const fe& d)
+  {
+    uint64_t acc = 0;
+    uint32_t top = 0;
+    uint32_t m[8];
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        mac96(acc, top, a.l[i], b.l[k - i]);
+        mac96(acc, top, c.l[i], d.l[k - i]);
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) mac96s(acc, top, m[i], P::MOD[k - i]);
+      m[k] = (uint32_t)acc * P::NINV;
+      mac96s(acc, top, m[k], P::MOD[0]);
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) {
+        mac96(acc, top, a.l[i], b.l[k - i]);
+        mac96(acc, top, c.l[i], d.l[k - i]);
+      }
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96s(acc, top, m[i], P::MOD[k - i]);
+      r.l[k - 8] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+    }
+    return reduce_once(r);
+  }
 #else
   static FF_HD fe mul(const fe& a, const fe& b)
   {
@@ -249,6 +287,7 @@ struct Fp {
     for (int i = 0; i < 8; i++) r.l[i] = t[i];
     return reduce_once(r);
   }
+  static FF_HD fe mul2sum(const fe& a, const fe& b, const fe& c, const fe& d) { return add(mul(a, b), mul(c, d)); }
 #endif
   static FF_HD fe sqr(const fe& a) { return mul(a, a); }
 

@@ -25,6 +25,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -518,11 +519,6 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
     p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
   };
   uint8_t* DP = z->d_partials;
-  fill(prof[2], plan_w, 1);
-  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 1, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2])); // commitment_b — src/proof_helper.rs:206
-  (void)hipEventRecord(prof[2]->ev[3], g2);
-  prof[2]->valid = true;
-  P_HIP(hipEventRecord(z->ev_g2done, g2));
 
   // ---- stream g1: construct_r1cs (src/proof_helper.rs:31-170) on the device
   P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, g1));
@@ -541,6 +537,16 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kForward, &nc, (bn254_scalar_t*)z->d_vec)); // :145
   P_HIP(qap_final(z->d_vec, n, g1));                                                                        // :154-167
   P_HIP(hipEventRecord(z->ev[2], g1));
+
+  // ---- stream g2: G2 bucket stages.  Held back until the QAP front end is done: the G2 accumulation
+  // fills every CU with ~4 ms workgroups, and the NTT passes of the (longer) g1 chain measured 8× slower
+  // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
+  P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
+  fill(prof[2], plan_w, 1);
+  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 1, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2])); // commitment_b — src/proof_helper.rs:206
+  (void)hipEventRecord(prof[2]->ev[3], g2);
+  prof[2]->valid = true;
+  P_HIP(hipEventRecord(z->ev_g2done, g2));
 
   // ---- stream g1: groth16_commitments — src/proof_helper.rs:198-205 : A, B1, C (shared sort), then H
   P_HIP(hipStreamWaitEvent(g1, z->ev_sort, 0));
@@ -573,11 +579,16 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
   const uint8_t* HP = z->h_partials;
-  msm_g1_host_tail(HP + 0 * PARTIALS_STRIDE, Ww, bw1, plan_w.g.c, (bn254_projective_t*)(out_points + 0));
-  msm_g1_host_tail(HP + 1 * PARTIALS_STRIDE, Ww, bw1, plan_w.g.c, (bn254_projective_t*)(out_points + 96));
-  msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, bw2, plan_w.g.c, (bn254_g2_projective_t*)(out_points + 192));
-  msm_g1_host_tail(HP + 3 * PARTIALS_STRIDE, Ww, bw1, plan_w.g.c, (bn254_projective_t*)(out_points + 384));
-  msm_g1_host_tail(HP + 4 * PARTIALS_STRIDE, Wh, bh, plan_h.g.c, (bn254_projective_t*)(out_points + 480));
+  {
+    // five independent Horner tails (≈0.2 ms each, the G2 one ≈0.7 ms): one host thread each
+    const int cw = plan_w.g.c, ch = plan_h.g.c;
+    std::thread t0([&] { msm_g1_host_tail(HP + 0 * PARTIALS_STRIDE, Ww, bw1, cw, (bn254_projective_t*)(out_points + 0)); });
+    std::thread t1([&] { msm_g1_host_tail(HP + 1 * PARTIALS_STRIDE, Ww, bw1, cw, (bn254_projective_t*)(out_points + 96)); });
+    std::thread t3([&] { msm_g1_host_tail(HP + 3 * PARTIALS_STRIDE, Ww, bw1, cw, (bn254_projective_t*)(out_points + 384)); });
+    std::thread t4([&] { msm_g1_host_tail(HP + 4 * PARTIALS_STRIDE, Wh, bh, ch, (bn254_projective_t*)(out_points + 480)); });
+    msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, bw2, cw, (bn254_g2_projective_t*)(out_points + 192));
+    t0.join(); t1.join(); t3.join(); t4.join();
+  }
   if (tm) {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
