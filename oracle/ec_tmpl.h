@@ -243,51 +243,58 @@ static void PFX(msm)(PFX(proj)* out, const u256* scalars, const PFX(aff)* bases,
     if (c > 16) c = 16;
   }
   const int nbm = (254 - 1) / c + 1 + 1; /* +1: room for the final carry */
-  const int bm_size = 1 << (c - 1);      /* buckets 1..2^(c-1) per window (index 0 ↔ digit magnitude 2^(c-1)… see below) */
+  const int bm_size = 1 << (c - 1);      /* buckets per window: digit magnitudes 1..2^(c-1) */
   const size_t nb = (size_t)nbm * bm_size;
   int T = 1;
 #ifdef _OPENMP
   T = omp_get_max_threads();
 #endif
-  if (T > n) T = n > 0 ? n : 1;
-  PFX(proj)* buckets = (PFX(proj)*)malloc(sizeof(PFX(proj)) * nb * T);
-  uint8_t* busy = (uint8_t*)calloc(nb * T, 1);
-  const int per = (n + T - 1) / T;
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-  for (int t = 0; t < T; t++) {
-    PFX(proj)* B = buckets + (size_t)t * nb;
-    uint8_t* busyB = busy + (size_t)t * nb;
-    int lo = t * per, hi = lo + per < n ? lo + per : n;
-    for (int i = lo; i < hi; i++) {
-      if (PFX(aff_is_zero)(&bases[i])) continue;
-      u256 s = scalars[i];
-      int negate = (int)((s.l[3] >> 61) & 1); /* bit 253 = top bit of a 254-bit scalar */
-      if (negate) fp_neg(&FR, &s, &s);
-      PFX(aff) base_neg;
-      PFX(aff_neg)(&base_neg, &bases[i]);
-      uint32_t carry = 0;
-      for (int w = 0; w < nbm; w++) {
-        uint32_t d = u256_digit(&s, (unsigned)w, (unsigned)c) + carry;
-        carry = 0;
+  /* worker layout: the reference gives every worker a private bucket array over a slice of the input
+   * (cpu_msm.hpp:240-247).  With many cores that costs T full bucket arrays; here the T workers are a
+   * (windows × slices) grid instead — worker (w, sl) owns window w of slice sl — so memory and the merge
+   * step scale with the number of slices, not with T. */
+  int slices = T / nbm;
+  if (slices < 1) slices = 1;
+  if (slices > n) slices = n > 0 ? n : 1;
+  PFX(proj)* buckets = (PFX(proj)*)malloc(sizeof(PFX(proj)) * nb * slices);
+  uint8_t* busy = (uint8_t*)calloc(nb * slices, 1);
+  const int per = (n + slices - 1) / slices;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (int sl = 0; sl < slices; sl++) {
+    for (int w = 0; w < nbm; w++) {
+      PFX(proj)* B = buckets + (size_t)sl * nb + (size_t)w * bm_size;
+      uint8_t* busyB = busy + (size_t)sl * nb + (size_t)w * bm_size;
+      int lo = sl * per, hi = lo + per < n ? lo + per : n;
+      for (int i = lo; i < hi; i++) {
+        if (PFX(aff_is_zero)(&bases[i])) continue;
+        u256 s = scalars[i];
+        int negate = (int)((s.l[3] >> 61) & 1); /* bit 253 = top bit of a 254-bit scalar */
+        if (negate) fp_neg(&FR, &s, &s);
+        /* signed digit of window w: d_w = raw_w + carry_w, carry chain recomputed from window 0 */
+        uint32_t carry = 0, d = 0;
+        for (int v = 0; v <= w; v++) {
+          d = u256_digit(&s, (unsigned)v, (unsigned)c) + carry;
+          carry = d > (uint32_t)bm_size ? 1 : 0;
+        }
         if (d == 0) continue;
         int neg_digit = 0;
         if (d > (uint32_t)bm_size) { /* digit in (2^(c-1), 2^c] → d − 2^c, carry 1 */
           d = (1u << c) - d;
           neg_digit = 1;
-          carry = 1;
           if (d == 0) continue; /* d was exactly 2^c */
         }
-        size_t idx = (size_t)w * bm_size + (d - 1);
-        const PFX(aff)* P = (negate ^ neg_digit) ? &base_neg : &bases[i];
-        if (busyB[idx]) PFX(add_mixed)(&B[idx], &B[idx], P);
-        else { PFX(from_affine)(&B[idx], P); busyB[idx] = 1; }
+        PFX(aff) base_neg;
+        const PFX(aff)* P = &bases[i];
+        if (negate ^ neg_digit) { PFX(aff_neg)(&base_neg, &bases[i]); P = &base_neg; }
+        if (busyB[d - 1]) PFX(add_mixed)(&B[d - 1], &B[d - 1], P);
+        else { PFX(from_affine)(&B[d - 1], P); busyB[d - 1] = 1; }
       }
     }
   }
-  /* merge worker copies into copy 0 */
+  /* merge slice copies into copy 0 */
 #pragma omp parallel for schedule(static)
   for (int64_t k = 0; k < (int64_t)nb; k++) {
-    for (int t = 1; t < T; t++) {
+    for (int t = 1; t < slices; t++) {
       size_t o = (size_t)t * nb + k;
       if (!busy[o]) continue;
       if (busy[k]) PFX(add)(&buckets[k], &buckets[k], &buckets[o]);
