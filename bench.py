@@ -94,6 +94,7 @@ def main():
     P = importlib.import_module("icicle-snark_amd.parallel")
     K.set_device("HIP", local_rank)
     if world > 1:
+        P.preload_rccl()   # our RCCL (on our HIP runtime) must be loaded before torch's bundled copy
         # control plane: torch.distributed (gloo) — rendezvous, barriers, broadcast of the ncclUniqueId.
         # data plane: RCCL all-gather over xGMI on this library's HIP runtime (csrc/comm/rccl_comm.cpp).
         # torch's own HIP runtime is never initialised in this process (it bundles a different ROCm).

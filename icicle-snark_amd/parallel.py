@@ -19,6 +19,28 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 RCCL_LIB_PATH = os.path.join(_HERE, "lib", "libicicle_snark_rccl.so")
 
 
+_rccl_lib = None
+
+
+def preload_rccl():
+    """Load libicicle_snark_rccl.so (and with it /opt/rocm's librccl.so.1, which sits on this library's HIP
+    runtime).  MUST run before `import torch`: the torch wheel bundles its own librccl with the same soname,
+    built for its own bundled HIP runtime; whichever is loaded first serves both, and ours must win."""
+    global _rccl_lib
+    if _rccl_lib is None:
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise ImportError(f"{RCCL_LIB_PATH} is missing: run `make`")
+        import sys
+        if "torch" in sys.modules:
+            maps = open("/proc/self/maps").read()
+            if "torch/lib/librccl" in maps:
+                raise RuntimeError("torch (and its bundled librccl) was imported before preload_rccl(); "
+                                   "call icicle-snark_amd.parallel.preload_rccl() first")
+        _rccl_lib = C.CDLL(RCCL_LIB_PATH)
+        _rccl_lib.icicle_snark_rccl_last_error.restype = C.c_char_p
+    return _rccl_lib
+
+
 def shard_range(total: int, rank: int, world: int):
     return total * rank // world, total * (rank + 1) // world
 
@@ -72,13 +94,10 @@ class RcclExchange:
     """RCCL all-gather on this library's HIP runtime; the id travels over the torch.distributed control plane."""
 
     def __init__(self, device_id: int, max_bytes: int = 4096):
+        self.lib = preload_rccl()          # before torch: see preload_rccl()
         import torch.distributed as dist
         self.dist = dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        if not os.path.exists(RCCL_LIB_PATH):
-            raise ImportError(f"{RCCL_LIB_PATH} is missing: run `make`")
-        self.lib = C.CDLL(RCCL_LIB_PATH)
-        self.lib.icicle_snark_rccl_last_error.restype = C.c_char_p
         ident = [None]
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
