@@ -43,6 +43,15 @@ struct FqOps {
 
 // Fq2 = Fq[u]/(u² + 1) — icicle/include/icicle/fields/complex_extension.h, nonresidue −1
 // (icicle/include/icicle/fields/snark_fields/bn254_base.h:66-70)
+// Fq2 multiply / square: out-of-line calls on the device by default (bounds code size and compile time of
+// the many kernels that contain full XYZZ additions); the translation unit of the hot G2 bucket-accumulation
+// kernel defines ISNARK_FQ2_INLINE and gets them inlined (no call-boundary register shuffles, no scratch).
+#if defined(ISNARK_FQ2_INLINE) && defined(__HIP_DEVICE_COMPILE__)
+#define FQ2_FN __device__ __forceinline__
+#else
+#define FQ2_FN FF_HD_NOINLINE
+#endif
+
 struct Fq2Ops {
   typedef fe2 T;
   static constexpr int NFE = 2;
@@ -55,13 +64,13 @@ struct Fq2Ops {
   // Out of line on the device: a G2 point addition inlines ~14 of these (3 Fq multiplies each);
   // keeping them as calls bounds code size and compile time at no measurable cost (the call
   // overhead is ~1 % of the ~1.6 k instructions inside).
-  static FF_HD_NOINLINE T mul(const T& a, const T& b)
+  static FQ2_FN T mul(T a, T b) // operands BY VALUE: they travel in VGPRs; references would go through scratch
   {
     // (a0 b0 − a1 b1) + (a0 b1 + a1 b0) u, each component as ONE fused two-product Montgomery reduction
     // (Fq::mul2sum): 2 × 192 multiply-adds, against 3 × 136 + five modular add/subs for Karatsuba.
     return {Fq::mul2sum(a.c0, b.c0, a.c1, Fq::neg(b.c1)), Fq::mul2sum(a.c0, b.c1, a.c1, b.c0)};
   }
-  static FF_HD_NOINLINE T sqr(const T& a)
+  static FQ2_FN T sqr(T a)
   {
     // (a0 + a1)(a0 − a1) + 2 a0 a1 u
     fe t = Fq::mul(a.c0, a.c1);

@@ -1,4 +1,5 @@
 // msm_g2.hip — G2 (Fq2 coordinates) instantiation of the MSM pipeline (see msm_impl.h).
+#define ISNARK_G2_ACC_EXTERN 1
 #include "msm_impl.h"
 
 namespace isnark {

@@ -257,6 +257,25 @@ __global__ __launch_bounds__(64) void batch_to_affine_kernel(const typename C::P
 }
 
 
+// launch of the bucket-accumulation kernel; the G2 instance lives in its own translation unit
+// (msm_g2_acc.hip, Fq2 arithmetic inlined)
+template <class C>
+struct AccumulateLauncher {
+  static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, hipStream_t s, typename C::X* buckets)
+  {
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, mont_pt, buckets);
+  }
+};
+#if defined(ISNARK_G2_ACC_EXTERN)
+template <>
+struct AccumulateLauncher<G2> {
+  static void launch(const SortPlan* pl, const G2::A* d_points, int mont_pt, uint32_t skip_below, hipStream_t s, G2::X* buckets)
+  {
+    isnark::msm_g2_accumulate_launch(pl, d_points, mont_pt, skip_below, s, buckets);
+  }
+};
+#endif
+
 struct ReduceShape {
   int k_log;
   uint32_t tpw, rblock, bpw;
@@ -283,7 +302,7 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   X* buckets = nullptr;
   HIP_TRY(ws_alloc((void**)&buckets, (size_t)pl->nbuckets * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);
-  hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, mont_pt, buckets);
+  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, s, buckets);
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
