@@ -181,8 +181,8 @@ struct ZKeyCache {
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   fe* h_witness = nullptr;      // pinned staging, n_vars
-  hipStream_t s_g1 = nullptr, s_g2 = nullptr;
-  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_g2done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr;
+  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
 
@@ -191,14 +191,17 @@ struct ZKeyCache {
     (void)hipSetDevice(device_id);
     if (s_g1) (void)hipStreamSynchronize(s_g1);
     if (s_g2) (void)hipStreamSynchronize(s_g2);
+    if (s_g3) (void)hipStreamSynchronize(s_g3);
     for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_partials})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
     if (h_witness) (void)hipHostFree(h_witness);
     if (s_g1) (void)icicle_destroy_stream(s_g1);
     if (s_g2) (void)icicle_destroy_stream(s_g2);
+    if (s_g3) (void)icicle_destroy_stream(s_g3);
     if (ev_witness) (void)hipEventDestroy(ev_witness);
     if (ev_sort) (void)hipEventDestroy(ev_sort);
+    if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
     if (ev_g2done) (void)hipEventDestroy(ev_g2done);
     for (auto e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -351,8 +354,10 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_g2done, hipEventDisableTiming));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
   out = std::move(z);
@@ -490,7 +495,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   if (int rc = ensure_domain(cm, z)) return rc;
 
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
-  hipStream_t g1 = z->s_g1, g2 = z->s_g2;
+  hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3;
   if (wtns) {
     Wtns w;
     if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
@@ -548,6 +553,12 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   prof[2]->valid = true;
   P_HIP(hipEventRecord(z->ev_g2done, g2));
 
+  // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
+  P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
+  (void)hipEventRecord(prof[4]->ev[0], g3);
+  P_ICICLE(msm_sort_run(z->d_vec + n + z->H.lo, z->H.len(), 0, 10, 0, g3, &plan_h));
+  P_HIP(hipEventRecord(z->ev_sort_h, g3));
+
   // ---- stream g1: groth16_commitments — src/proof_helper.rs:198-205 : A, B1, C (shared sort), then H
   P_HIP(hipStreamWaitEvent(g1, z->ev_sort, 0));
   const uint32_t skip_below = skip > wlo ? skip - wlo : 0; // C ignores witness[0..=n_public]
@@ -561,8 +572,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
     (void)hipEventRecord(p->ev[3], g1);
     p->valid = true;
   }
-  (void)hipEventRecord(prof[4]->ev[0], g1);
-  P_ICICLE(msm_sort_run(z->d_vec + n + z->H.lo, z->H.len(), 0, 10, 0, g1, &plan_h));
+  P_HIP(hipStreamWaitEvent(g1, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 1, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4]));
   (void)hipEventRecord(prof[4]->ev[3], g1);
@@ -576,6 +586,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   for (int k = 0; k < 5; k++) P_HIP(hipMemcpyAsync(z->h_partials + k * PARTIALS_STRIDE, DP + k * PARTIALS_STRIDE, sizes[k], hipMemcpyDeviceToHost, g1));
   P_HIP(hipStreamSynchronize(g1));
   P_HIP(hipStreamSynchronize(g2));
+  P_HIP(hipStreamSynchronize(g3));
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
   const uint8_t* HP = z->h_partials;
