@@ -169,6 +169,15 @@ def main():
         # sorted index + one 64-B affine base gathered; per bucket 8 B of (offset,count) + a 128-B XYZZ result
         alg_bytes = g["L"] * g["W"] * (4 + 64) + g["nbuckets"] * (8 + 128)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        # HBM traffic of the same kernel/geometry from the PMC counters (separate rocprofv3 passes, committed under
+        # profiles/); only quoted when the geometry matches the profiled launch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if all(pmc["geometry"][k] == g[k] for k in ("L", "c", "W", "nbuckets")):
+                traffic = pmc["traffic_bytes"]
+        except Exception:
+            pass
         out = {
             "metric": "groth16_prove_constraints_per_s", "value": N / (ms_per_step * 1e-3), "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -180,7 +189,7 @@ def main():
                        "prove_ms_with_witness_over_pcie": pcie_ms,
                        "phase_ms": {"qap_ntt": phases["qap"] / args.steps, "msm": phases["msm"] / args.steps}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
+                         "traffic": traffic, "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
                          "algorithmic_bytes": alg_bytes, "geometry": g},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -39,6 +39,8 @@ struct FqOps {
   static FF_HD T to_mont(const T& a) { return Fq::to_mont(a); }
   static FF_HD T from_mont(const T& a) { return Fq::from_mont(a); }
   static FF_HD T inv(const T& a) { return Fq::inv(a); }
+  // a·b − c·d with a single Montgomery reduction
+  static FF_HD T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return Fq::mul2sum(a, b, Fq::neg(c), d); }
 };
 
 // Fq2 = Fq[u]/(u² + 1) — icicle/include/icicle/fields/complex_extension.h, nonresidue −1
@@ -81,6 +83,7 @@ struct Fq2Ops {
   static FF_HD bool eq(const T& a, const T& b) { return Fq::eq(a.c0, b.c0) && Fq::eq(a.c1, b.c1); }
   static FF_HD T to_mont(const T& a) { return {Fq::to_mont(a.c0), Fq::to_mont(a.c1)}; }
   static FF_HD T from_mont(const T& a) { return {Fq::from_mont(a.c0), Fq::from_mont(a.c1)}; }
+  static FF_HD T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
   static FF_HD T inv(const T& a)
   {
     fe n = Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1));
@@ -172,7 +175,7 @@ struct Curve {
     T PPP = F::mul(Pd, PP);
     T Q = F::mul(acc.x, PP);
     T X3 = F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q));
-    T Y3 = F::sub(F::mul(Rd, F::sub(Q, X3)), F::mul(acc.y, PPP));
+    T Y3 = F::mul_sub_mul(Rd, F::sub(Q, X3), acc.y, PPP); // R·(Q − X3) − Y1·PPP, one reduction (G1)
     acc.x = X3;
     acc.y = Y3;
     acc.zz = F::mul(acc.zz, PP);
