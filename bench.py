@@ -190,7 +190,12 @@ def main():
                        "phase_ms": {"qap_ntt": phases["qap"] / args.steps, "msm": phases["msm"] / args.steps}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
-                         "algorithmic_bytes": alg_bytes, "geometry": g},
+                         "algorithmic_bytes": alg_bytes, "geometry": g,
+                         # the kernel is integer-VALU bound (PMC: VALU active ≈100 % of the launch); its meaningful
+                         # ceiling is the measured Fq multiply rate of ff.h (125 G/s): one XYZZ mixed
+                         # add = 10 field multiplies (one of them fused), L·W adds per launch
+                         "alu": {"achieved_gmul_per_s": g["L"] * g["W"] * 10 / (kern_ms * 1e-3) / 1e9, "peak_gmul_per_s": 125.0,
+                                 "frac": g["L"] * g["W"] * 10 / (kern_ms * 1e-3) / 1e9 / 125.0}},
         }
         if world == 1 and not args.no_cpu_baseline:
             cm.evict(key)

@@ -80,7 +80,7 @@ icicle_get_active_device icicle_is_host_memory icicle_is_active_device_memory ic
 icicle_is_device_available icicle_get_registered_devices icicle_malloc icicle_malloc_async icicle_free icicle_free_async
 icicle_get_available_memory icicle_memset icicle_memset_async icicle_copy icicle_copy_async icicle_copy_to_host
 icicle_copy_to_host_async icicle_copy_to_device icicle_copy_to_device_async icicle_create_stream icicle_destroy_stream
-icicle_stream_synchronize icicle_device_synchronize
+icicle_stream_synchronize icicle_device_synchronize icicle_get_device_properties
 create_config_extension destroy_config_extension config_extension_set_int config_extension_set_bool
 config_extension_get_int config_extension_get_bool clone_config_extension
 bn254_generate_scalars bn254_add bn254_sub bn254_mul bn254_inv bn254_pow bn254_from_u32

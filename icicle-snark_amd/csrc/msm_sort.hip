@@ -179,46 +179,136 @@ __global__ __launch_bounds__(SCAN_T) void msm_scan_finish_kernel(const uint32_t*
   }
 }
 
-// ---- order buckets by decreasing size (counting sort on min(count, ORDER_BINS-1)) ----------------
-// One thread accumulates one bucket; buckets of a wave should hold the same number of points or the
-// wave runs for its largest bucket (random digits: Poisson sizes, a quarter of the lanes idle —
-// SQ_THREAD_CYCLES_VALU / (64·SQ_ACTIVE_INST_VALU) = 0.77 before this ordering).  The reference sorts
-// bucket sizes with two more CUB radix sorts (cuda_msm.cuh:606-630); sizes are small integers, so a
-// counting sort is enough.
-constexpr int ORDER_BINS = 2048;
-__global__ __launch_bounds__(256) void msm_size_hist_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ size_hist)
-{
-  __shared__ uint32_t sh[ORDER_BINS];
-  for (int i = threadIdx.x; i < ORDER_BINS; i += blockDim.x) sh[i] = 0;
-  __syncthreads();
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < m; b += stride) atomicAdd(&sh[min(counts[b], (uint32_t)ORDER_BINS - 1)], 1u);
-  __syncthreads();
-  for (int i = threadIdx.x; i < ORDER_BINS; i += blockDim.x)
-    if (sh[i]) atomicAdd(&size_hist[i], sh[i]);
-}
-// exclusive scan in DESCENDING key order: start[k] = number of buckets with a larger key
-__global__ __launch_bounds__(256) void msm_size_scan_kernel(uint32_t* size_hist /* in: hist, out: start */)
+// generic finish of the 3-kernel exclusive scan: out[i] = bsum[block] + local exclusive prefix
+__global__ __launch_bounds__(SCAN_T) void msm_scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t m, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ out)
 {
   __shared__ uint32_t sh[SCAN_T];
-  const int per = ORDER_BINS / SCAN_T; // 8 keys per thread, thread 0 owns the largest keys
-  uint32_t v[8], s = 0;
-  for (int k = 0; k < per; k++) {
-    v[k] = size_hist[ORDER_BINS - 1 - (threadIdx.x * per + k)];
+  const uint32_t base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_E;
+  uint32_t v[SCAN_E], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_E; k++) {
+    v[k] = base + k < m ? in[base + k] : 0;
     s += v[k];
   }
-  uint32_t run = block_exclusive_scan(s, sh, nullptr);
-  for (int k = 0; k < per; k++) {
-    size_hist[ORDER_BINS - 1 - (threadIdx.x * per + k)] = run;
+  uint32_t run = bsum[blockIdx.x] + block_exclusive_scan(s, sh, nullptr);
+#pragma unroll
+  for (int k = 0; k < SCAN_E; k++) {
+    if (base + k < m) out[base + k] = run;
     run += v[k];
   }
 }
-__global__ __launch_bounds__(256) void msm_size_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ size_cursor, uint32_t* __restrict__ order)
+
+// ---- order buckets by decreasing size (counting sort on min(count, ORDER_BINS-1)) ----------------
+// One thread accumulates one bucket; buckets of a wave should hold the same number of points or the
+// wave runs for its largest bucket (random digits: Poisson sizes, a quarter of the lanes idle —
+// SQ_THREAD_CYCLES_VALU / (64·SQ_ACTIVE_INST_VALU) = 0.77 before this ordering, 0.99 after).  The
+// reference sorts bucket sizes with two more CUB radix sorts (cuda_msm.cuh:606-630); sizes are small
+// integers, so a counting sort is enough: per-workgroup LDS histograms, one scan, LDS ranks — no global
+// atomics (a first version with global atomics on ~100 hot counters cost 1.1 ms at 2^19 buckets).
+constexpr int ORDER_BINS = 256;
+__device__ __forceinline__ uint32_t order_key(uint32_t cnt) { return (uint32_t)ORDER_BINS - 1 - min(cnt, (uint32_t)ORDER_BINS - 1); } // ascending key = descending size
+__global__ __launch_bounds__(ORDER_BINS) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t nblk, uint32_t* __restrict__ blockhist)
 {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= m) return;
-  const uint32_t pos = atomicAdd(&size_cursor[min(counts[b], (uint32_t)ORDER_BINS - 1)], 1u);
-  order[pos] = b;
+  __shared__ uint32_t h[ORDER_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * ORDER_BINS + threadIdx.x;
+  if (b < m) atomicAdd(&h[order_key(counts[b])], 1u);
+  __syncthreads();
+  blockhist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x]; // key-major
+}
+__global__ __launch_bounds__(ORDER_BINS) void msm_order_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t nblk, const uint32_t* __restrict__ scanned, uint32_t* __restrict__ order)
+{
+  __shared__ uint32_t h[ORDER_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * ORDER_BINS + threadIdx.x;
+  if (b < m) {
+    const uint32_t key = order_key(counts[b]);
+    const uint32_t r = atomicAdd(&h[key], 1u);
+    order[scanned[key * nblk + blockIdx.x] + r] = b;
+  }
+}
+
+// ---- two-level scatter ----------------------------------------------------------------------------
+// The one-level scatter writes 4 bytes at a random position of a 134 MB array per digit (PMC: WRITE_SIZE 2.0 GB for
+// 134 MB of payload at L = 2^21 — every store is its own partial-line write).  Two levels keep every store inside
+// a small, densely written region:
+//  A  (msm_partition_kernel)   a workgroup takes 4096 scalars × all windows, counts its digits per PARTITION
+//     (the top ≤8 bits of the bucket index; LDS atomics), reserves a run per partition with one global atomic,
+//     and writes (index | low bucket bits | sign) into that run — ≈16 consecutive entries (64 B) per partition.
+//  B  (msm_bucket_sort_kernel) one workgroup per partition (≈8 K entries, 32 KB, L2-resident) places the entries
+//     at offsets[bucket] + rank with LDS cursors for the ≤128 buckets of the partition.
+constexpr int PA_THREADS = 256, PA_PER_THREAD = 16, PA_SCALARS = PA_THREADS * PA_PER_THREAD;
+
+__global__ __launch_bounds__(256) void msm_part_init_kernel(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, MsmGeom g, int low_bits, uint32_t NP,
+                                                            uint32_t nparts, uint32_t nb, uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ total)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < nparts) part_cursor[p] = offsets[(p / NP) * g.NB + ((p % NP) << low_bits)];
+  if (p == 0) *total = offsets[nb - 1] + counts[nb - 1];
+}
+
+__global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_bits, uint32_t NP, uint32_t nparts,
+                                                                    uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ tmp)
+{
+  extern __shared__ uint32_t sh[];
+  uint32_t* hist = sh;
+  uint32_t* cur = sh + nparts;
+  for (uint32_t p = threadIdx.x; p < nparts; p += PA_THREADS) hist[p] = 0;
+  __syncthreads();
+  const uint32_t first = blockIdx.x * PA_SCALARS;
+  for (int u = 0; u < PA_PER_THREAD; u++) {
+    const uint32_t i = first + u * PA_THREADS + threadIdx.x;
+    if (i < L) {
+      uint32_t t[9], neg;
+      recode(scalars, i, g, mont, t, neg);
+      for (int w = 0; w < g.W; w++) {
+        const uint32_t d = digit(t, w, g);
+        if (d) atomicAdd(&hist[(uint32_t)w * NP + (((d & 0x7fffffffu) - 1) >> low_bits)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < nparts; p += PA_THREADS) {
+    const uint32_t h = hist[p];
+    cur[p] = h ? atomicAdd(&part_cursor[p], h) : 0;
+  }
+  __syncthreads();
+  const uint32_t low_mask = (1u << low_bits) - 1;
+  for (int u = 0; u < PA_PER_THREAD; u++) {
+    const uint32_t i = first + u * PA_THREADS + threadIdx.x;
+    if (i < L) {
+      uint32_t t[9], neg;
+      recode(scalars, i, g, mont, t, neg);
+      for (int w = 0; w < g.W; w++) {
+        const uint32_t d = digit(t, w, g);
+        if (d) {
+          const uint32_t bk = (d & 0x7fffffffu) - 1;
+          const uint32_t pos = atomicAdd(&cur[(uint32_t)w * NP + (bk >> low_bits)], 1u);
+          tmp[pos] = i | ((bk & low_mask) << 24) | (((d >> 31) ^ neg) << 31);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void msm_bucket_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ offsets, MsmGeom g, int low_bits, uint32_t NP, uint32_t nb,
+                                                              const uint32_t* __restrict__ total, uint32_t* __restrict__ sorted)
+{
+  __shared__ uint32_t cur[128];
+  const uint32_t part = blockIdx.x;
+  const uint32_t b0 = (part / NP) * g.NB + ((part % NP) << low_bits);
+  const uint32_t nbk = 1u << low_bits;
+  if (threadIdx.x < nbk) cur[threadIdx.x] = offsets[b0 + threadIdx.x];
+  const uint32_t start = offsets[b0];
+  const uint32_t end = b0 + nbk < nb ? offsets[b0 + nbk] : *total;
+  __syncthreads();
+  for (uint32_t e = start + threadIdx.x; e < end; e += blockDim.x) {
+    const uint32_t v = tmp[e];
+    const uint32_t pos = atomicAdd(&cur[(v >> 24) & 0x7f], 1u);
+    sorted[pos] = v & 0x80ffffffu;
+  }
 }
 
 int ilog2_ceil(uint64_t x)
@@ -265,8 +355,14 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->large_thr = thr;
   const uint32_t nblocks = (nb + SCAN_B - 1) / SCAN_B;
   const uint64_t nentries = (uint64_t)L * g.W;
-  // layout: counts | offsets | cursor | large_list | order | n_large[4] | bsum[nblocks] | size_hist[ORDER_BINS]
-  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 5 + 4 + nblocks + ORDER_BINS) * 4, s), ICICLE_ALLOCATION_FAILED);
+  // bucket index = partition (top ≤ 8 bits) | low bits
+  const int low_bits = (g.c - 1) > 8 ? (g.c - 1) - 8 : 0;
+  const uint32_t NP = g.NB >> low_bits, nparts = NP * (uint32_t)g.W;
+  const bool two_level = L <= (1u << 24) && (size_t)nparts * 8 <= 64 * 1024;
+  const uint32_t oblk = (nb + ORDER_BINS - 1) / ORDER_BINS;           // workgroups of the size-order pass
+  const uint32_t om = oblk * ORDER_BINS, oscan = (om + SCAN_B - 1) / SCAN_B;
+  // layout: counts | offsets | cursor | large_list | order | n_large[4] | bsum[nblocks] | part_cursor[nparts] | blockhist[om] | obsum[oscan]
+  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 5 + 4 + nblocks + nparts + om + oscan) * 4, s), ICICLE_ALLOCATION_FAILED);
   pl->counts = pl->ws;
   pl->offsets = pl->counts + nb;
   uint32_t* cursor = pl->offsets + nb;
@@ -274,26 +370,36 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->order = pl->large_list + nb;
   pl->n_large = pl->order + nb;
   uint32_t* bsum = pl->n_large + 4;
-  uint32_t* size_hist = bsum + nblocks;
+  uint32_t* part_cursor = bsum + nblocks;
+  uint32_t* blockhist = part_cursor + nparts;
+  uint32_t* obsum = blockhist + om;
   HIP_TRY(ws_alloc((void**)&pl->sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
+  uint32_t* tmp = nullptr;
+  if (two_level) HIP_TRY(ws_alloc((void**)&tmp, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
 
   unsigned zb = (nb + 255) / 256;
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, nb);
   hipLaunchKernelGGL(msm_zero_kernel, dim3(1), dim3(64), 0, s, pl->n_large, 4u);
-  hipLaunchKernelGGL(msm_zero_kernel, dim3(ORDER_BINS / 256), dim3(256), 0, s, size_hist, (uint32_t)ORDER_BINS);
   const unsigned lgrid = (L + 255) / 256;
   if (L) hipLaunchKernelGGL(msm_hist_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, pl->counts);
   hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum);
   hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
   hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list);
-  if (L) hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
+  if (L && two_level) {
+    hipLaunchKernelGGL(msm_part_init_kernel, dim3((nparts + 255) / 256), dim3(256), 0, s, pl->offsets, pl->counts, g, low_bits, NP, nparts, nb, part_cursor, pl->n_large + 1);
+    hipLaunchKernelGGL(msm_partition_kernel, dim3((L + PA_SCALARS - 1) / PA_SCALARS), dim3(PA_THREADS), (size_t)nparts * 8, s, d_scalars, L, g, mont_sc, low_bits, NP, nparts, part_cursor, tmp);
+    hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nparts), dim3(256), 0, s, tmp, pl->offsets, g, low_bits, NP, nb, pl->n_large + 1, pl->sorted);
+  } else if (L) {
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
+  }
   // bucket ids by decreasing size
-  unsigned hb = (nb + 255) / 256;
-  if (hb > 512) hb = 512;
-  hipLaunchKernelGGL(msm_size_hist_kernel, dim3(hb), dim3(256), 0, s, pl->counts, nb, size_hist);
-  hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(SCAN_T), 0, s, size_hist);
-  hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, pl->counts, nb, size_hist, pl->order);
+  hipLaunchKernelGGL(msm_order_hist_kernel, dim3(oblk), dim3(ORDER_BINS), 0, s, pl->counts, nb, oblk, blockhist);
+  hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(oscan), dim3(SCAN_T), 0, s, blockhist, om, obsum);
+  hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, obsum, oscan);
+  hipLaunchKernelGGL(msm_scan_apply_kernel, dim3(oscan), dim3(SCAN_T), 0, s, blockhist, om, obsum, blockhist);
+  hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(oblk), dim3(ORDER_BINS), 0, s, pl->counts, nb, oblk, blockhist, pl->order);
+  if (tmp) HIP_TRY(ws_free(tmp, s), ICICLE_DEALLOCATION_FAILED);
   return check_launch("msm_sort");
 }
 

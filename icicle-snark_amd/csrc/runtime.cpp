@@ -361,6 +361,16 @@ ISNARK_API eIcicleError icicle_device_synchronize(void)
   return ICICLE_SUCCESS;
 }
 
+ISNARK_API eIcicleError icicle_get_device_properties(IcicleDeviceProperties* p)
+{
+  if (!p) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  p->using_host_memory = false;
+  p->num_memory_regions = 0;
+  p->supports_pinned_memory = true;
+  return ICICLE_SUCCESS;
+}
+
 // ---- config extension: string-keyed int/bool bag (icicle/include/icicle/config_extension.h) ----
 struct ConfigExtension {
   std::map<std::string, int> ints;

@@ -148,6 +148,13 @@ eIcicleError icicle_create_stream(icicleStreamHandle* stream);                  
 eIcicleError icicle_destroy_stream(icicleStreamHandle stream);                  /* runtime.cpp:274 */
 eIcicleError icicle_stream_synchronize(icicleStreamHandle stream);              /* runtime.cpp:244 */
 eIcicleError icicle_device_synchronize(void);                                   /* runtime.cpp:249 */
+/* icicle/include/icicle/device.h:53-58 == wrappers/rust/icicle-runtime/src/device.rs:14-20 */
+typedef struct {
+  bool using_host_memory;
+  int num_memory_regions;
+  bool supports_pinned_memory;
+} IcicleDeviceProperties;
+eIcicleError icicle_get_device_properties(IcicleDeviceProperties* properties);  /* runtime.cpp:254 */
 
 /* ---- config extension: icicle/src/config_extension.cpp:7-37 ---- */
 ConfigExtension* create_config_extension(void);
