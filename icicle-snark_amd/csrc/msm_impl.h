@@ -108,23 +108,43 @@ __device__ __forceinline__ typename C::X block_reduce(typename C::X v, typename 
   return v;
 }
 
+// large buckets, step 1: one workgroup per (bucket, chunk) work item sums ≤ MSM_LARGE_CHUNK entries
 template <class C>
 __global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                                    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint32_t* __restrict__ large_list,
-                                                                    uint32_t skip_below, int pts_mont, typename C::X* __restrict__ buckets)
+                                                                    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint2* __restrict__ items, uint32_t item_cap,
+                                                                    uint32_t skip_below, int pts_mont, typename C::X* __restrict__ item_partials)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
-  const uint32_t nl = *n_large;
-  for (uint32_t li = blockIdx.x; li < nl; li += gridDim.x) {
-    const uint32_t b = large_list[li];
-    const uint32_t cnt = counts[b], off = offsets[b];
+  const uint32_t ni = min(n_large[2], item_cap);
+  for (uint32_t it = blockIdx.x; it < ni; it += gridDim.x) {
+    const uint2 w = items[it];
+    const uint32_t b = w.x;
+    const uint32_t lo = offsets[b] + w.y * MSM_LARGE_CHUNK, hi = min(offsets[b] + counts[b], lo + MSM_LARGE_CHUNK);
     typename C::X acc = C::x_zero();
-    for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
       bool z;
-      typename C::A p = load_base<C>(bases, sorted[off + k], skip_below, pts_mont, z);
+      typename C::A p = load_base<C>(bases, sorted[k], skip_below, pts_mont, z);
       if (!z) C::x_madd(acc, p);
     }
+    acc = block_reduce<C>(acc, sh, blockDim.x);
+    if (threadIdx.x == 0) item_partials[it] = acc;
+    __syncthreads();
+  }
+}
+// large buckets, step 2: one workgroup per large bucket sums its chunk partials into the bucket
+template <class C>
+__global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint32_t* __restrict__ large_list,
+                                                                 const uint32_t* __restrict__ large_first, const typename C::X* __restrict__ item_partials, typename C::X* __restrict__ buckets)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
+  const uint32_t nl = n_large[0];
+  for (uint32_t li = blockIdx.x; li < nl; li += gridDim.x) {
+    const uint32_t b = large_list[li];
+    const uint32_t nch = (counts[b] + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK, first = large_first[li];
+    typename C::X acc = C::x_zero();
+    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) acc = C::x_add(acc, item_partials[first + k]);
     acc = block_reduce<C>(acc, sh, blockDim.x);
     if (threadIdx.x == 0) buckets[b] = acc;
     __syncthreads();
@@ -306,8 +326,12 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(512), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_list, skip_below, mont_pt, buckets);
+  X* item_partials = nullptr;
+  HIP_TRY(ws_alloc((void**)&item_partials, (size_t)pl->item_cap * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, mont_pt, item_partials);
+  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials, buckets);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
+  HIP_TRY(ws_free(item_partials, s), ICICLE_DEALLOCATION_FAILED);
   hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.W), dim3(rs.rblock), rs.rblock * sizeof(X), s, buckets, g.NB, rs.k_log, d_partials);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   HIP_TRY(ws_free(buckets, s), ICICLE_DEALLOCATION_FAILED);

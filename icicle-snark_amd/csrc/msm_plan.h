@@ -9,6 +9,8 @@
 
 namespace isnark {
 
+constexpr uint32_t MSM_LARGE_CHUNK = 4096; // entries per work item of a large bucket (256 threads × 16 additions)
+
 struct MsmGeom {
   int c, W;
   uint32_t NB;   // buckets per window = 2^(c-1)
@@ -22,8 +24,11 @@ struct SortPlan {
   uint32_t* ws = nullptr;      // base of the u32 workspace below
   uint32_t* counts = nullptr;  // [nbuckets] entries per bucket (bucket = w·NB + |digit| − 1)
   uint32_t* offsets = nullptr; // [nbuckets] exclusive prefix sum
-  uint32_t* n_large = nullptr; // [1]  number of buckets with more than large_thr entries
-  uint32_t* large_list = nullptr; // [nbuckets]
+  uint32_t* n_large = nullptr; // [0] number of large buckets, [1] total entries, [2] number of large work items
+  uint32_t* large_list = nullptr; // [nbuckets] ids of buckets with more than large_thr entries
+  uint32_t* large_first = nullptr; // [nbuckets] first work item of each large bucket
+  uint2* large_items = nullptr;   // [item_cap] (bucket, chunk) work items: a large bucket is cut into MSM_LARGE_CHUNK-entry chunks
+  uint32_t item_cap = 0;
   uint32_t* order = nullptr;   // [nbuckets] bucket ids by decreasing entry count (wave-uniform trip counts)
   uint32_t* sorted = nullptr;  // [L·W] (index within the scalar vector) | sign << 31, grouped by bucket
   hipStream_t stream = nullptr;

@@ -84,15 +84,32 @@ __global__ __launch_bounds__(256) void msm_zero_kernel(uint32_t* __restrict__ p,
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
 }
 
+// Small digits of the two lowest windows are first counted in LDS: real witnesses are dominated by 0/1 and other
+// small values, i.e. by a handful of buckets of windows 0/1; without this, a third of all global atomics of a
+// witness-like scalar set hit ONE counter (measured 4.6 ms instead of 1 ms at L = 2^20).
+constexpr uint32_t HIST_HOT = 512; // cached magnitudes per window, windows 0 and 1
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, uint32_t* __restrict__ counts)
 {
+  __shared__ uint32_t hot[2 * HIST_HOT];
+  for (uint32_t k = threadIdx.x; k < 2 * HIST_HOT; k += blockDim.x) hot[k] = 0;
+  __syncthreads();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L) return;
-  uint32_t t[9], neg;
-  recode(scalars, i, g, mont, t, neg);
-  for (int w = 0; w < g.W; w++) {
-    const uint32_t d = digit(t, w, g);
-    if (d) atomicAdd(&counts[(uint32_t)w * g.NB + ((d & 0x7fffffffu) - 1)], 1u);
+  if (i < L) {
+    uint32_t t[9], neg;
+    recode(scalars, i, g, mont, t, neg);
+    for (int w = 0; w < g.W; w++) {
+      const uint32_t d = digit(t, w, g);
+      if (d) {
+        const uint32_t bk = (d & 0x7fffffffu) - 1;
+        if (w < 2 && bk < HIST_HOT && bk < g.NB) atomicAdd(&hot[w * HIST_HOT + bk], 1u);
+        else atomicAdd(&counts[(uint32_t)w * g.NB + bk], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < 2 * HIST_HOT; k += blockDim.x) {
+    const uint32_t v = hot[k];
+    if (v) atomicAdd(&counts[(k / HIST_HOT) * g.NB + (k % HIST_HOT)], v);
   }
 }
 
@@ -157,7 +174,8 @@ __global__ __launch_bounds__(SCAN_T) void msm_scan_top_kernel(uint32_t* bsum, ui
   }
 }
 __global__ __launch_bounds__(SCAN_T) void msm_scan_finish_kernel(const uint32_t* __restrict__ counts, uint32_t m, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ offsets,
-                                                                  uint32_t* __restrict__ cursor, uint32_t thr, uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list)
+                                                                  uint32_t* __restrict__ cursor, uint32_t thr, uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list,
+                                                                  uint32_t* __restrict__ large_first, uint2* __restrict__ large_items, uint32_t item_cap)
 {
   __shared__ uint32_t sh[SCAN_T];
   const uint32_t base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_E;
@@ -173,7 +191,15 @@ __global__ __launch_bounds__(SCAN_T) void msm_scan_finish_kernel(const uint32_t*
     if (base + k < m) {
       offsets[base + k] = run;
       cursor[base + k] = run;
-      if (v[k] > thr) large_list[atomicAdd(n_large, 1u)] = base + k;
+      if (v[k] > thr) {
+        // a large bucket becomes ⌈count / MSM_LARGE_CHUNK⌉ work items, each summed by one workgroup
+        const uint32_t li = atomicAdd(n_large, 1u);
+        const uint32_t nch = (v[k] + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK;
+        const uint32_t first = atomicAdd(n_large + 2, nch);
+        large_list[li] = base + k;
+        large_first[li] = first;
+        for (uint32_t q = 0; q < nch && first + q < item_cap; q++) large_items[first + q] = make_uint2(base + k, q);
+      }
       run += v[k];
     }
   }
@@ -293,18 +319,29 @@ __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __r
   }
 }
 
-__global__ __launch_bounds__(256) void msm_bucket_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ offsets, MsmGeom g, int low_bits, uint32_t NP, uint32_t nb,
-                                                              const uint32_t* __restrict__ total, uint32_t* __restrict__ sorted)
+constexpr int PB_SPLIT = 8; // workgroups per partition (a witness-like scalar set puts a third of all entries into ONE partition)
+__global__ __launch_bounds__(256) void msm_bucket_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, MsmGeom g, int low_bits,
+                                                              uint32_t NP, uint32_t nb, const uint32_t* __restrict__ total, uint32_t* __restrict__ sorted)
 {
-  __shared__ uint32_t cur[128];
+  __shared__ uint32_t hist[128], cur[128];
   const uint32_t part = blockIdx.x;
   const uint32_t b0 = (part / NP) * g.NB + ((part % NP) << low_bits);
   const uint32_t nbk = 1u << low_bits;
-  if (threadIdx.x < nbk) cur[threadIdx.x] = offsets[b0 + threadIdx.x];
   const uint32_t start = offsets[b0];
   const uint32_t end = b0 + nbk < nb ? offsets[b0 + nbk] : *total;
+  // this workgroup's share: every PB_SPLIT-th 256-entry stripe of the partition
+  const uint32_t stride = blockDim.x * gridDim.y, first = start + blockIdx.y * blockDim.x + threadIdx.x;
+  if (first - threadIdx.x >= end) return; // nothing for this workgroup (uniform across the workgroup)
+  if (threadIdx.x < 128) hist[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t e = start + threadIdx.x; e < end; e += blockDim.x) {
+  for (uint32_t e = first; e < end; e += stride) atomicAdd(&hist[(tmp[e] >> 24) & 0x7f], 1u);
+  __syncthreads();
+  if (threadIdx.x < nbk) {
+    const uint32_t h = hist[threadIdx.x];
+    cur[threadIdx.x] = h ? atomicAdd(&cursor[b0 + threadIdx.x], h) : 0; // cursor[] starts at offsets[] (scan_finish)
+  }
+  __syncthreads();
+  for (uint32_t e = first; e < end; e += stride) {
     const uint32_t v = tmp[e];
     const uint32_t pos = atomicAdd(&cur[(v >> 24) & 0x7f], 1u);
     sorted[pos] = v & 0x80ffffffu;
@@ -361,18 +398,22 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   const bool two_level = L <= (1u << 24) && (size_t)nparts * 8 <= 64 * 1024;
   const uint32_t oblk = (nb + ORDER_BINS - 1) / ORDER_BINS;           // workgroups of the size-order pass
   const uint32_t om = oblk * ORDER_BINS, oscan = (om + SCAN_B - 1) / SCAN_B;
-  // layout: counts | offsets | cursor | large_list | order | n_large[4] | bsum[nblocks] | part_cursor[nparts] | blockhist[om] | obsum[oscan]
-  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 5 + 4 + nblocks + nparts + om + oscan) * 4, s), ICICLE_ALLOCATION_FAILED);
+  // work items of large buckets: ≤ entries/CHUNK full chunks + one partial chunk per large bucket (≤ entries/thr of those)
+  pl->item_cap = (uint32_t)(nentries / MSM_LARGE_CHUNK + nentries / thr + 2);
+  // layout: counts | offsets | cursor | large_list | order | large_first | n_large[4] | bsum[nblocks] | part_cursor[nparts] | blockhist[om] | obsum[oscan] | large_items[2·item_cap]
+  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 6 + 4 + nblocks + nparts + om + oscan + 2 * (size_t)pl->item_cap + 2) * 4, s), ICICLE_ALLOCATION_FAILED);
   pl->counts = pl->ws;
   pl->offsets = pl->counts + nb;
   uint32_t* cursor = pl->offsets + nb;
   pl->large_list = cursor + nb;
   pl->order = pl->large_list + nb;
-  pl->n_large = pl->order + nb;
+  pl->large_first = pl->order + nb;
+  pl->n_large = pl->large_first + nb;
   uint32_t* bsum = pl->n_large + 4;
   uint32_t* part_cursor = bsum + nblocks;
   uint32_t* blockhist = part_cursor + nparts;
   uint32_t* obsum = blockhist + om;
+  pl->large_items = reinterpret_cast<uint2*>(obsum + oscan + ((nb * 6 + 4 + nblocks + nparts + om + oscan) & 1)); // 8-byte aligned
   HIP_TRY(ws_alloc((void**)&pl->sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
   uint32_t* tmp = nullptr;
   if (two_level) HIP_TRY(ws_alloc((void**)&tmp, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
@@ -385,11 +426,11 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   if (L) hipLaunchKernelGGL(msm_hist_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, pl->counts);
   hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum);
   hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
-  hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list);
+  hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list, pl->large_first, pl->large_items, pl->item_cap);
   if (L && two_level) {
     hipLaunchKernelGGL(msm_part_init_kernel, dim3((nparts + 255) / 256), dim3(256), 0, s, pl->offsets, pl->counts, g, low_bits, NP, nparts, nb, part_cursor, pl->n_large + 1);
     hipLaunchKernelGGL(msm_partition_kernel, dim3((L + PA_SCALARS - 1) / PA_SCALARS), dim3(PA_THREADS), (size_t)nparts * 8, s, d_scalars, L, g, mont_sc, low_bits, NP, nparts, part_cursor, tmp);
-    hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nparts), dim3(256), 0, s, tmp, pl->offsets, g, low_bits, NP, nb, pl->n_large + 1, pl->sorted);
+    hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nparts, PB_SPLIT), dim3(256), 0, s, tmp, pl->offsets, cursor, g, low_bits, NP, nb, pl->n_large + 1, pl->sorted);
   } else if (L) {
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
   }
