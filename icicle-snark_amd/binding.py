@@ -487,13 +487,17 @@ class CacheManager:
                                              pj, C.c_size_t(len(pj)), qj, C.c_size_t(len(qj))), "assemble_proof")
         return pj.value.decode(), qj.value.decode()
 
-    def prove_mem(self, key: str, wtns: bytes, r: int | None = None, s: int | None = None):
-        pj, qj = C.create_string_buffer(1 << 14), C.create_string_buffer(1 << 20)
+    def prove_mem(self, key: str, wtns: bytes, r: int | None = None, s: int | None = None, resident: bool = False):
+        """commitments + blinding + JSON in one call (the blinding terms are computed on a host thread while the GPU
+        works).  resident=True re-uses the witness already uploaded by an earlier call."""
+        if not hasattr(self, "_bufs"):
+            self._bufs = (C.create_string_buffer(1 << 14), C.create_string_buffer(1 << 20))
+        pj, qj = self._bufs
         rb = int(r).to_bytes(32, "little") if r is not None else None
         sb = int(s).to_bytes(32, "little") if s is not None else None
         tm = Timings()
-        _pcheck(lib().groth16_prove_mem(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), rb, sb, pj, C.c_size_t(len(pj)),
-                                        qj, C.c_size_t(len(qj)), C.byref(tm)), "prove_mem")
+        _pcheck(lib().groth16_prove_resident(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), int(resident), rb, sb, pj,
+                                             C.c_size_t(len(pj)), qj, C.c_size_t(len(qj)), C.byref(tm)), "prove_resident")
         return pj.value.decode(), qj.value.decode(), tm
 
     def prove(self, witness: str, zkey: str, proof: str, public: str, device: str = "HIP"):

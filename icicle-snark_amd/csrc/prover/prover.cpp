@@ -181,8 +181,9 @@ struct ZKeyCache {
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   fe* h_witness = nullptr;      // pinned staging, n_vars
-  hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr;
-  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr;
+  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
+             ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
 
@@ -192,6 +193,8 @@ struct ZKeyCache {
     if (s_g1) (void)hipStreamSynchronize(s_g1);
     if (s_g2) (void)hipStreamSynchronize(s_g2);
     if (s_g3) (void)hipStreamSynchronize(s_g3);
+    if (s_g4) (void)hipStreamSynchronize(s_g4);
+    if (s_g5) (void)hipStreamSynchronize(s_g5);
     for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_partials})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
@@ -199,11 +202,17 @@ struct ZKeyCache {
     if (s_g1) (void)icicle_destroy_stream(s_g1);
     if (s_g2) (void)icicle_destroy_stream(s_g2);
     if (s_g3) (void)icicle_destroy_stream(s_g3);
+    if (s_g4) (void)icicle_destroy_stream(s_g4);
+    if (s_g5) (void)icicle_destroy_stream(s_g5);
     if (ev_witness) (void)hipEventDestroy(ev_witness);
     if (ev_sort) (void)hipEventDestroy(ev_sort);
     if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
     if (ev_g2done) (void)hipEventDestroy(ev_g2done);
+    if (ev_g4done) (void)hipEventDestroy(ev_g4done);
+    if (ev_g5done) (void)hipEventDestroy(ev_g5done);
     for (auto e : ev)
+      if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_done)
       if (e) (void)hipEventDestroy(e);
   }
 };
@@ -355,11 +364,16 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g4));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g5));
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_g2done, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_g4done, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_g5done, hipEventDisableTiming));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
+  for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   out = std::move(z);
   return 0;
 }
@@ -559,47 +573,76 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_ICICLE(msm_sort_run(z->d_vec + n + z->H.lo, z->H.len(), 0, 10, 0, g3, &plan_h));
   P_HIP(hipEventRecord(z->ev_sort_h, g3));
 
-  // ---- stream g1: groth16_commitments — src/proof_helper.rs:198-205 : A, B1, C (shared sort), then H
-  P_HIP(hipStreamWaitEvent(g1, z->ev_sort, 0));
+  // ---- groth16_commitments — src/proof_helper.rs:198-205.  A, B1, C share the witness sort and run on three
+  // streams (g1, g4, g5) so that the latency-bound bucket reduction of one overlaps the accumulation of the
+  // others; H follows A on g1.
   const uint32_t skip_below = skip > wlo ? skip - wlo : 0; // C ignores witness[0..=n_public]
   const int order[3] = {0, 1, 3};
   const Shard* sh3[3] = {&z->A, &z->B1, &z->C};
+  hipStream_t st3[3] = {g1, z->s_g4, z->s_g5};
   for (int k = 0; k < 3; k++) {
     MsmProfile* p = prof[order[k]];
     fill(p, plan_w, 0);
-    (void)hipEventRecord(p->ev[0], g1);
-    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 1, k == 2 ? skip_below : 0, g1, DP + order[k] * PARTIALS_STRIDE, p));
-    (void)hipEventRecord(p->ev[3], g1);
+    P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
+    if (k) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
+    (void)hipEventRecord(p->ev[0], st3[k]);
+    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 1, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p));
+    (void)hipEventRecord(p->ev[3], st3[k]);
     p->valid = true;
   }
+  P_HIP(hipEventRecord(z->ev_g4done, z->s_g4));
+  P_HIP(hipEventRecord(z->ev_g5done, z->s_g5));
   P_HIP(hipStreamWaitEvent(g1, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 1, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4]));
   (void)hipEventRecord(prof[4]->ev[3], g1);
   prof[4]->valid = true;
-  // join g2 into g1, one D2H of all partial sums, host tails (window sums → Horner)
-  P_HIP(hipStreamWaitEvent(g1, z->ev_g2done, 0));
-  P_HIP(hipEventRecord(z->ev[3], g1));
+  // Each MSM's partial sums go to pinned memory on ITS OWN stream as soon as its reduction is done, and a host
+  // thread per MSM waits for that copy and runs the Horner tail — the tails of the early finishers (B2, A, B1, C)
+  // overlap the GPU work still in flight; only the last one (H) is exposed.
   uint32_t Ww = 0, bw1 = 0, bw2 = 0, Wh = 0, bh = 0;
   const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Ww, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
   const size_t sizes[5] = {by1, by1, by2, by1, byh};
-  for (int k = 0; k < 5; k++) P_HIP(hipMemcpyAsync(z->h_partials + k * PARTIALS_STRIDE, DP + k * PARTIALS_STRIDE, sizes[k], hipMemcpyDeviceToHost, g1));
+  hipStream_t st5[5] = {g1, z->s_g4, g2, z->s_g5, g1};
+  // the A copy must not wait for H (same stream): A's partials were complete at ev_a_done, copy them on g3 instead
+  P_HIP(hipStreamWaitEvent(g3, prof[0]->ev[3], 0));
+  st5[0] = g3;
+  P_HIP(hipStreamWaitEvent(g1, z->ev_g2done, 0));
+  P_HIP(hipStreamWaitEvent(g1, z->ev_g4done, 0));
+  P_HIP(hipStreamWaitEvent(g1, z->ev_g5done, 0));
+  for (int k = 0; k < 5; k++) {
+    P_HIP(hipMemcpyAsync(z->h_partials + k * PARTIALS_STRIDE, DP + k * PARTIALS_STRIDE, sizes[k], hipMemcpyDeviceToHost, st5[k]));
+    P_HIP(hipEventRecord(z->ev_done[k], st5[k]));
+  }
+  P_HIP(hipEventRecord(z->ev[3], g1)); // end of the MSM phase on the longest chain (timing only)
+  {
+    const uint8_t* HP = z->h_partials;
+    const int cw = plan_w.g.c, ch = plan_h.g.c;
+    hipEvent_t* evd = z->ev_done;
+    const int dev = z->device_id;
+    auto g1tail = [&](int k, uint32_t W, uint32_t bpw, int c, size_t off) {
+      (void)hipSetDevice(dev);
+      (void)hipEventSynchronize(evd[k]);
+      msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, bpw, c, (bn254_projective_t*)(out_points + off));
+    };
+    std::thread t0(g1tail, 0, Ww, bw1, cw, (size_t)0);
+    std::thread t1(g1tail, 1, Ww, bw1, cw, (size_t)96);
+    std::thread t3(g1tail, 3, Ww, bw1, cw, (size_t)384);
+    std::thread t2([&] {
+      (void)hipSetDevice(dev);
+      (void)hipEventSynchronize(evd[2]);
+      msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, bw2, cw, (bn254_g2_projective_t*)(out_points + 192));
+    });
+    g1tail(4, Wh, bh, ch, 480);
+    t0.join(); t1.join(); t2.join(); t3.join();
+  }
   P_HIP(hipStreamSynchronize(g1));
   P_HIP(hipStreamSynchronize(g2));
   P_HIP(hipStreamSynchronize(g3));
+  P_HIP(hipStreamSynchronize(z->s_g4));
+  P_HIP(hipStreamSynchronize(z->s_g5));
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
-  const uint8_t* HP = z->h_partials;
-  {
-    // five independent Horner tails (≈0.2 ms each, the G2 one ≈0.7 ms): one host thread each
-    const int cw = plan_w.g.c, ch = plan_h.g.c;
-    std::thread t0([&] { msm_g1_host_tail(HP + 0 * PARTIALS_STRIDE, Ww, bw1, cw, (bn254_projective_t*)(out_points + 0)); });
-    std::thread t1([&] { msm_g1_host_tail(HP + 1 * PARTIALS_STRIDE, Ww, bw1, cw, (bn254_projective_t*)(out_points + 96)); });
-    std::thread t3([&] { msm_g1_host_tail(HP + 3 * PARTIALS_STRIDE, Ww, bw1, cw, (bn254_projective_t*)(out_points + 384)); });
-    std::thread t4([&] { msm_g1_host_tail(HP + 4 * PARTIALS_STRIDE, Wh, bh, ch, (bn254_projective_t*)(out_points + 480)); });
-    msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, bw2, cw, (bn254_g2_projective_t*)(out_points + 192));
-    t0.join(); t1.join(); t3.join(); t4.join();
-  }
   if (tm) {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
@@ -630,53 +673,85 @@ __attribute__((visibility("default"))) int groth16_sum_commitments(const uint8_t
   return 0;
 }
 
+} // extern "C"
+
+namespace {
+// blinding terms that do not depend on the commitments: δ1·r, δ1·s, δ2·s, δ1·r·s (src/proof_helper.rs:280-283);
+// groth16_prove_mem computes them on a host thread while the GPU works
+struct Blinding {
+  bn254_scalar_t r, s;
+  bn254_projective_t d1r, d1s, d1rs;
+  bn254_g2_projective_t d2s;
+};
+void compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_in, Blinding* b)
+{
+  bn254_scalar_t rs[2];
+  if (!r_in || !s_in) bn254_generate_scalars(rs, 2); // ScalarCfg::generate_random(2) — src/proof_helper.rs:276
+  if (r_in) memcpy(&rs[0], r_in, 32);
+  if (s_in) memcpy(&rs[1], s_in, 32);
+  b->r = rs[0];
+  b->s = rs[1];
+  const bn254_projective_t* delta1 = (const bn254_projective_t*)&z->vk_delta_1;
+  const bn254_g2_projective_t* delta2 = (const bn254_g2_projective_t*)&z->vk_delta_2;
+  bn254_mul_scalar(delta1, &b->r, &b->d1r);
+  bn254_mul_scalar(delta1, &b->s, &b->d1s);
+  bn254_mul_scalar(&b->d1r, &b->s, &b->d1rs);
+  bn254_g2_mul_scalar(delta2, &b->s, &b->d2s);
+}
+int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap);
+} // namespace
+
+extern "C" {
+
 __attribute__((visibility("default"))) int groth16_assemble_proof(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, const uint8_t points[GROTH16_COMMITMENTS_BYTES],
                                                                   const uint8_t* r_in, const uint8_t* s_in, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap)
 {
   if (!cm || !wtns || !points) return fail(ERR_ARG, "null argument");
   ZKeyCache* z = find(cm, key);
   if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  Blinding bl;
+  compute_blinding(z, r_in, s_in, &bl);
+  return assemble_impl(z, wtns, wtns_len, points, bl, proof_json, proof_cap, public_json, public_cap);
+}
+
+} // extern "C"
+
+namespace {
+int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap)
+{
   Wtns w;
   if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
   if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length");
   typedef bn254_projective_t P1;
   typedef bn254_g2_projective_t P2;
-  P1 pi_a, pi_b1, pi_c, pi_h, t1, t2;
-  P2 pi_b, u1;
+  P1 pi_a, pi_b1, pi_c, pi_h, t2;
+  P2 pi_b;
   memcpy(&pi_a, points, 96);
   memcpy(&pi_b1, points + 96, 96);
   memcpy(&pi_b, points + 192, 192);
   memcpy(&pi_c, points + 384, 96);
   memcpy(&pi_h, points + 480, 96);
-  bn254_scalar_t rs[2], r, s, rsprod;
-  if (!r_in || !s_in) bn254_generate_scalars(rs, 2); // ScalarCfg::generate_random(2) — src/proof_helper.rs:276
-  if (r_in) memcpy(&rs[0], r_in, 32);
-  if (s_in) memcpy(&rs[1], s_in, 32);
-  r = rs[0];
-  s = rs[1];
   const P1* alpha1 = (const P1*)&z->vk_alpha_1;
   const P1* beta1 = (const P1*)&z->vk_beta_1;
-  const P1* delta1 = (const P1*)&z->vk_delta_1;
   const P2* beta2 = (const P2*)&z->vk_beta_2;
-  const P2* delta2 = (const P2*)&z->vk_delta_2;
   // src/proof_helper.rs:280-283
-  bn254_mul_scalar(delta1, &r, &t1);            // δ1·r
   bn254_ecadd(&pi_a, alpha1, &pi_a);
-  bn254_ecadd(&pi_a, &t1, &pi_a);               // pi_a = A + α1 + δ1·r
-  bn254_g2_mul_scalar(delta2, &s, &u1);
+  bn254_ecadd(&pi_a, &bl.d1r, &pi_a);           // pi_a = A + α1 + δ1·r
   bn254_g2_ecadd(&pi_b, beta2, &pi_b);
-  bn254_g2_ecadd(&pi_b, &u1, &pi_b);            // pi_b = B2 + β2 + δ2·s
-  bn254_mul_scalar(delta1, &s, &t2);
+  bn254_g2_ecadd(&pi_b, &bl.d2s, &pi_b);        // pi_b = B2 + β2 + δ2·s
   bn254_ecadd(&pi_b1, beta1, &pi_b1);
-  bn254_ecadd(&pi_b1, &t2, &pi_b1);             // pi_b1 = B1 + β1 + δ1·s
+  bn254_ecadd(&pi_b1, &bl.d1s, &pi_b1);         // pi_b1 = B1 + β1 + δ1·s
   bn254_ecadd(&pi_c, &pi_h, &pi_c);             // C + H
-  bn254_mul_scalar(&pi_a, &s, &t2);
-  bn254_ecadd(&pi_c, &t2, &pi_c);               // + pi_a·s
-  bn254_mul_scalar(&pi_b1, &r, &t2);
-  bn254_ecadd(&pi_c, &t2, &pi_c);               // + pi_b1·r
-  bn254_mul_scalar(&t1, &s, &t2);               // δ1·r·s
-  bn254_ecsub(&pi_c, &t2, &pi_c);
-  (void)rsprod;
+  {
+    P1 ta, tb;
+    std::thread th([&] { bn254_mul_scalar(&pi_a, &bl.s, &ta); }); // pi_a·s  ∥  pi_b1·r
+    bn254_mul_scalar(&pi_b1, &bl.r, &tb);
+    th.join();
+    bn254_ecadd(&pi_c, &ta, &pi_c);
+    bn254_ecadd(&pi_c, &tb, &pi_c);
+  }
+  bn254_ecsub(&pi_c, &bl.d1rs, &pi_c);          // − δ1·r·s
+  (void)t2;
   bn254_affine_t a_aff, c_aff;
   bn254_g2_affine_t b_aff;
   bn254_to_affine(&pi_a, &a_aff);
@@ -712,14 +787,35 @@ __attribute__((visibility("default"))) int groth16_assemble_proof(Groth16CacheMa
   if (need) return fail(need, "output buffer too small (need %d bytes)", need);
   return 0;
 }
+} // namespace
+
+extern "C" {
+
+// groth16_prove_mem with the option to re-use the witness already resident on the device (bench.py: inputs in HBM)
+__attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, int wtns_resident, const uint8_t* r, const uint8_t* s,
+                                                                   char* proof_json, size_t proof_cap, char* public_json, size_t public_cap, Groth16Timings* tm);
 
 __attribute__((visibility("default"))) int groth16_prove_mem(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, const uint8_t* r, const uint8_t* s, char* proof_json, size_t proof_cap,
                                                              char* public_json, size_t public_cap, Groth16Timings* tm)
 {
+  return groth16_prove_resident(cm, key, wtns, wtns_len, 0, r, s, proof_json, proof_cap, public_json, public_cap, tm);
+}
+
+__attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, int wtns_resident, const uint8_t* r, const uint8_t* s,
+                                                                   char* proof_json, size_t proof_cap, char* public_json, size_t public_cap, Groth16Timings* tm)
+{
   uint8_t pts[GROTH16_COMMITMENTS_BYTES];
   const auto t0 = std::chrono::steady_clock::now();
-  if (int rc = groth16_commitments(cm, key, wtns, wtns_len, pts, tm)) return rc;
-  int rc = groth16_assemble_proof(cm, key, wtns, wtns_len, pts, r, s, proof_json, proof_cap, public_json, public_cap);
+  if (!cm || !wtns) return fail(ERR_ARG, "null argument");
+  ZKeyCache* z = find(cm, key);
+  if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  // r, s and the commitment-independent blinding terms on a host thread while the GPU computes the commitments
+  Blinding bl;
+  std::thread th([&] { compute_blinding(z, r, s, &bl); });
+  int rc = groth16_commitments(cm, key, wtns_resident ? nullptr : wtns, wtns_len, pts, tm);
+  th.join();
+  if (rc) return rc;
+  rc = assemble_impl(z, wtns, wtns_len, pts, bl, proof_json, proof_cap, public_json, public_cap);
   if (tm) tm->total_ms = ms_since(t0);
   return rc;
 }

@@ -79,6 +79,12 @@ int groth16_prove_mem(Groth16CacheManager* cm, const char* key, const void* wtns
                       const uint8_t* s, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap,
                       Groth16Timings* timings);
 
+/* Same, but with wtns_resident != 0 the witness uploaded by an earlier call is re-used on the device (the bytes are
+ * still needed for the public signals): "inputs already resident in HBM", what bench.py times. */
+int groth16_prove_resident(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, int wtns_resident,
+                           const uint8_t* r, const uint8_t* s, char* proof_json, size_t proof_cap, char* public_json,
+                           size_t public_cap, Groth16Timings* timings);
+
 /* sizes of the cached circuit */
 typedef struct {
   uint32_t n_vars, n_public, domain_size, n_coef;
