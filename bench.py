@@ -92,8 +92,17 @@ def main():
     K = importlib.import_module("icicle-snark_amd")   # raises if the HIP library is missing: no fallback
     S = importlib.import_module("icicle-snark_amd.synth")
     P = importlib.import_module("icicle-snark_amd.parallel")
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): ICICLE_SNARK_BENCH_DEVICE pins every rank to one device,
+    # ICICLE_SNARK_BENCH_EXCHANGE=gloo swaps the RCCL all-gather for the gloo one (same Exchange interface)
+    if os.environ.get("ICICLE_SNARK_BENCH_DEVICE"):
+        local_rank = int(os.environ["ICICLE_SNARK_BENCH_DEVICE"])
+    use_gloo = os.environ.get("ICICLE_SNARK_BENCH_EXCHANGE") == "gloo"
     K.set_device("HIP", local_rank)
-    if world > 1:
+    if world > 1 and use_gloo:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        exch = P.GlooExchange()
+    elif world > 1:
         P.preload_rccl()   # our RCCL (on our HIP runtime) must be loaded before torch's bundled copy
         # control plane: torch.distributed (gloo) — rendezvous, barriers, broadcast of the ncclUniqueId.
         # data plane: RCCL all-gather over xGMI on this library's HIP runtime (csrc/comm/rccl_comm.cpp).
