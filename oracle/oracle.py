@@ -272,6 +272,35 @@ def num_threads() -> int:
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n: int):
+    lib().oracle_set_num_threads(C.c_int(int(n)))
+
+
+def calibrate_threads(candidates=(8, 16, 32, 64, 128, 256)) -> int:
+    """Pick the OpenMP thread count that runs a small G1 MSM fastest.  Containers often expose more logical CPUs than
+    their CPU quota allows to run (on the 256-thread GPU host 32 threads were 10x faster than 256)."""
+    import time
+    rng = np.random.default_rng(1)
+    n = 20000
+    sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    pts = fixed_base_mul("g1", ec_to_affine("g1", ec_generator("g1")), sc[::-1].copy())
+    best, best_t = None, None
+    ncpu = os.cpu_count() or 1
+    for t in candidates:
+        if t > ncpu:
+            break
+        set_num_threads(t)
+        msm("g1", sc, pts)
+        t0 = time.perf_counter()
+        msm("g1", sc, pts)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = t, dt
+    set_num_threads(best or 1)
+    return best or 1
+
+
 # --------------------------------------------------------------------------- snarkjs containers
 def read_sections(data: bytes, expected_type: bytes, max_version: int = 2):
     """FileWrapper::read_bin_file — src/file_wrapper.rs:45-103. Returns {id: (offset, size)}."""
