@@ -90,7 +90,7 @@ bn254_g2_from_affine bn254_g2_generator bn254_g2_is_on_curve bn254_g2_base_field
 bn254_vector_add bn254_vector_sub bn254_vector_mul bn254_scalar_convert_montgomery
 bn254_affine_convert_montgomery bn254_g2_affine_convert_montgomery
 bn254_ntt bn254_ntt_init_domain bn254_ntt_release_domain bn254_get_root_of_unity bn254_get_root_of_unity_from_domain
-bn254_msm bn254_g2_msm
+bn254_msm bn254_g2_msm bn254_pairing
 icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
 icicle_snark_msm_profile
 """.split()
@@ -503,6 +503,39 @@ class CacheManager:
     def prove(self, witness: str, zkey: str, proof: str, public: str, device: str = "HIP"):
         """groth16_prove — src/lib.rs:33-61"""
         _pcheck(lib().groth16_prove(witness.encode(), zkey.encode(), proof.encode(), public.encode(), device.encode(), self._h), "groth16_prove")
+
+
+PROVER_SYMBOLS = """
+groth16_cache_manager_new groth16_cache_manager_free groth16_prove groth16_cache_load groth16_cache_load_file
+groth16_cache_contains groth16_cache_evict groth16_commitments groth16_sum_commitments groth16_assemble_proof
+groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error
+groth16_verify groth16_verify_json groth16_verify_last_error
+""".split()
+
+
+def pairing(p_aff: np.ndarray, q_aff: np.ndarray) -> np.ndarray:
+    """pairing — wrappers/rust/icicle-core/src/pairing/mod.rs:14-22.  Affine standard-form points in, the 12 Fq
+    coefficients of e(P,Q) out (host computation, as in the reference)."""
+    out = np.zeros((12, 4), dtype=np.uint64)
+    check(lib().bn254_pairing(ptr_of(np.ascontiguousarray(p_aff)), ptr_of(np.ascontiguousarray(q_aff)), ptr_of(out)), "pairing")
+    return out
+
+
+def groth16_verify_json(proof_json: str, public_json: str, vk_json: str) -> bool:
+    """groth16_verify_helper — src/proof_helper.rs:319-372 on JSON texts."""
+    rc = lib().groth16_verify_json(proof_json.encode(), public_json.encode(), vk_json.encode())
+    if rc < 0:
+        lib().groth16_verify_last_error.restype = C.c_char_p
+        raise ProverError(f"groth16_verify: {lib().groth16_verify_last_error().decode()} (code {rc})")
+    return rc == 1
+
+
+def groth16_verify(proof: str, public: str, vk: str):
+    """groth16_verify — src/lib.rs:63-82 (paths in; raises on a rejected proof like the reference's assert)."""
+    rc = lib().groth16_verify(proof.encode(), public.encode(), vk.encode())
+    if rc != 0:
+        lib().groth16_verify_last_error.restype = C.c_char_p
+        raise ProverError(f"groth16_verify: {lib().groth16_verify_last_error().decode()} (code {rc})")
 
 
 def sum_commitments(blocks: bytes, count: int) -> bytes:

@@ -1,7 +1,7 @@
 // prove — stdin REPL worker with the protocol of the reference CLI (src/main.rs:121-186):
 //   > prove --witness W --zkey Z --proof P --public Q --device HIP
 // prints COMMAND_COMPLETED after every command, COMMAND_EMPTY for blank lines, COMMAND_EXIT on "exit".
-// `verify` is out of scope for this round (pairing) and reports so.
+//   > verify --proof P --public Q --vk verification_key.json
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -10,7 +10,7 @@
 
 static void print_help()
 {
-  std::cout << "Usage:\n  prove [--system groth16] --witness <file> --zkey <file> --proof <file> --public <file> --device <HIP>\n  exit\n";
+  std::cout << "Usage:\n  prove [--system groth16] --witness <file> --zkey <file> --proof <file> --public <file> --device <HIP>\n  verify [--system groth16] --proof <file> --public <file> --vk <file>\n  exit\n";
 }
 
 int main()
@@ -58,7 +58,31 @@ int main()
       }
       std::cout << "COMMAND_COMPLETED" << std::endl;
     } else if (cmd == "verify") {
-      std::cerr << "verify is not implemented in this build (pairing is outside the prove path)" << std::endl;
+      // defaults of src/main.rs:84-86
+      std::string proof = "proof.json", pub = "public.json", vk = "verification_key.json", a, v;
+      bool ok = true;
+      while (in >> a) {
+        if (a == "--system") {
+          if (in >> v && v != "groth16" && v != "Groth16" && v != "GROTH16") {
+            std::cerr << "Unknown proof system: " << v << std::endl;
+            ok = false;
+          }
+        } else if (a == "--proof") in >> proof;
+        else if (a == "--public") in >> pub;
+        else if (a == "--vk") in >> vk;
+        else print_help();
+      }
+      if (!ok) {
+        print_help();
+        continue;
+      }
+      int rc = groth16_verify(proof.c_str(), pub.c_str(), vk.c_str());
+      // the reference panics on a rejected proof (assert, src/lib.rs:79); report and keep the worker alive instead
+      if (rc == 0) std::cout << "VERIFY_OK" << std::endl;
+      else {
+        std::cerr << "verify failed (" << rc << "): " << groth16_verify_last_error() << std::endl;
+        std::cout << "VERIFY_FAILED" << std::endl;
+      }
       std::cout << "COMMAND_COMPLETED" << std::endl;
     } else {
       print_help();

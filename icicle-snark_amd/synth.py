@@ -264,6 +264,26 @@ def setup(r1cs: R1CS, fixed_base_mul, points_to_mont=None, seed: int = SEED):
     return _finish(m, npub, n, _e(a_tau), _e(b_tau), _e(c_s), _e(ic_s), _e(h_s), mcs, vals, toxic, fixed_base_mul, points_to_mont)
 
 
+def vk_to_json(vk: dict) -> str:
+    """snarkjs verification_key.json text for the `vk` dict `setup` returns (fields read by the reference:
+    src/cache.rs:84-106; projective third coordinates as snarkjs writes them)."""
+    import json
+
+    def g1(a):
+        x, y = arr_to_ints(a)
+        return [str(x), str(y), "1"]
+
+    def g2(a):
+        x0, x1, y0, y1 = arr_to_ints(a)
+        return [[str(x0), str(x1)], [str(y0), str(y1)], ["1", "0"]]
+
+    return json.dumps({
+        "protocol": "groth16", "curve": "bn128", "nPublic": int(vk["n_public"]),
+        "vk_alpha_1": g1(vk["vk_alpha_1"]), "vk_beta_2": g2(vk["vk_beta_2"]), "vk_gamma_2": g2(vk["vk_gamma_2"]),
+        "vk_delta_2": g2(vk["vk_delta_2"]), "IC": [g1(p) for p in vk["IC"]],
+    }, indent=1)
+
+
 def squaring_chain_witness(N: int, a: int = 3):
     w = [0] * (N + 2)
     w[0], w[2] = 1, a % R_MOD

@@ -94,6 +94,15 @@ int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16Ci
 
 const char* groth16_last_error(void);
 
+/* groth16_verify — src/lib.rs:63-82 with groth16_verify_helper (src/proof_helper.rs:319-372) and the snarkjs
+ * verification_key.json reader (src/cache.rs:74-108).  Checks e(−A,B)·e(IC₀+Σ pubᵢ·ICᵢ₊₁, γ₂)·e(C,δ₂)·e(α₁,β₂) = 1
+ * with four host pairings.  groth16_verify (paths): 0 = accepted, 1 = "Verification failed" (the reference
+ * asserts), negative = I/O or format error.  groth16_verify_json (texts): 1 = accepted, 0 = rejected, negative =
+ * format error.  No device is needed. */
+int groth16_verify(const char* proof_path, const char* public_path, const char* vk_path);
+int groth16_verify_json(const char* proof_json, const char* public_json, const char* vk_json);
+const char* groth16_verify_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

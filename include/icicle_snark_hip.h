@@ -66,6 +66,7 @@ typedef struct { bn254_fq_t x, y, z; } bn254_projective_t;
 typedef struct { bn254_fq_t c0, c1; } bn254_fq2_t;
 typedef struct { bn254_fq2_t x, y; } bn254_g2_affine_t;
 typedef struct { bn254_fq2_t x, y, z; } bn254_g2_projective_t;
+typedef struct { bn254_fq2_t c[2][3]; } bn254_fq12_t; /* PairingConfig::TargetField: c[i][j] = coefficient of v^j w^i */
 
 /* icicle/include/icicle/msm.h:21-53 == wrappers/rust/icicle-core/src/msm/mod.rs:13-49 */
 typedef struct {
@@ -193,6 +194,9 @@ void bn254_g2_from_affine(const bn254_g2_affine_t* p, bn254_g2_projective_t* out
 void bn254_g2_generator(bn254_g2_projective_t* out);
 bool bn254_g2_is_on_curve(const bn254_g2_projective_t* p);
 void bn254_g2_base_field_from_u32(uint32_t val, bn254_fq2_t* result);
+
+/* ---- pairing (host): icicle/src/pairing.cpp:11-26, models/bn.h; Rust: icicle-core/src/pairing/mod.rs:38-43 ---- */
+eIcicleError bn254_pairing(const bn254_affine_t* p, const bn254_g2_affine_t* q, bn254_fq12_t* out);
 
 /* ---- device vector ops: icicle/src/vec_ops.cpp:52-97,165-171 (CUDA: cuda_vec_ops.cu, cuda_mont.cuh) ---- */
 eIcicleError bn254_vector_add(const bn254_scalar_t* a, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);

@@ -18,6 +18,8 @@ fixtures are outputs of the reference itself:
                  the oracle pipeline — accepted by the reference pairing check
                  (groth16_verify_helper, src/proof_helper.rs:319-372 on bn254_pairing)
 
+  pairing.json   bn254_pairing (icicle/src/pairing.cpp:22-26) on multiples of the generators
+
 Data only: inputs and expected outputs as hex strings; no reference source text.
 """
 import base64
@@ -139,6 +141,17 @@ def main():
                vk_delta_2=hx(vk["vk_delta_2"]), IC=[hx(p) for p in vk["IC"]])
     json.dump(dict(circuit="squaring_chain(6), a=3", zkey=base64.b64encode(zkey).decode(), wtns=base64.b64encode(wtns).decode(),
                    vk=vkj, cases=out), open(os.path.join(HERE, "groth16.json"), "w"), indent=0)
+
+    # ------------------------------------------------------------------ pairing (the reference's bn254_pairing)
+    prnd = random.Random(0x9A1812)
+    cases = []
+    gen1, gen2 = R.ec("g1", "generator"), R.ec("g2", "generator")
+    for a, b in [(1, 1), (2, 1), (1, 2), (prnd.randrange(O.R_MOD), prnd.randrange(O.R_MOD)),
+                 (O.R_MOD - 1, prnd.randrange(O.R_MOD)), (prnd.randrange(1 << 64), prnd.randrange(1 << 64))]:
+        P = R.ec("g1", "to_affine", R.ec("g1", "mul_scalar", gen1, a))
+        Q = R.ec("g2", "to_affine", R.ec("g2", "mul_scalar", gen2, b))
+        cases.append(dict(a=hi(a), b=hi(b), p=hx(P), q=hx(Q), e=hx(R.pairing(P, Q))))
+    json.dump(dict(cases=cases), open(os.path.join(HERE, "pairing.json"), "w"), indent=0)
     print("golden fixtures written to", HERE)
 
 

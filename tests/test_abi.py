@@ -25,6 +25,15 @@ def test_library_exports_every_declared_symbol(K):
         assert hasattr(lib, name), f"missing export {name}"
 
 
+def test_library_exports_every_prover_symbol(K):
+    lib = K.lib()
+    hdr = open(os.path.join(ROOT, "include", "groth16_prover.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*|Groth16CacheManager\*)\s+(groth16_\w+)\s*\(", hdr, re.M))
+    assert declared == set(K.PROVER_SYMBOLS), declared ^ set(K.PROVER_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"missing export {name}"
+
+
 def test_struct_layouts_match_reference(K):
     # sizes/offsets of the reference's structs on x86-64 (icicle/include/icicle/{msm,ntt,vec_ops,device}.h)
     assert C.sizeof(K.Device) == 68

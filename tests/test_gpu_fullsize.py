@@ -20,6 +20,17 @@ def rand_fr(rng, n):
     return a
 
 
+
+def _vk_of(O, zkey):
+    """verification key (standard-form affine numpy points) read back from the zkey header and section 3"""
+    z = O.parse_zkey(zkey)
+    conv = lambda a: O.fq_convert_montgomery(a, False)
+    sec = O.read_sections(zkey, b"zkey")
+    ic = np.frombuffer(O._section(zkey, sec, 3), dtype=np.uint64).reshape(-1, 2, 4)
+    return dict(vk_alpha_1=conv(z["vk_alpha_1"]), vk_beta_2=conv(z["vk_beta_2"]), vk_gamma_2=conv(z["vk_gamma_2"]),
+                vk_delta_2=conv(z["vk_delta_2"]), IC=[conv(p) for p in ic], n_public=len(ic) - 1)
+
+
 @pytest.mark.parametrize("grp", ["g1", "g2"])
 def test_msm_linearity_and_additivity_full_size(gpu, O, grp):
     K = gpu
@@ -81,17 +92,15 @@ def test_benchmark_1600k_prove(gpu, O):
     p2, q2, _ = cm.prove_mem("full", wtns, 1, 1)
     assert p1 == p2 and q1 == q2                                # deterministic (bucket order inside atomics is not)
     assert json.loads(q1) == [str(pow(3, 1 << N, S.R_MOD))]
+    vk = _vk_of(O, zkey)                                         # vk from the synthesised key itself
+    vkj = S.vk_to_json(vk)
+    p3, q3, _ = cm.prove_mem("full", wtns)                      # random blinding
+    assert p3 != p1
+    assert K.groth16_verify_json(p1, q1, vkj) and K.groth16_verify_json(p3, q3, vkj)   # the library's own pairing check
     import ref as R
-    if R.available():
-        z = O.parse_zkey(zkey)                                   # vk from the synthesised key itself
-        conv = lambda a: O.fq_convert_montgomery(a, False)
-        sec = O.read_sections(zkey, b"zkey")
-        ic = np.frombuffer(O._section(zkey, sec, 3), dtype=np.uint64).reshape(-1, 2, 4)
-        vk = dict(vk_alpha_1=conv(z["vk_alpha_1"]), vk_beta_2=conv(z["vk_beta_2"]), vk_gamma_2=conv(z["vk_gamma_2"]),
-                  vk_delta_2=conv(z["vk_delta_2"]), IC=[conv(p) for p in ic])
+    if R.available():                                            # … and the reference's
         assert R.groth16_verify(json.loads(p1), json.loads(q1), vk)
-        p3, q3, _ = cm.prove_mem("full", wtns)                  # random blinding
-        assert p3 != p1 and R.groth16_verify(json.loads(p3), json.loads(q3), vk)
+        assert R.groth16_verify(json.loads(p3), json.loads(q3), vk)
     cm.close()
     K.release_domain()
 
@@ -187,14 +196,10 @@ def test_benchmark_3200k_sharded_commitments(gpu, O):
     got, _ = cm.assemble("full", wtns, K.sum_commitments(blocks, 4), 5, 9)
     assert got == want
     assert json.loads(public) == [str(pow(3, 1 << N, S.R_MOD))]
+    vk = _vk_of(O, zkey)
+    assert K.groth16_verify_json(want, public, S.vk_to_json(vk))
     import ref as R
     if R.available():
-        z = O.parse_zkey(zkey)
-        conv = lambda a: O.fq_convert_montgomery(a, False)
-        sec = O.read_sections(zkey, b"zkey")
-        ic = np.frombuffer(O._section(zkey, sec, 3), dtype=np.uint64).reshape(-1, 2, 4)
-        vk = dict(vk_alpha_1=conv(z["vk_alpha_1"]), vk_beta_2=conv(z["vk_beta_2"]), vk_gamma_2=conv(z["vk_gamma_2"]),
-                  vk_delta_2=conv(z["vk_delta_2"]), IC=[conv(p) for p in ic])
         assert R.groth16_verify(json.loads(want), json.loads(public), vk)
     cm.close()
     K.release_domain()

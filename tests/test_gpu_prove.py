@@ -59,6 +59,8 @@ def test_squaring_chain_vs_oracle(gpu, cm, O, S, N):
     p1, _, _ = cm.prove_mem(key, wtns)
     p2, _, _ = cm.prove_mem(key, wtns)
     assert p1 != p2
+    vkj = S.vk_to_json(dict(vk, n_public=len(vk["IC"]) - 1))
+    assert K.groth16_verify_json(pj, qj, vkj) and K.groth16_verify_json(p1, qj, vkj)
     import ref as R
     if R.available():
         assert R.groth16_verify(json.loads(pj), json.loads(qj), vk)
@@ -76,6 +78,7 @@ def test_bit_heavy_random_circuit_vs_oracle(gpu, cm, O, S):
     pj, qj, _ = cm.prove_mem("rand", wtns, 5, 7)
     proof, public = O.groth16_prove(zkey, wtns, 5, 7)
     assert json.loads(pj) == proof and json.loads(qj) == public
+    assert K.groth16_verify_json(pj, qj, S.vk_to_json(dict(vk, n_public=len(vk["IC"]) - 1)))
     import ref as R
     if R.available():
         assert R.groth16_verify(proof, public, vk)
