@@ -91,6 +91,8 @@ bn254_vector_add bn254_vector_sub bn254_vector_mul bn254_scalar_convert_montgome
 bn254_affine_convert_montgomery bn254_g2_affine_convert_montgomery
 bn254_ntt bn254_ntt_init_domain bn254_ntt_release_domain bn254_get_root_of_unity bn254_get_root_of_unity_from_domain
 bn254_msm bn254_g2_msm bn254_pairing
+bn254_pairing_target_field_add bn254_pairing_target_field_sub bn254_pairing_target_field_mul bn254_pairing_target_field_inv
+bn254_pairing_target_field_pow bn254_pairing_target_field_from_u32 bn254_pairing_target_field_generate_scalars
 icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
 icicle_snark_msm_profile
 """.split()
@@ -518,6 +520,20 @@ def pairing(p_aff: np.ndarray, q_aff: np.ndarray) -> np.ndarray:
     coefficients of e(P,Q) out (host computation, as in the reference)."""
     out = np.zeros((12, 4), dtype=np.uint64)
     check(lib().bn254_pairing(ptr_of(np.ascontiguousarray(p_aff)), ptr_of(np.ascontiguousarray(q_aff)), ptr_of(out)), "pairing")
+    return out
+
+
+def gt_op(op: str, a: np.ndarray, b=None) -> np.ndarray:
+    """TargetField arithmetic (bn254_pairing_target_field_{add,sub,mul,inv,pow}); `b` is an int for pow."""
+    out = np.zeros((12, 4), dtype=np.uint64)
+    f = getattr(lib(), "bn254_pairing_target_field_" + op)
+    a = np.ascontiguousarray(a)
+    if op == "inv":
+        f(ptr_of(a), ptr_of(out))
+    elif op == "pow":
+        f(ptr_of(a), C.c_int(int(b)), ptr_of(out))
+    else:
+        f(ptr_of(a), ptr_of(np.ascontiguousarray(b)), ptr_of(out))
     return out
 
 

@@ -14,6 +14,7 @@
 // The value returned is the canonical representative of e(P,Q) in the same basis as the reference's
 // TargetField (12 Fq coefficients, standard form): tests compare it bit for bit with oracle/_ref.
 #include <mutex>
+#include <random>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -85,7 +86,12 @@ f12 f12_mul(const f12& a, const f12& b)
   f6 c1 = f6_sub(f6_sub(f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1)), v0), v1);
   return {f6_add(v0, f6_mul_v(v1)), c1};
 }
-f12 f12_sqr(const f12& a) { return f12_mul(a, a); }
+f12 f12_sqr(const f12& a) // complex squaring: (a0 + a1 w)² = (a0+a1)(a0+v·a1) − a0a1 − v·a0a1 + 2·a0a1 w
+{
+  f6 ab = f6_mul(a.c0, a.c1);
+  f6 t = f6_mul(f6_add(a.c0, a.c1), f6_add(a.c0, f6_mul_v(a.c1)));
+  return {f6_sub(f6_sub(t, ab), f6_mul_v(ab)), f6_add(ab, ab)};
+}
 f12 f12_conj(const f12& a) { return {a.c0, f6_neg(a.c1)}; } // a^(p^6)
 f12 f12_inv(const f12& a)
 {
@@ -409,6 +415,20 @@ bool read_file(const char* path, std::string* out)
   return true;
 }
 
+void bn254_base_field_generate_scalars_one(bn254_fq_t* out) // unseeded, like utils/rand_gen.h:5
+{
+  static thread_local std::mt19937_64 gen{std::random_device{}()};
+  fe v;
+  for (int k = 0; k < 8; k += 2) {
+    uint64_t x = gen();
+    v.l[k] = (uint32_t)x;
+    v.l[k + 1] = (uint32_t)(x >> 32);
+  }
+  v.l[7] &= 0x3fffffff; // < 2^254 < 6p
+  for (int k = 0; k < 5; k++) v = Fq::reduce_once(v);
+  memcpy(out, &v, 32);
+}
+
 } // namespace
 
 extern "C" {
@@ -430,6 +450,60 @@ __attribute__((visibility("default"))) eIcicleError bn254_pairing(const bn254_af
   }
   f12_store_std(pairing_mont(G1::aff_to_mont(P), G2::aff_to_mont(Q)), out);
   return ICICLE_SUCCESS;
+}
+
+// ---- TargetField (Fq12) host FFI: icicle/src/fields/ffi_extern_pairing_extension.cpp:6-52 (standard form in and out) ----
+static f12 f12_load_std(const bn254_fq12_t* a)
+{
+  f12 r;
+  const fe* src = reinterpret_cast<const fe*>(a);
+  fe* dst = reinterpret_cast<fe*>(&r);
+  for (int i = 0; i < 12; i++) dst[i] = Fq::to_mont(src[i]);
+  return r;
+}
+static f12 f12_addsub(const f12& a, const f12& b, bool sub)
+{
+  f12 r;
+  const fe* x = reinterpret_cast<const fe*>(&a);
+  const fe* y = reinterpret_cast<const fe*>(&b);
+  fe* z = reinterpret_cast<fe*>(&r);
+  for (int i = 0; i < 12; i++) z[i] = sub ? Fq::sub(x[i], y[i]) : Fq::add(x[i], y[i]);
+  return r;
+}
+__attribute__((visibility("default"))) void bn254_pairing_target_field_add(const bn254_fq12_t* a, const bn254_fq12_t* b, bn254_fq12_t* r)
+{
+  f12_store_std(f12_addsub(f12_load_std(a), f12_load_std(b), false), r);
+}
+__attribute__((visibility("default"))) void bn254_pairing_target_field_sub(const bn254_fq12_t* a, const bn254_fq12_t* b, bn254_fq12_t* r)
+{
+  f12_store_std(f12_addsub(f12_load_std(a), f12_load_std(b), true), r);
+}
+__attribute__((visibility("default"))) void bn254_pairing_target_field_mul(const bn254_fq12_t* a, const bn254_fq12_t* b, bn254_fq12_t* r)
+{
+  f12_store_std(f12_mul(f12_load_std(a), f12_load_std(b)), r);
+}
+__attribute__((visibility("default"))) void bn254_pairing_target_field_inv(const bn254_fq12_t* a, bn254_fq12_t* r)
+{
+  f12_store_std(f12_inv(f12_load_std(a)), r);
+}
+__attribute__((visibility("default"))) void bn254_pairing_target_field_pow(const bn254_fq12_t* base, int exp, bn254_fq12_t* r)
+{
+  f12 acc = f12_one(), b = f12_load_std(base);
+  for (unsigned e = (unsigned)exp; e; e >>= 1) {
+    if (e & 1) acc = f12_mul(acc, b);
+    b = f12_sqr(b);
+  }
+  f12_store_std(acc, r);
+}
+__attribute__((visibility("default"))) void bn254_pairing_target_field_from_u32(uint32_t val, bn254_fq12_t* r)
+{
+  memset(r, 0, sizeof *r);
+  r->c[0][0].c0.limbs[0] = val;
+}
+__attribute__((visibility("default"))) void bn254_pairing_target_field_generate_scalars(bn254_fq12_t* out, int size)
+{
+  for (int i = 0; i < size; i++)
+    for (int j = 0; j < 12; j++) bn254_base_field_generate_scalars_one(reinterpret_cast<bn254_fq_t*>(&out[i]) + j);
 }
 
 __attribute__((visibility("default"))) const char* groth16_verify_last_error(void) { return g_verr; }

@@ -197,6 +197,14 @@ void bn254_g2_base_field_from_u32(uint32_t val, bn254_fq2_t* result);
 
 /* ---- pairing (host): icicle/src/pairing.cpp:11-26, models/bn.h; Rust: icicle-core/src/pairing/mod.rs:38-43 ---- */
 eIcicleError bn254_pairing(const bn254_affine_t* p, const bn254_g2_affine_t* q, bn254_fq12_t* out);
+/* TargetField host FFI: icicle/src/fields/ffi_extern_pairing_extension.cpp:6-52 (Rust: icicle-bn254/src/pairing/mod.rs:16) */
+void bn254_pairing_target_field_add(const bn254_fq12_t* a, const bn254_fq12_t* b, bn254_fq12_t* result);
+void bn254_pairing_target_field_sub(const bn254_fq12_t* a, const bn254_fq12_t* b, bn254_fq12_t* result);
+void bn254_pairing_target_field_mul(const bn254_fq12_t* a, const bn254_fq12_t* b, bn254_fq12_t* result);
+void bn254_pairing_target_field_inv(const bn254_fq12_t* a, bn254_fq12_t* result);
+void bn254_pairing_target_field_pow(const bn254_fq12_t* base, int exp, bn254_fq12_t* result);
+void bn254_pairing_target_field_from_u32(uint32_t val, bn254_fq12_t* result);
+void bn254_pairing_target_field_generate_scalars(bn254_fq12_t* out, int size);
 
 /* ---- device vector ops: icicle/src/vec_ops.cpp:52-97,165-171 (CUDA: cuda_vec_ops.cu, cuda_mont.cuh) ---- */
 eIcicleError bn254_vector_add(const bn254_scalar_t* a, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);

@@ -179,6 +179,20 @@ def gt_mul(a, b):
     return out
 
 
+def gt_op(op: str, a, b=None):
+    """bn254_pairing_target_field_{add,sub,mul,inv,pow} — icicle/src/fields/ffi_extern_pairing_extension.cpp"""
+    out = _new(12, 4)
+    f = getattr(lib(), "bn254_pairing_target_field_" + op)
+    a = np.ascontiguousarray(a)
+    if op == "inv":
+        f(_p(a), _p(out))
+    elif op == "pow":
+        f(_p(a), C.c_int(int(b)), _p(out))
+    else:
+        f(_p(a), _p(np.ascontiguousarray(b)), _p(out))
+    return out
+
+
 def groth16_verify(proof: dict, public: list, vk: dict) -> bool:
     """groth16_verify_helper — src/proof_helper.rs:319-372:
     e(-A,B)·e(cpub,γ₂)·e(C,δ₂)·e(α₁,β₂) == 1.  `vk` holds affine numpy points

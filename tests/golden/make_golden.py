@@ -46,6 +46,10 @@ def hx(a):
     return np.ascontiguousarray(a).tobytes().hex()
 
 
+def unh(h):
+    return np.frombuffer(bytes.fromhex(h), dtype=np.uint64).copy().reshape(12, 4)
+
+
 def hi(x):
     return int(x).to_bytes(32, "little").hex()
 
@@ -151,7 +155,10 @@ def main():
         P = R.ec("g1", "to_affine", R.ec("g1", "mul_scalar", gen1, a))
         Q = R.ec("g2", "to_affine", R.ec("g2", "mul_scalar", gen2, b))
         cases.append(dict(a=hi(a), b=hi(b), p=hx(P), q=hx(Q), e=hx(R.pairing(P, Q))))
-    json.dump(dict(cases=cases), open(os.path.join(HERE, "pairing.json"), "w"), indent=0)
+    e0, e1 = unh(cases[3]["e"]), unh(cases[4]["e"])
+    gt = dict(a=hx(e0), b=hx(e1), add=hx(R.gt_op("add", e0, e1)), sub=hx(R.gt_op("sub", e0, e1)), mul=hx(R.gt_op("mul", e0, e1)),
+              inv=hx(R.gt_op("inv", e0)), pow5=hx(R.gt_op("pow", e0, 5)))
+    json.dump(dict(cases=cases, target_field=gt), open(os.path.join(HERE, "pairing.json"), "w"), indent=0)
     print("golden fixtures written to", HERE)
 
 

@@ -21,6 +21,23 @@ def test_pairing_matches_reference_golden(K):
         assert np.array_equal(e, unhex(c["e"], 12, 4)), (c["a"], c["b"])
 
 
+def test_target_field_ffi_matches_reference_golden(K):
+    g = load_golden("pairing.json")["target_field"]
+    a, b = unhex(g["a"], 12, 4), unhex(g["b"], 12, 4)
+    for op in ("add", "sub", "mul"):
+        assert np.array_equal(K.gt_op(op, a, b), unhex(g[op], 12, 4)), op
+    assert np.array_equal(K.gt_op("inv", a), unhex(g["inv"], 12, 4))
+    assert np.array_equal(K.gt_op("pow", a, 5), unhex(g["pow5"], 12, 4))
+    one = np.zeros((12, 4), dtype=np.uint64)
+    K.lib().bn254_pairing_target_field_from_u32(1, K.ptr_of(one))
+    assert np.array_equal(K.gt_op("mul", a, K.gt_op("inv", a)), one)
+    rnd = np.zeros((3, 12, 4), dtype=np.uint64)
+    K.lib().bn254_pairing_target_field_generate_scalars(K.ptr_of(rnd), 3)
+    q = int.from_bytes(bytes.fromhex("47fd7cd8168c203c8dca7168916a81975d588181b64550b829a031e1724e6430"), "little")
+    vals = [int.from_bytes(r.tobytes(), "little") for r in rnd.reshape(-1, 4)]
+    assert len(set(vals)) == 36 and all(v < q for v in vals)
+
+
 def test_pairing_matches_reference_live(K, R):
     rnd = random.Random(77)
     g1, g2 = R.ec("g1", "generator"), R.ec("g2", "generator")
