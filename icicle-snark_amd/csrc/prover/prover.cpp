@@ -17,6 +17,7 @@
 //    so cache construction needs no conversion pass over ~1 GB of points;
 //  * the NTT domain is sized 2·domain_size so that the coset keys g^i (g = ω_2n, src/cache.rs:183-184,
 //    264-289) are read from the twiddle table instead of a separate array + CWD file cache.
+#include <atomic>
 #include <chrono>
 #include <fcntl.h>
 #include <map>
@@ -128,6 +129,7 @@ struct MappedFile {
     void* p = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
     if (p == MAP_FAILED) return fail(ERR_IO, "cannot mmap %s", path);
     data = (const uint8_t*)p;
+    (void)madvise(p, len, MADV_WILLNEED); // start the read-ahead; the upload workers touch the pages in parallel
     return 0;
   }
 };
@@ -233,14 +235,99 @@ G2::P g2_from_mont_affine(const uint8_t* p)
   return {Fq2Ops::from_mont(a.x), Fq2Ops::from_mont(a.y), one};
 }
 
-int upload_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint32_t lo, uint32_t hi, uint64_t& bytes)
+// ---- cold path: host → device ingest ------------------------------------------------------------
+// The zkey arrives as pageable memory (an mmap of the file, or the caller's buffer).  A pageable hipMemcpy is a
+// single-threaded staging copy; here UPLOAD_THREADS workers copy 4 MB chunks into their own pair of pinned buffers
+// and enqueue the DMA on their own streams, so page faults / memcpy of one chunk overlap the DMA of the others.
+struct UploadJob {
+  void* dst;
+  const uint8_t* src;
+  size_t n;
+};
+constexpr int UPLOAD_THREADS = 8;
+constexpr size_t UPLOAD_CHUNK = 4u << 20;
+
+struct UploadPool { // pinned staging, allocated once per process and device
+  std::mutex mu;
+  int device = -1;
+  uint8_t* pinned = nullptr;
+  hipStream_t streams[UPLOAD_THREADS] = {};
+  hipEvent_t events[UPLOAD_THREADS][2] = {};
+};
+UploadPool g_upload;
+
+int staged_upload(int device_id, const std::vector<UploadJob>& jobs)
+{
+  std::lock_guard<std::mutex> lk(g_upload.mu);
+  UploadPool& P = g_upload;
+  if (P.device != device_id) {
+    if (P.pinned) {
+      (void)hipHostFree(P.pinned);
+      for (int t = 0; t < UPLOAD_THREADS; t++) {
+        (void)hipStreamDestroy(P.streams[t]);
+        (void)hipEventDestroy(P.events[t][0]);
+        (void)hipEventDestroy(P.events[t][1]);
+      }
+      P.pinned = nullptr;
+      P.device = -1;
+    }
+    P_HIP(hipHostMalloc((void**)&P.pinned, UPLOAD_THREADS * 2 * UPLOAD_CHUNK));
+    for (int t = 0; t < UPLOAD_THREADS; t++) {
+      P_HIP(hipStreamCreateWithFlags(&P.streams[t], hipStreamNonBlocking));
+      P_HIP(hipEventCreateWithFlags(&P.events[t][0], hipEventDisableTiming));
+      P_HIP(hipEventCreateWithFlags(&P.events[t][1], hipEventDisableTiming));
+    }
+    P.device = device_id;
+  }
+  std::vector<UploadJob> chunks;
+  for (const UploadJob& j : jobs)
+    for (size_t off = 0; off < j.n; off += UPLOAD_CHUNK)
+      chunks.push_back({(uint8_t*)j.dst + off, j.src + off, j.n - off < UPLOAD_CHUNK ? j.n - off : UPLOAD_CHUNK});
+  std::atomic<size_t> next{0};
+  std::atomic<int> err{(int)hipSuccess};
+  auto worker = [&](int t) {
+    if (hipSetDevice(device_id) != hipSuccess) {
+      err = (int)hipErrorInvalidDevice;
+      return;
+    }
+    uint8_t* buf[2] = {P.pinned + (size_t)t * 2 * UPLOAD_CHUNK, P.pinned + ((size_t)t * 2 + 1) * UPLOAD_CHUNK};
+    bool used[2] = {false, false};
+    for (int k = 0;; k ^= 1) {
+      const size_t i = next.fetch_add(1);
+      if (i >= chunks.size() || err.load() != (int)hipSuccess) break;
+      hipError_t e = hipSuccess;
+      if (used[k]) e = hipEventSynchronize(P.events[t][k]); // the DMA that last read this buffer is done
+      if (e == hipSuccess) {
+        memcpy(buf[k], chunks[i].src, chunks[i].n);
+        e = hipMemcpyAsync(chunks[i].dst, buf[k], chunks[i].n, hipMemcpyHostToDevice, P.streams[t]);
+      }
+      if (e == hipSuccess) e = hipEventRecord(P.events[t][k], P.streams[t]);
+      used[k] = true;
+      if (e != hipSuccess) {
+        err = (int)e;
+        break;
+      }
+    }
+    hipError_t e = hipStreamSynchronize(P.streams[t]);
+    if (e != hipSuccess) err = (int)e;
+  };
+  std::vector<std::thread> th;
+  const int nt = chunks.size() < (size_t)UPLOAD_THREADS ? (int)chunks.size() : UPLOAD_THREADS;
+  for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
+  if (nt > 0) worker(0);
+  for (auto& x : th) x.join();
+  if (err.load() != (int)hipSuccess) return fail((int)ICICLE_COPY_FAILED, "zkey upload: %s", hipGetErrorString((hipError_t)err.load()));
+  return 0;
+}
+
+int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint32_t lo, uint32_t hi, uint64_t& bytes, std::vector<UploadJob>& jobs)
 {
   if (sec->size != (uint64_t)total * elem) return fail(ERR_FORMAT, "zkey: point section size mismatch");
   sh.lo = lo;
   sh.hi = hi;
   const size_t n = (size_t)sh.len() * elem;
   P_HIP(hipMalloc(&sh.d_points, n ? n : 256));
-  if (n) P_HIP(hipMemcpy(sh.d_points, sec->p + (size_t)sh.lo * elem, n, hipMemcpyHostToDevice));
+  if (n) jobs.push_back({sh.d_points, sec->p + (size_t)sh.lo * elem, n});
   bytes += n;
   return 0;
 }
@@ -303,44 +390,20 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   if (s4->size < 4 || (s4->size - 4) % rec) return fail(ERR_FORMAT, "zkey: coefficient section size");
   const uint32_t n_coef = (uint32_t)((s4->size - 4) / rec);
   z->n_coef = n_coef;
-  std::vector<uint32_t> rowptr(2 * (size_t)n + 2, 0), cols(n_coef ? n_coef : 1), order(n_coef ? n_coef : 1);
-  const uint8_t* cp = s4->p + 4;
-  for (uint32_t i = 0; i < n_coef; i++) {
-    const uint8_t* e = cp + (size_t)i * rec;
-    uint32_t c, sidx;
-    memcpy(&c, e + 4, 4);
-    memcpy(&sidx, e + 8, 4);
-    const uint32_t m = e[0];
-    if (m > 1 || c >= n || sidx >= z->n_vars) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", i);
-    rowptr[(size_t)m * n + c + 1]++;
-  }
-  for (size_t i = 0; i < 2 * (size_t)n; i++) rowptr[i + 1] += rowptr[i];
-  {
-    std::vector<uint32_t> cur(rowptr.begin(), rowptr.end() - 1);
-    std::vector<fe> vals(n_coef ? n_coef : 1);
-    for (uint32_t i = 0; i < n_coef; i++) {
-      const uint8_t* e = cp + (size_t)i * rec;
-      uint32_t c, sidx;
-      memcpy(&c, e + 4, 4);
-      memcpy(&sidx, e + 8, 4);
-      const uint32_t pos = cur[(size_t)e[0] * n + c]++;
-      cols[pos] = sidx;
-      memcpy(vals[pos].l, e + 12, 32);
-    }
-    P_HIP(hipMalloc((void**)&z->d_rowptr, (2 * (size_t)n + 1) * 4));
-    P_HIP(hipMalloc((void**)&z->d_cols, (size_t)(n_coef ? n_coef : 1) * 4));
-    P_HIP(hipMalloc((void**)&z->d_vals, (size_t)(n_coef ? n_coef : 1) * 32));
-    P_HIP(hipMemcpy(z->d_rowptr, rowptr.data(), (2 * (size_t)n + 1) * 4, hipMemcpyHostToDevice));
-    P_HIP(hipMemcpy(z->d_cols, cols.data(), (size_t)n_coef * 4, hipMemcpyHostToDevice));
-    P_HIP(hipMemcpy(z->d_vals, vals.data(), (size_t)n_coef * 32, hipMemcpyHostToDevice));
-    z->device_bytes += (2 * (size_t)n + 1) * 4 + (size_t)n_coef * 36;
-    // the file stores value·R² ; one from_mont (src/cache.rs:214) leaves value·R = Montgomery form of the coefficient
-    VecOpsConfig vc;
-    memset(&vc, 0, sizeof vc);
-    vc.is_a_on_device = vc.is_result_on_device = true;
-    vc.batch_size = 1;
-    P_ICICLE(bn254_scalar_convert_montgomery((const bn254_scalar_t*)z->d_vals, n_coef, false, &vc, (bn254_scalar_t*)z->d_vals));
-  }
+  // device CSR built by kernels from the raw records (prover/csr.hip); the records travel with the points below
+  uint32_t* d_records = nullptr;
+  const size_t rec_bytes = (size_t)n_coef * rec;
+  P_HIP(hipMalloc((void**)&d_records, rec_bytes ? rec_bytes : 4));
+  struct FreeTmp {
+    void* p;
+    ~FreeTmp() { (void)hipFree(p); }
+  } free_records{d_records};
+  P_HIP(hipMalloc((void**)&z->d_rowptr, (2 * (size_t)n + 1) * 4));
+  P_HIP(hipMalloc((void**)&z->d_cols, (size_t)(n_coef ? n_coef : 1) * 4));
+  P_HIP(hipMalloc((void**)&z->d_vals, (size_t)(n_coef ? n_coef : 1) * 32));
+  z->device_bytes += (2 * (size_t)n + 1) * 4 + (size_t)n_coef * 36;
+  std::vector<UploadJob> jobs;
+  if (rec_bytes) jobs.push_back({d_records, s4->p + 4, rec_bytes});
 
   // bases (sections 5-9), this process's point range only
   // A, B1, B2 share the witness range [wlo, whi); C (= witness[n_public+1..]) takes the part of that SAME
@@ -349,11 +412,17 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   const uint32_t skip = z->n_public + 1;
   const uint32_t clo = (wlo > skip ? wlo : skip) - skip, chi = (whi > skip ? whi : skip) - skip;
   const uint32_t hlo = (uint32_t)((uint64_t)n * rank / count), hhi = (uint32_t)((uint64_t)n * (rank + 1) / count);
-  if (int rc = upload_shard(z->A, s5, 64, z->n_vars, wlo, whi, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->B1, s6, 64, z->n_vars, wlo, whi, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->B2, s7, 128, z->n_vars, wlo, whi, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->C, s8, 64, z->n_vars - skip, clo, chi, z->device_bytes)) return rc;
-  if (int rc = upload_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes)) return rc;
+  if (int rc = alloc_shard(z->A, s5, 64, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
+  if (int rc = alloc_shard(z->B1, s6, 64, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
+  if (int rc = alloc_shard(z->B2, s7, 128, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
+  if (int rc = alloc_shard(z->C, s8, 64, z->n_vars - skip, clo, chi, z->device_bytes, jobs)) return rc;
+  if (int rc = alloc_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes, jobs)) return rc;
+  if (int rc = staged_upload(device_id, jobs)) return rc;
+  {
+    uint32_t first_bad = 0;
+    P_HIP(qap_build_csr(d_records, n_coef, n, z->n_vars, z->d_rowptr, z->d_cols, z->d_vals, &first_bad, nullptr));
+    if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
+  }
 
   P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));

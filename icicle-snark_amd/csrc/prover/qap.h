@@ -17,4 +17,10 @@ hipError_t qap_coset_mul3(bn254::fe* d_vec, const bn254::fe* keys, uint32_t key_
 // slot1 = slot0∘slot1 − slot2 — src/proof_helper.rs:154-167 (slot0 is left untouched)
 hipError_t qap_final(bn254::fe* d_vec, uint32_t n, hipStream_t s);
 
+// cold path (csr.hip): CSR of zkey section 4 built on the device from the raw 44-byte records
+// {m:u32 c:u32 s:u32 value[32 B]} (src/cache.rs:126-166); vals come out as Montgomery-form coefficients (:214).
+// rowptr has 2n+1 entries.  *first_bad = index of the first out-of-range record, 0xffffffff if none.  Synchronises `s`.
+hipError_t qap_build_csr(const uint32_t* d_records, uint32_t n_coef, uint32_t n, uint32_t n_vars, uint32_t* d_rowptr, uint32_t* d_cols, bn254::fe* d_vals,
+                         uint32_t* first_bad, hipStream_t s);
+
 } // namespace isnark

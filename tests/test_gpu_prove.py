@@ -125,7 +125,7 @@ def test_cli_repl_protocol(gpu, O, S, tmp_path):
         assert R.groth16_verify(proof, json.loads((tmp_path / "q.json").read_text()), vk)
 
 
-def test_prover_errors(gpu, cm, S):
+def test_prover_errors(gpu, cm, S, O):
     K = gpu
     with pytest.raises(K.ProverError):
         cm.load("bad", b"nope" + bytes(100))
@@ -138,3 +138,9 @@ def test_prover_errors(gpu, cm, S):
         cm.prove_mem("missing", S.write_wtns(w), 1, 1)
     with pytest.raises(K.ProverError):      # no CPU fallback
         cm.prove("w", "z", "p", "q", device="CPU")
+    # a coefficient record that points outside the domain is rejected by the device-side CSR build
+    off, _ = O.read_sections(zkey, b"zkey")[4]
+    bad = bytearray(zkey)
+    bad[off + 4 + 3 * 44 + 4: off + 4 + 3 * 44 + 8] = (1 << 20).to_bytes(4, "little")   # record 3: c = 2^20 ≥ n
+    with pytest.raises(K.ProverError, match="coefficient 3 out of range"):
+        cm.load("bad-coef", bytes(bad))
