@@ -458,8 +458,13 @@ class CacheManager:
         return bool(lib().groth16_cache_contains(self._h, key.encode()))
 
     def load(self, key: str, zkey: bytes, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1):
-        buf = (C.c_char * len(zkey)).from_buffer_copy(zkey) if not isinstance(zkey, np.ndarray) else None
-        p = buf if buf is not None else zkey.ctypes.data_as(C.c_void_p)
+        # zero-copy views of the caller's buffer (a 0.8 GB zkey must not be duplicated on the way in)
+        if isinstance(zkey, np.ndarray):
+            p = zkey.ctypes.data_as(C.c_void_p)
+        elif isinstance(zkey, bytes):
+            p = C.c_char_p(zkey)
+        else:
+            p = (C.c_char * len(zkey)).from_buffer(zkey)   # bytearray / writable memoryview
         _pcheck(lib().groth16_cache_load(self._h, key.encode(), p, C.c_size_t(len(zkey)), device_id, shard_rank, shard_count), "cache_load")
 
     def load_file(self, key: str, path: str, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1):

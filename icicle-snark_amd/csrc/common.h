@@ -114,6 +114,29 @@ hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s);
 hipError_t ws_free(void* p, hipStream_t s);
 void ws_release_stream(hipStream_t s); // caller has synchronised the stream
 
+// Scoped workspace block: returned to its stream's arena when the scope ends, on every path (error returns too).
+template <class T>
+struct WsScoped {
+  T* p = nullptr;
+  hipStream_t s = nullptr;
+  WsScoped() = default;
+  WsScoped(const WsScoped&) = delete;
+  WsScoped& operator=(const WsScoped&) = delete;
+  ~WsScoped() { release(); }
+  hipError_t alloc(size_t count, hipStream_t stream)
+  {
+    release();
+    s = stream;
+    return ws_alloc((void**)&p, (count ? count : 1) * sizeof(T), stream);
+  }
+  void release()
+  {
+    if (p) (void)ws_free(p, s);
+    p = nullptr;
+  }
+  operator T*() const { return p; }
+};
+
 // finish an API call: synchronise unless the caller asked for async execution
 inline eIcicleError end_call(hipStream_t s, bool is_async)
 {

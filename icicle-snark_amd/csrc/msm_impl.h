@@ -319,22 +319,20 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   typedef typename C::X X;
   const MsmGeom& g = pl->g;
   const ReduceShape rs = reduce_shape<X>(g);
-  X* buckets = nullptr;
-  HIP_TRY(ws_alloc((void**)&buckets, (size_t)pl->nbuckets * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
+  WsScoped<X> buckets, item_partials;
+  HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);
-  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, s, buckets);
+  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, s, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
-  X* item_partials = nullptr;
-  HIP_TRY(ws_alloc((void**)&item_partials, (size_t)pl->item_cap * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, mont_pt, item_partials);
-  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials, buckets);
+  HIP_TRY(item_partials.alloc(pl->item_cap, s), ICICLE_ALLOCATION_FAILED);
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, mont_pt, item_partials.p);
+  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
-  HIP_TRY(ws_free(item_partials, s), ICICLE_DEALLOCATION_FAILED);
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.W), dim3(rs.rblock), rs.rblock * sizeof(X), s, buckets, g.NB, rs.k_log, d_partials);
+  item_partials.release();
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.W), dim3(rs.rblock), rs.rblock * sizeof(X), s, buckets.p, g.NB, rs.k_log, d_partials);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
-  HIP_TRY(ws_free(buckets, s), ICICLE_DEALLOCATION_FAILED);
   return ICICLE_SUCCESS;
 }
 
@@ -389,14 +387,14 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   prof->W = pl.g.W;
   prof->is_g2 = sizeof(A) > 64;
   const ReduceShape rs = reduce_shape<X>(pl.g);
-  X* partials = nullptr;
-  HIP_TRY(ws_alloc((void**)&partials, (size_t)pl.g.W * rs.bpw * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  ICICLE_TRY(msm_buckets_run<C>(&pl, sb.ptr<A>(), cfg->are_points_montgomery_form, 0, s, partials, prof));
-  hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials, pl.g.W, (int)rs.bpw, pl.g.c, sr.ptr<P>());
+  WsScoped<X> partials;
+  HIP_TRY(partials.alloc((size_t)pl.g.W * rs.bpw, s), ICICLE_ALLOCATION_FAILED);
+  ICICLE_TRY(msm_buckets_run<C>(&pl, sb.ptr<A>(), cfg->are_points_montgomery_form, 0, s, partials.p, prof));
+  hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, (int)rs.bpw, pl.g.c, sr.ptr<P>());
   ICICLE_TRY(check_launch("msm_tail"));
   (void)hipEventRecord(prof->ev[3], s);
   prof->valid = true;
-  HIP_TRY(ws_free(partials, s), ICICLE_DEALLOCATION_FAILED);
+  partials.release();
   msm_sort_release(&pl);
   ICICLE_TRY(sr.finish());
   if (profile) {
@@ -418,24 +416,21 @@ eIcicleError generator_mul_impl(const bn254_scalar_t* sc, uint64_t n, hipStream_
   if (!sc || !out) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(require_device());
   if (n == 0) return ICICLE_SUCCESS;
-  X* table = nullptr;
-  P* proj = nullptr;
-  typename F::T* scratch = nullptr;
-  HIP_TRY(ws_alloc((void**)&table, 32 * 255 * sizeof(X), s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(ws_alloc((void**)&proj, n * sizeof(P), s), ICICLE_ALLOCATION_FAILED);
-  HIP_TRY(ws_alloc((void**)&scratch, n * sizeof(typename F::T), s), ICICLE_ALLOCATION_FAILED);
+  WsScoped<X> table;
+  WsScoped<P> proj;
+  WsScoped<typename F::T> scratch;
+  HIP_TRY(table.alloc(32 * 255, s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(proj.alloc(n, s), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(scratch.alloc(n, s), ICICLE_ALLOCATION_FAILED);
   A gm = C::aff_to_mont(gen_std);
-  hipLaunchKernelGGL((fixed_base_table_kernel<C>), dim3(1), dim3(256), 0, s, gm, table);
+  hipLaunchKernelGGL((fixed_base_table_kernel<C>), dim3(1), dim3(256), 0, s, gm, table.p);
   ICICLE_TRY(check_launch("fixed_base_table"));
-  hipLaunchKernelGGL((fixed_base_mul_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const fe*>(sc), n, table, proj);
+  hipLaunchKernelGGL((fixed_base_mul_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const fe*>(sc), n, table.p, proj.p);
   ICICLE_TRY(check_launch("fixed_base_mul"));
   const int chunk = 32;
   const uint64_t nthreads = (n + chunk - 1) / chunk;
-  hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, proj, n, chunk, reinterpret_cast<A*>(out), scratch);
+  hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, proj.p, n, chunk, reinterpret_cast<A*>(out), scratch.p);
   ICICLE_TRY(check_launch("batch_to_affine"));
-  HIP_TRY(ws_free(table, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(ws_free(proj, s), ICICLE_DEALLOCATION_FAILED);
-  HIP_TRY(ws_free(scratch, s), ICICLE_DEALLOCATION_FAILED);
   return ICICLE_SUCCESS;
 }
 

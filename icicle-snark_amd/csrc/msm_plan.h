@@ -32,12 +32,17 @@ struct SortPlan {
   uint32_t* order = nullptr;   // [nbuckets] bucket ids by decreasing entry count (wave-uniform trip counts)
   uint32_t* sorted = nullptr;  // [L·W] (index within the scalar vector) | sign << 31, grouped by bucket
   hipStream_t stream = nullptr;
+  SortPlan() = default;
+  SortPlan(const SortPlan&) = delete;
+  SortPlan& operator=(const SortPlan&) = delete;
+  ~SortPlan(); // = msm_sort_release(this): the workspace goes back to the arena on every path
 };
 
 // geometry for a length-L MSM (c_cfg > 0 forces the window size)
 MsmGeom msm_geometry(uint32_t L, int c_cfg);
 // recode → histogram → scan → scatter on stream s.  Workspace comes from the arena of stream s and is
-// returned by msm_sort_release (which only marks it reusable by later work on that stream).
+// returned by msm_sort_release (which only marks it reusable by later work on that stream; idempotent, also
+// run by ~SortPlan).
 eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl);
 void msm_sort_release(SortPlan* pl);
 

@@ -416,7 +416,11 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->large_items = reinterpret_cast<uint2*>(obsum + oscan + ((nb * 6 + 4 + nblocks + nparts + om + oscan) & 1)); // 8-byte aligned
   HIP_TRY(ws_alloc((void**)&pl->sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
   uint32_t* tmp = nullptr;
-  if (two_level) HIP_TRY(ws_alloc((void**)&tmp, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
+  WsScoped<uint32_t> tmp_block;
+  if (two_level) {
+    HIP_TRY(tmp_block.alloc((size_t)nentries, s), ICICLE_ALLOCATION_FAILED);
+    tmp = tmp_block;
+  }
 
   unsigned zb = (nb + 255) / 256;
   if (zb > 1024) zb = 1024;
@@ -440,7 +444,6 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, obsum, oscan);
   hipLaunchKernelGGL(msm_scan_apply_kernel, dim3(oscan), dim3(SCAN_T), 0, s, blockhist, om, obsum, blockhist);
   hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(oblk), dim3(ORDER_BINS), 0, s, pl->counts, nb, oblk, blockhist, pl->order);
-  if (tmp) HIP_TRY(ws_free(tmp, s), ICICLE_DEALLOCATION_FAILED);
   return check_launch("msm_sort");
 }
 
@@ -450,6 +453,7 @@ void msm_sort_release(SortPlan* pl)
   if (pl->sorted) (void)ws_free(pl->sorted, pl->stream);
   pl->ws = pl->sorted = nullptr;
 }
+SortPlan::~SortPlan() { msm_sort_release(this); }
 
 } // namespace isnark
 

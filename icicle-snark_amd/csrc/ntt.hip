@@ -481,8 +481,12 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
   else { np = 3; lr[0] = MAX_LOG_R; lr[1] = (logn - MAX_LOG_R + 1) / 2; lr[2] = (logn - MAX_LOG_R) / 2; } // 9 bits = three radix-8 rounds
 
   fe* scratch = nullptr;
+  WsScoped<fe> scratch_block;
   const bool need_pre_coset = has_coset && !inverse;
-  if (np > 1 || need_pre_coset) HIP_TRY(ws_alloc((void**)&scratch, total * sizeof(fe), s), ICICLE_ALLOCATION_FAILED);
+  if (np > 1 || need_pre_coset) {
+    HIP_TRY(scratch_block.alloc(total, s), ICICLE_ALLOCATION_FAILED);
+    scratch = scratch_block;
+  }
   if (need_pre_coset) {
     // x_j *= g^j into scratch, then transform from scratch
     HIP_TRY(hipMemcpyAsync(scratch, d_in, total * sizeof(fe), hipMemcpyDeviceToDevice, s), ICICLE_COPY_FAILED);
@@ -560,7 +564,7 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
     hipLaunchKernelGGL(coset_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_out, n, batch, d_gpow, logn);
     ICICLE_TRY(check_launch("coset_mul"));
   }
-  if (scratch) HIP_TRY(ws_free(scratch, s), ICICLE_DEALLOCATION_FAILED);
+  scratch_block.release();
   if (d_gpow) {
     HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
     HIP_TRY(hipFree(d_gpow), ICICLE_DEALLOCATION_FAILED);

@@ -237,7 +237,7 @@ G2::P g2_from_mont_affine(const uint8_t* p)
 
 // ---- cold path: host → device ingest ------------------------------------------------------------
 // The zkey arrives as pageable memory (an mmap of the file, or the caller's buffer).  A pageable hipMemcpy is a
-// single-threaded staging copy; here UPLOAD_THREADS workers copy 4 MB chunks into their own pair of pinned buffers
+// single-threaded staging copy; here UPLOAD_THREADS workers copy 2 MB chunks into their own pair of pinned buffers
 // and enqueue the DMA on their own streams, so page faults / memcpy of one chunk overlap the DMA of the others.
 struct UploadJob {
   void* dst;
@@ -245,14 +245,11 @@ struct UploadJob {
   size_t n;
 };
 constexpr int UPLOAD_THREADS = 8;
-constexpr size_t UPLOAD_CHUNK = 4u << 20;
+constexpr size_t UPLOAD_CHUNK = 2u << 20;
 
-struct UploadPool { // pinned staging, allocated once per process and device
+struct UploadPool { // pinned staging, allocated once per process
   std::mutex mu;
-  int device = -1;
   uint8_t* pinned = nullptr;
-  hipStream_t streams[UPLOAD_THREADS] = {};
-  hipEvent_t events[UPLOAD_THREADS][2] = {};
 };
 UploadPool g_upload;
 
@@ -260,25 +257,21 @@ int staged_upload(int device_id, const std::vector<UploadJob>& jobs)
 {
   std::lock_guard<std::mutex> lk(g_upload.mu);
   UploadPool& P = g_upload;
-  if (P.device != device_id) {
-    if (P.pinned) {
-      (void)hipHostFree(P.pinned);
+  if (!P.pinned) P_HIP(hipHostMalloc((void**)&P.pinned, UPLOAD_THREADS * 2 * UPLOAD_CHUNK, hipHostMallocPortable));
+  // streams and events live only for this call: idle streams would still occupy hardware-queue slots that the
+  // prover's own streams need (runtime.cpp, GPU_MAX_HW_QUEUES)
+  struct Lanes {
+    hipStream_t streams[UPLOAD_THREADS] = {};
+    hipEvent_t events[UPLOAD_THREADS][2] = {};
+    ~Lanes()
+    {
       for (int t = 0; t < UPLOAD_THREADS; t++) {
-        (void)hipStreamDestroy(P.streams[t]);
-        (void)hipEventDestroy(P.events[t][0]);
-        (void)hipEventDestroy(P.events[t][1]);
+        if (streams[t]) (void)hipStreamDestroy(streams[t]);
+        for (int k = 0; k < 2; k++)
+          if (events[t][k]) (void)hipEventDestroy(events[t][k]);
       }
-      P.pinned = nullptr;
-      P.device = -1;
     }
-    P_HIP(hipHostMalloc((void**)&P.pinned, UPLOAD_THREADS * 2 * UPLOAD_CHUNK));
-    for (int t = 0; t < UPLOAD_THREADS; t++) {
-      P_HIP(hipStreamCreateWithFlags(&P.streams[t], hipStreamNonBlocking));
-      P_HIP(hipEventCreateWithFlags(&P.events[t][0], hipEventDisableTiming));
-      P_HIP(hipEventCreateWithFlags(&P.events[t][1], hipEventDisableTiming));
-    }
-    P.device = device_id;
-  }
+  } lanes;
   std::vector<UploadJob> chunks;
   for (const UploadJob& j : jobs)
     for (size_t off = 0; off < j.n; off += UPLOAD_CHUNK)
@@ -296,23 +289,28 @@ int staged_upload(int device_id, const std::vector<UploadJob>& jobs)
       const size_t i = next.fetch_add(1);
       if (i >= chunks.size() || err.load() != (int)hipSuccess) break;
       hipError_t e = hipSuccess;
-      if (used[k]) e = hipEventSynchronize(P.events[t][k]); // the DMA that last read this buffer is done
+      if (used[k]) e = hipEventSynchronize(lanes.events[t][k]); // the DMA that last read this buffer is done
       if (e == hipSuccess) {
         memcpy(buf[k], chunks[i].src, chunks[i].n);
-        e = hipMemcpyAsync(chunks[i].dst, buf[k], chunks[i].n, hipMemcpyHostToDevice, P.streams[t]);
+        e = hipMemcpyAsync(chunks[i].dst, buf[k], chunks[i].n, hipMemcpyHostToDevice, lanes.streams[t]);
       }
-      if (e == hipSuccess) e = hipEventRecord(P.events[t][k], P.streams[t]);
+      if (e == hipSuccess) e = hipEventRecord(lanes.events[t][k], lanes.streams[t]);
       used[k] = true;
       if (e != hipSuccess) {
         err = (int)e;
         break;
       }
     }
-    hipError_t e = hipStreamSynchronize(P.streams[t]);
+    hipError_t e = hipStreamSynchronize(lanes.streams[t]);
     if (e != hipSuccess) err = (int)e;
   };
   std::vector<std::thread> th;
   const int nt = chunks.size() < (size_t)UPLOAD_THREADS ? (int)chunks.size() : UPLOAD_THREADS;
+  for (int t = 0; t < nt; t++) {
+    P_HIP(hipStreamCreateWithFlags(&lanes.streams[t], hipStreamNonBlocking));
+    P_HIP(hipEventCreateWithFlags(&lanes.events[t][0], hipEventDisableTiming));
+    P_HIP(hipEventCreateWithFlags(&lanes.events[t][1], hipEventDisableTiming));
+  }
   for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
   if (nt > 0) worker(0);
   for (auto& x : th) x.join();
@@ -342,6 +340,14 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   dev.id = device_id;
   P_ICICLE(icicle_set_device(&dev));
 
+  const bool trace = getenv("ICICLE_SNARK_TRACE_COLD") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cold] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   std::vector<Section> s;
   if (int rc = read_sections(data, len, "zkey", 2, s)) return rc;
   const Section *s1, *s2, *s4, *s5, *s6, *s7, *s8, *s9;
@@ -404,6 +410,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   z->device_bytes += (2 * (size_t)n + 1) * 4 + (size_t)n_coef * 36;
   std::vector<UploadJob> jobs;
   if (rec_bytes) jobs.push_back({d_records, s4->p + 4, rec_bytes});
+  lap("header + coefficient buffers");
 
   // bases (sections 5-9), this process's point range only
   // A, B1, B2 share the witness range [wlo, whi); C (= witness[n_public+1..]) takes the part of that SAME
@@ -417,12 +424,15 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   if (int rc = alloc_shard(z->B2, s7, 128, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
   if (int rc = alloc_shard(z->C, s8, 64, z->n_vars - skip, clo, chi, z->device_bytes, jobs)) return rc;
   if (int rc = alloc_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes, jobs)) return rc;
+  lap("point buffers (hipMalloc)");
   if (int rc = staged_upload(device_id, jobs)) return rc;
+  lap("staged upload");
   {
     uint32_t first_bad = 0;
     P_HIP(qap_build_csr(d_records, n_coef, n, z->n_vars, z->d_rowptr, z->d_cols, z->d_vals, &first_bad, nullptr));
     if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
   }
+  lap("device CSR build");
 
   P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
@@ -430,6 +440,8 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE));
   P_HIP(hipHostMalloc((void**)&z->h_witness, (size_t)z->n_vars * 32));
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
+  // five streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
+  // Stream priorities were tried (QAP chain high, G2 low, …): every variant was 1-2 ms slower than equal priorities.
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
@@ -443,6 +455,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipEventCreateWithFlags(&z->ev_g5done, hipEventDisableTiming));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
   for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  lap("work buffers, streams, events");
   out = std::move(z);
   return 0;
 }

@@ -139,7 +139,7 @@ def test_prover_errors(gpu, cm, S, O):
     with pytest.raises(K.ProverError):      # no CPU fallback
         cm.prove("w", "z", "p", "q", device="CPU")
     # a coefficient record that points outside the domain is rejected by the device-side CSR build
-    off, _ = O.read_sections(zkey, b"zkey")[4]
+    (off, _), = O.read_sections(zkey, b"zkey")[4]
     bad = bytearray(zkey)
     bad[off + 4 + 3 * 44 + 4: off + 4 + 3 * 44 + 8] = (1 << 20).to_bytes(4, "little")   # record 3: c = 2^20 ≥ n
     with pytest.raises(K.ProverError, match="coefficient 3 out of range"):
