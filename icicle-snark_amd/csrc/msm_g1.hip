@@ -15,6 +15,7 @@ eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int point
 {
   return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, s, (G1::X*)d_partials, prof);
 }
+eIcicleError msm_g1_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G1>(d_points, n, from_form, s); }
 void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out)
 {
   G1::P p = msm_host_tail<G1>((const G1::X*)h_partials, W, bpw, c);

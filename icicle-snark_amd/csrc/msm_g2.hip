@@ -7,6 +7,7 @@ eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int point
 {
   return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, s, (G2::X*)d_partials, prof);
 }
+eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G2>(d_points, n, from_form, s); }
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out)
 {
   G2::P p = msm_host_tail<G2>((const G2::X*)h_partials, W, bpw, c);

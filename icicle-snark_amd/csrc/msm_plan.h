@@ -62,9 +62,14 @@ MsmProfile* msm_profile_next();
 // d_partials (device, caller-provided, ≥ msm_partials_bytes()).  Entries whose scalar index is < skip_below
 // are ignored and the base index is (scalar index − skip_below): lets the C MSM (witness[n_public+1..])
 // share the witness sort.
+// `points_form` below: 0 standard form, 1 Montgomery R = 2^256 (as stored in zkey files), 2 the internal encoding of the
+// bucket kernels (packed canonical Montgomery R' = 2^261, ff29.h).  msm_*_points_to_internal converts a base array
+// in place (once per key; the identity (0,0) is preserved) so that the hot loop loads points without a conversion.
+eIcicleError msm_g1_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s);
+eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s);
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bpw);
-eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
-eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
+eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
 // host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective
 void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out);
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out);

@@ -433,6 +433,14 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
   }
   lap("device CSR build");
+  // bases: the file's Montgomery form (R = 2^256) → the bucket kernels' internal encoding (R' = 2^261), once, in place
+  P_ICICLE(msm_g1_points_to_internal(z->A.d_points, z->A.len(), 1, nullptr));
+  P_ICICLE(msm_g1_points_to_internal(z->B1.d_points, z->B1.len(), 1, nullptr));
+  P_ICICLE(msm_g2_points_to_internal(z->B2.d_points, z->B2.len(), 1, nullptr));
+  P_ICICLE(msm_g1_points_to_internal(z->C.d_points, z->C.len(), 1, nullptr));
+  P_ICICLE(msm_g1_points_to_internal(z->H.d_points, z->H.len(), 1, nullptr));
+  P_HIP(hipStreamSynchronize(nullptr));
+  lap("points to internal form");
 
   P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
@@ -644,7 +652,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
   P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
   fill(prof[2], plan_w, 1);
-  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 1, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2])); // commitment_b — src/proof_helper.rs:206
+  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2])); // commitment_b — src/proof_helper.rs:206
   (void)hipEventRecord(prof[2]->ev[3], g2);
   prof[2]->valid = true;
   P_HIP(hipEventRecord(z->ev_g2done, g2));
@@ -668,7 +676,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
     P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
     if (k) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
     (void)hipEventRecord(p->ev[0], st3[k]);
-    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 1, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p));
+    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p));
     (void)hipEventRecord(p->ev[3], st3[k]);
     p->valid = true;
   }
@@ -676,7 +684,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_HIP(hipEventRecord(z->ev_g5done, z->s_g5));
   P_HIP(hipStreamWaitEvent(g1, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
-  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 1, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4]));
+  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4]));
   (void)hipEventRecord(prof[4]->ev[3], g1);
   prof[4]->valid = true;
   // Each MSM's partial sums go to pinned memory on ITS OWN stream as soon as its reduction is done, and a host

@@ -1,0 +1,87 @@
+// f29_check.cpp — host-side checked build of the lazy radix-2^29 arithmetic (csrc/ff29.h, csrc/ec29.h).
+// Test infrastructure: compiled with g++ -DF29_CHECK by tests/test_f29.py; every bound stated in those headers is
+// asserted (128-bit column accumulators, limb domination in subtractions, value bounds) while the results are
+// compared with the 8×32-bit arithmetic of ff.h / ec.h.  Returns 0 on success; f29_last_failure() names the
+// first violated bound.
+#include <stdint.h>
+#include <string.h>
+
+#include "../icicle-snark_amd/csrc/ec29.h"
+
+using namespace bn254;
+
+static const char* g_msg = "";
+extern "C" const char* f29_last_failure() { return f29::g_check_failure ? f29::g_check_failure : g_msg; }
+extern "C" void f29_reset() { f29::g_check_failure = nullptr; g_msg = ""; }
+
+static bool same(const fe& a, const fe& b) { return memcmp(&a, &b, sizeof a) == 0; }
+static int bad(const char* m) { g_msg = m; return 1; }
+
+// field level: n triples (a, b, c) of canonical standard-form Fq elements
+extern "C" int f29_check_field(const fe* v, int n)
+{
+  for (int i = 0; i + 3 < n; i++) {
+    const fe a = v[i], b = v[i + 1], c = v[i + 2], d = v[i + 3];
+    const fe am = Fq::to_mont(a), bm = Fq::to_mont(b), cm = Fq::to_mont(c), dm = Fq::to_mont(d);
+    const fe9 a9 = f29::from_std(a), b9 = f29::from_std(b), c9 = f29::from_std(c), d9 = f29::from_std(d);
+    if (!same(f29::to_mont256(a9), am)) return bad("from_std/to_mont256 round trip");
+    if (!same(f29::to_mont256(f29::from_mont256(am)), am)) return bad("from_mont256");
+    if (!same(f29::pack(f29::unpack(a)), a)) return bad("pack/unpack");
+    if (!same(f29::to_mont256(f29::mul(a9, b9)), Fq::mul(am, bm))) return bad("mul");
+    if (!same(f29::to_mont256(f29::sqr(a9)), Fq::sqr(am))) return bad("sqr");
+    if (!same(f29::to_mont256(f29::mul2(a9, b9, c9, d9)), Fq::add(Fq::mul(am, bm), Fq::mul(cm, dm)))) return bad("mul2");
+    if (!same(f29::to_mont256(f29::mul4(a9, b9, c9, d9, a9, c9, b9, d9)),
+              Fq::add(Fq::add(Fq::mul(am, bm), Fq::mul(cm, dm)), Fq::add(Fq::mul(am, cm), Fq::mul(bm, dm)))))
+      return bad("mul4");
+    if (!same(f29::to_mont256(f29::norm(f29::sub<3, 1>(a9, b9))), Fq::sub(am, bm))) return bad("sub<3,1>");
+    if (!same(f29::to_mont256(f29::norm(f29::add(a9, b9))), Fq::add(am, bm))) return bad("add");
+    const fe9 t = f29::norm(f29::sub<5, 3>(a9, f29::add(b9, f29::dbl(c9))));
+    if (!same(f29::to_mont256(f29::reduce_lt2p(t)), Fq::sub(Fq::sub(am, bm), Fq::dbl(cm)))) return bad("sub<5,3>/reduce_lt2p");
+    if (!same(f29::pack(f29::canon(f29::unpack(a))), a)) return bad("canon of canonical");
+    // lazy squares at the stated input bound (<5p, N)
+    const fe9 w = f29::norm(f29::sub<3, 1>(a9, b9));
+    if (!same(f29::to_mont256(f29::sqr(w)), Fq::sqr(Fq::sub(am, bm)))) return bad("sqr of a lazy difference");
+    const bool z = f29::maybe_zero_mod_p(f29::norm(f29::sub<3, 1>(a9, a9)));
+    if (!z || !f29::is_zero_canon(f29::canon(f29::norm(f29::sub<3, 1>(a9, a9))))) return bad("zero test");
+    if (f29::g_check_failure) return 2;
+  }
+  return 0;
+}
+
+// curve level: accumulate n affine points (Montgomery-256 packed, signs in bit 0 of sg[i]) with both arithmetics
+template <class CL>
+static int chain(const typename CL::Old::A* pts, const uint8_t* sg, int n, int form, const typename CL::Old::A* pts_form)
+{
+  typedef typename CL::Old Old;
+  typename Old::X ref = Old::x_zero();
+  typename CL::X acc = CL::x_zero();
+  for (int i = 0; i < n; i++) {
+    typename Old::A p = pts[i];
+    if (sg[i] & 1) p = Old::aff_neg(p);
+    Old::x_madd(ref, p);
+    CL::x_madd(acc, CL::load_affine(pts_form[i], form, sg[i] & 1));
+    if (f29::g_check_failure) return 2;
+    // compare as group elements AND as coordinates (same formulas ⇒ same field values)
+    const typename Old::X got = CL::x_store(acc);
+    if (memcmp(&got, &ref, sizeof got) != 0) {
+      // identical points can differ in representation only after a doubling/cancellation branch; compare projectively
+      typename Old::P a = Old::x_to_projective(got), b = Old::x_to_projective(ref);
+      if (!Old::p_eq(a, b)) return bad("madd chain diverged from ec.h");
+    }
+  }
+  return 0;
+}
+// pts: Montgomery-256 packed affine; pts_form: the same points in the encoding `form` (0 std, 1 mont256, 2 internal)
+extern "C" int f29_check_g1_chain(const void* pts, const uint8_t* sg, int n, int form, const void* pts_form)
+{
+  return chain<G1L>((const G1::A*)pts, sg, n, form, (const G1::A*)pts_form);
+}
+extern "C" int f29_check_g2_chain(const void* pts, const uint8_t* sg, int n, int form, const void* pts_form)
+{
+  return chain<G2L>((const G2::A*)pts, sg, n, form, (const G2::A*)pts_form);
+}
+// encode canonical Montgomery-256 elements into the internal form (packed canonical Montgomery-261)
+extern "C" void f29_to_internal(const fe* in, fe* out, int n)
+{
+  for (int i = 0; i < n; i++) out[i] = f29::pack(f29::canon(f29::from_mont256(in[i])));
+}
