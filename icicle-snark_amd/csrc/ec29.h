@@ -46,6 +46,9 @@ struct Fq29 {
   static FF_HD T sqr_n(const T& a) { return f29::sqr(a); }                        // a N, <12
   static FF_HD T sub3(const T& a, const T& b) { return f29::sub<3, 1>(a, b); }    // a + 3p − b, b N <2
   static FF_HD T norm(const T& a) { return f29::norm(a); }
+  static FF_HD T dbl(const T& a) { return f29::dbl(a); }
+  static FF_HD T tripled(const T& a) { return f29::add(f29::dbl(a), a); }         // a N → limbs < 3·2^29, <6
+  static FF_HD T lt2p(const T& a) { return f29::reduce_lt2p(f29::norm(a)); }      // a <8 → N, <2
   static FF_HD T x3(const T& RR, const T& PPP, const T& Q)                         // RR − PPP − 2Q → N, <2
   {
     return f29::reduce_lt2p(f29::norm(f29::sub<5, 3>(RR, f29::add(PPP, f29::dbl(Q)))));
@@ -87,6 +90,9 @@ struct Fq2_29 {
   }
   static FF_HD T sub3(const T& a, const T& b) { return {f29::sub<3, 1>(a.c0, b.c0), f29::sub<3, 1>(a.c1, b.c1)}; }
   static FF_HD T norm(const T& a) { return {f29::norm(a.c0), f29::norm(a.c1)}; }
+  static FF_HD T dbl(const T& a) { return {f29::dbl(a.c0), f29::dbl(a.c1)}; }
+  static FF_HD T tripled(const T& a) { return {Fq29::tripled(a.c0), Fq29::tripled(a.c1)}; }
+  static FF_HD T lt2p(const T& a) { return {Fq29::lt2p(a.c0), Fq29::lt2p(a.c1)}; }
   static FF_HD T x3(const T& RR, const T& PPP, const T& Q) { return {Fq29::x3(RR.c0, PPP.c0, Q.c0), Fq29::x3(RR.c1, PPP.c1, Q.c1)}; }
   // Y3 = R·D − Y1·PPP, four products per component in one reduction; D is normalised first (column bound 36·2^58)
   static FF_HD T y3(const T& Rn, const T& D, const T& Y1, const T& PPP)
@@ -189,6 +195,62 @@ struct CurveL {
     acc.x = X3;
     acc.zz = F::mul(acc.zz, PP);
     acc.zzz = F::mul(acc.zzz, PPP);
+  }
+
+  // 2·(XYZZ) — EFD dbl-2008-s-1 (a = 0).  U = 2Y (norm: <4), V = U², W = U·V, S = X·V, M = 3X² (reduced to <2),
+  // X3 = M² − 2S, Y3 = M·(S − X3) − W·Y, ZZ3 = V·ZZ, ZZZ3 = W·ZZZ
+  static FF_HD X x_dbl(const X& p)
+  {
+    if (x_is_zero(p)) return p;
+    const T Un = F::norm(F::dbl(p.y));
+    const T V = F::sqr_n(Un);
+    const T W = F::mul(Un, V);
+    const T S = F::mul(p.x, V);
+    const T XX = F::sqr_n(p.x);
+    const T Mn = F::lt2p(F::tripled(XX)); // 3·XX <6, normalised and reduced: N, <2
+    const T MM = F::sqr_n(Mn);
+    const T X3 = F::x3(MM, F::zero(), S);
+    const T D = F::sub3(S, X3);
+    return {X3, F::y3(Mn, D, p.y, W), F::mul(V, p.zz), F::mul(W, p.zzz)};
+  }
+
+  // XYZZ + XYZZ — EFD add-2008-s
+  static FF_HD X x_add(const X& a, const X& b)
+  {
+    if (x_is_zero(a)) return b;
+    if (x_is_zero(b)) return a;
+    const T U1 = F::mul(a.x, b.zz);
+    const T U2 = F::mul(b.x, a.zz);
+    const T S1 = F::mul(a.y, b.zzz);
+    const T S2 = F::mul(b.y, a.zzz);
+    const T Pn = F::norm(F::sub3(U2, U1));
+    const T Rn = F::norm(F::sub3(S2, S1));
+    if (F::maybe_zero(Pn) && F::is_zero_full(Pn)) {
+      if (F::is_zero_full(Rn)) return x_dbl(a);
+      return x_zero();
+    }
+    const T PP = F::sqr_n(Pn);
+    const T PPP = F::mul(Pn, PP);
+    const T Q = F::mul(U1, PP);
+    const T RR = F::sqr_n(Rn);
+    const T X3 = F::x3(RR, PPP, Q);
+    const T D = F::sub3(Q, X3);
+    return {X3, F::y3(Rn, D, S1, PPP), F::mul(F::mul(a.zz, b.zz), PP), F::mul(F::mul(a.zzz, b.zzz), PPP)};
+  }
+
+  // bucket arrays between the accumulation and the reduction kernels hold XYZZ in the internal encoding
+  // (packed canonical Montgomery-261, same 128 / 256 bytes as ec.h's XYZZ; identity = all zero)
+  static FF_HD typename Old::X x_store_internal(const X& p)
+  {
+    if (x_is_zero(p)) return Old::x_zero();
+    return {F::store_internal(p.x), F::store_internal(p.y), F::store_internal(p.zz), F::store_internal(p.zzz)};
+  }
+  static FF_HD X x_load_internal(const typename Old::X& p) { return {F::load_internal(p.x), F::load_internal(p.y), F::load_internal(p.zz), F::load_internal(p.zzz)}; }
+  // ec.h XYZZ (canonical Montgomery-256) → lazy
+  static FF_HD X x_from_old(const typename Old::X& p)
+  {
+    if (Old::x_is_zero(p)) return x_zero();
+    return {F::load_mont256(p.x), F::load_mont256(p.y), F::load_mont256(p.zz), F::load_mont256(p.zzz)};
   }
 
   // lazy affine (N, <16) → packed internal encoding

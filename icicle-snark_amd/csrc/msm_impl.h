@@ -58,7 +58,8 @@ __device__ __forceinline__ fe ld_fe(const fe* p)
 }
 
 // The bucket accumulation runs on the lazy radix-2^29 field (ec29.h): ~1.4× fewer VALU instructions per mixed
-// addition than the 8×32-bit arithmetic of ec.h.  Buckets leave the kernel in the packed XYZZ form of ec.h.
+// addition than the 8×32-bit arithmetic of ec.h.  The bucket array between the accumulation and the reduction
+// kernels holds XYZZ in the internal encoding (packed canonical Montgomery R' = 2^261, same size as ec.h's XYZZ).
 template <class C> struct Lazy;
 template <> struct Lazy<G1> { typedef G1L type; };
 template <> struct Lazy<G2> { typedef G2L type; };
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A
     const typename CL::A p = load_base_lazy<C>(bases, sorted[off + k], skip_below, form, z);
     if (!z) CL::x_madd(acc, p);
   }
-  buckets[b] = CL::x_store(acc);
+  buckets[b] = CL::x_store_internal(acc);
 }
 
 // in-place conversion of an affine base array to the internal encoding (cold path, once per key)
@@ -168,37 +169,57 @@ __global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* 
     typename C::X acc = C::x_zero();
     for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) acc = C::x_add(acc, item_partials[first + k]);
     acc = block_reduce<C>(acc, sh, blockDim.x);
-    if (threadIdx.x == 0) buckets[b] = acc;
+    if (threadIdx.x == 0) buckets[b] = Lazy<C>::type::x_store_internal(Lazy<C>::type::x_from_old(acc)); // bucket array encoding
     __syncthreads();
   }
 }
 
+// tree sum over the workgroup on the lazy field; LDS holds unpacked lazy XYZZ (144 B G1 / 288 B G2 per thread)
+template <class C>
+__device__ __forceinline__ typename Lazy<C>::type::X block_reduce_lazy(typename Lazy<C>::type::X v, typename Lazy<C>::type::X* sh, int nthreads)
+{
+  typedef typename Lazy<C>::type CL;
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = nthreads >> 1; s > 0; s >>= 1) {
+    if (tid < s) {
+      v = CL::x_add(v, sh[tid + s]);
+      sh[tid] = v;
+    }
+    __syncthreads();
+  }
+  return v;
+}
+
 // Σ_b (b+1)·B_b per window.  grid = (blocks per window, W); each thread owns K = 2^k_log buckets.
+// Buckets arrive in the internal encoding; partial sums leave as ec.h XYZZ (Montgomery R = 2^256) for the tails.
 template <class C>
 __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials)
 {
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
-  typedef typename C::X X;
+  X* sh = reinterpret_cast<X*>(smem);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // thread within the window
   const uint32_t base = t << k_log;
-  const X* B = buckets + (size_t)blockIdx.y * NB + base;
-  X line = C::x_zero(), tri = C::x_zero();
+  const typename C::X* B = buckets + (size_t)blockIdx.y * NB + base;
+  X line = CL::x_zero(), tri = CL::x_zero();
   for (int j = (1 << k_log) - 1; j >= 0; j--) {
-    line = C::x_add(line, B[j]);
-    tri = C::x_add(tri, line);
+    line = CL::x_add(line, CL::x_load_internal(B[j]));
+    tri = CL::x_add(tri, line);
   }
   // + base·line  (double-and-add, MSB first)
-  if (base != 0 && !C::x_is_zero(line)) {
-    X m = C::x_zero();
+  if (base != 0 && !CL::x_is_zero(line)) {
+    X m = CL::x_zero();
     for (int bit = 31 - __clz(base); bit >= 0; bit--) {
-      m = C::x_dbl(m);
-      if ((base >> bit) & 1) m = C::x_add(m, line);
+      m = CL::x_dbl(m);
+      if ((base >> bit) & 1) m = CL::x_add(m, line);
     }
-    tri = C::x_add(tri, m);
+    tri = CL::x_add(tri, m);
   }
-  tri = block_reduce<C>(tri, sh, blockDim.x);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tri;
+  tri = block_reduce_lazy<C>(tri, sh, blockDim.x);
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(tri);
 }
 
 // window sums → Horner → projective standard form.  One workgroup of 64 threads.
@@ -361,7 +382,7 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.W), dim3(rs.rblock), rs.rblock * sizeof(X), s, buckets.p, g.NB, rs.k_log, d_partials);
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.W), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NB, rs.k_log, d_partials);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
 }

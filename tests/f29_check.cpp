@@ -71,6 +71,47 @@ static int chain(const typename CL::Old::A* pts, const uint8_t* sg, int n, int f
   }
   return 0;
 }
+// reduction-style use: lazy x_add / x_dbl over partial sums built from the points, against ec.h
+template <class CL>
+static int addtree(const typename CL::Old::A* pts, int n)
+{
+  typedef typename CL::Old Old;
+  if (n < 4) return 0;
+  // partial sums s_i = P_0 + … + P_i in both arithmetics
+  typename Old::X ro = Old::x_zero();
+  typename CL::X rl = CL::x_zero();
+  typename Old::X line_o = Old::x_zero(), tri_o = Old::x_zero();
+  typename CL::X line_l = CL::x_zero(), tri_l = CL::x_zero();
+  for (int i = 0; i < n; i++) {
+    Old::x_madd(ro, pts[i]);
+    CL::x_madd(rl, CL::load_affine(pts[i], 1, false));
+    // running sums like msm_bucket_reduce_kernel, through the internal encoding like the bucket array
+    const typename CL::X b = CL::x_load_internal(CL::x_store_internal(rl));
+    line_o = Old::x_add(line_o, ro);
+    tri_o = Old::x_add(tri_o, line_o);
+    line_l = CL::x_add(line_l, b);
+    tri_l = CL::x_add(tri_l, line_l);
+    if (i % 5 == 4) { // doublings, incl. x_add(a, a) → doubling branch and a + (−a) → identity
+      tri_o = Old::x_dbl(tri_o);
+      tri_l = CL::x_dbl(tri_l);
+      line_o = Old::x_add(line_o, line_o);
+      line_l = CL::x_add(line_l, line_l);
+      const typename Old::X z = Old::x_add(ro, Old::x_neg(ro));
+      typename CL::X nl = CL::x_from_old(Old::x_neg(ro));
+      const typename CL::X zl = CL::x_add(rl, nl);
+      if (!Old::x_is_zero(z) || !CL::x_is_zero(zl)) return bad("a + (−a) is not the identity");
+    }
+    if (f29::g_check_failure) return 2;
+    const typename Old::X got = CL::x_store(tri_l);
+    if (!Old::p_eq(Old::x_to_projective(got), Old::x_to_projective(tri_o))) return bad("x_add/x_dbl diverged from ec.h");
+    const typename Old::X got2 = CL::x_store(CL::x_from_old(tri_o));
+    if (memcmp(&got2, &tri_o, sizeof got2) != 0) return bad("x_from_old/x_store round trip");
+  }
+  return 0;
+}
+extern "C" int f29_check_g1_addtree(const void* pts, int n) { return addtree<G1L>((const G1::A*)pts, n); }
+extern "C" int f29_check_g2_addtree(const void* pts, int n) { return addtree<G2L>((const G2::A*)pts, n); }
+
 // pts: Montgomery-256 packed affine; pts_form: the same points in the encoding `form` (0 std, 1 mont256, 2 internal)
 extern "C" int f29_check_g1_chain(const void* pts, const uint8_t* sg, int n, int form, const void* pts_form)
 {

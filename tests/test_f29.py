@@ -83,3 +83,13 @@ def test_madd_chains_match_ec_and_respect_bounds(chk, O, grp):
         assert fn(_p(mont[40:]), _p(np.zeros(3, dtype=np.uint8)), 3, form, _p(np.ascontiguousarray(enc[40:]))) == 0, chk.f29_last_failure().decode()
         chk.f29_reset()
         assert fn(_p(mont[40:]), _p(np.ones(3, dtype=np.uint8)), 3, form, _p(np.ascontiguousarray(enc[40:]))) == 0, chk.f29_last_failure().decode()
+
+
+@pytest.mark.parametrize("grp", ["g1", "g2"])
+def test_add_dbl_trees_match_ec_and_respect_bounds(chk, O, grp):
+    rnd = random.Random(41)
+    n = 120 if grp == "g1" else 50
+    _, mont = _points(O, grp, [rnd.randrange(1, O.R_MOD) for _ in range(n)])
+    chk.f29_reset()
+    rc = getattr(chk, f"f29_check_{grp}_addtree")(_p(mont), n)
+    assert rc == 0, chk.f29_last_failure().decode()
