@@ -198,7 +198,7 @@ def main():
             "metric": "groth16_prove_constraints_per_s", "value": N / (ms_per_step * 1e-3), "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u256 mod p (8xu32 limbs, Montgomery)", "data": "synthetic",
+            "dtype": "u256 mod p (MSM: 9x29-bit limbs in u32, Montgomery R=2^261, lazy reduction; NTT/QAP: 8xu32 limbs, Montgomery R=2^256)", "data": "synthetic",
             "config": {"workload": f"benchmark/{N // 1000}k squaring chain (BN254, {N} constraints, domain 2^{info.domain_size.bit_length() - 1}), "
                                    "cached zkey, witness resident in HBM, random r/s",
                        "constraints": N, "msm_sharding": f"point-range x{world}" if world > 1 else "none",
@@ -209,11 +209,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
                          "algorithmic_bytes": alg_bytes, "geometry": g,
-                         # the kernel is integer-VALU bound (PMC: VALU active ≈100 % of the launch); its meaningful
-                         # ceiling is the measured Fq multiply rate of ff.h (125 G/s): one XYZZ mixed
-                         # add = 10 field multiplies (one of them fused), L·W adds per launch
-                         "alu": {"achieved_gmul_per_s": g["L"] * g["W"] * 10 / (kern_ms * 1e-3) / 1e9, "peak_gmul_per_s": 125.0,
-                                 "frac": g["L"] * g["W"] * 10 / (kern_ms * 1e-3) / 1e9 / 125.0}},
+                         # the kernel is integer-VALU bound, not HBM bound (PMC: profiles/r01_pmc_msm_g1_2p21_radix29.txt).
+                         # Its ceiling is the issue rate of the 4-cycle multiplier instructions: one XYZZ mixed addition on
+                         # the radix-2^29 field = 1467 v_mad_u64_u32 + 81 v_mul_lo_u32 (csrc/ff29.h, ec29.h), L·W additions per
+                         # launch; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-ops/s (v_mad_u64_u32 measured at 4 cycles
+                         # per wave64, scratch/mulbench4.hip)
+                         "alu": {"achieved_tmad_per_s": g["L"] * g["W"] * 1548 / (kern_ms * 1e-3) / 1e12, "peak_tmad_per_s": 39.3216,
+                                 "frac": g["L"] * g["W"] * 1548 / (kern_ms * 1e-3) / 1e12 / 39.3216}},
         }
         if world == 1 and not args.no_cpu_baseline:
             cm.evict(key)
