@@ -183,7 +183,7 @@ struct ZKeyCache {
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   fe* h_witness = nullptr;      // pinned staging, n_vars
-  hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr;
+  hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
   hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
              ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint64_t device_bytes = 0;
@@ -201,6 +201,7 @@ struct ZKeyCache {
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
     if (h_witness) (void)hipHostFree(h_witness);
+    if (s_qap) (void)icicle_destroy_stream(s_qap);
     if (s_g1) (void)icicle_destroy_stream(s_g1);
     if (s_g2) (void)icicle_destroy_stream(s_g2);
     if (s_g3) (void)icicle_destroy_stream(s_g3);
@@ -448,8 +449,9 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE));
   P_HIP(hipHostMalloc((void**)&z->h_witness, (size_t)z->n_vars * 32));
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
-  // five streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
+  // six streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
   // Stream priorities were tried (QAP chain high, G2 low, …): every variant was 1-2 ms slower than equal priorities.
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_qap)); // QAP front end (its own hardware queue; a higher stream priority made no difference)
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
@@ -629,11 +631,13 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   };
   uint8_t* DP = z->d_partials;
 
-  // ---- stream g1: construct_r1cs (src/proof_helper.rs:31-170) on the device
-  P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, g1));
+  // ---- stream gq: construct_r1cs (src/proof_helper.rs:31-170) on the device
+  hipStream_t gq = z->s_qap;
+  P_HIP(hipStreamWaitEvent(gq, z->ev_witness, 0));
+  P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, gq));
   NTTConfig nc;
   memset(&nc, 0, sizeof nc);
-  nc.stream = g1;
+  nc.stream = gq;
   nc.coset_gen.limbs[0] = 1;
   nc.batch_size = 3;
   nc.ordering = kNN;
@@ -642,10 +646,11 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
   int dom_log = 0;
   const fe* tw = ntt_domain_table(&dom_log);
-  P_HIP(qap_coset_mul3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, g1));                                   // :121-141
+  P_HIP(qap_coset_mul3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, gq));                                   // :121-141
   P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kForward, &nc, (bn254_scalar_t*)z->d_vec)); // :145
-  P_HIP(qap_final(z->d_vec, n, g1));                                                                        // :154-167
-  P_HIP(hipEventRecord(z->ev[2], g1));
+  P_HIP(qap_final(z->d_vec, n, gq));                                                                        // :154-167
+  P_HIP(hipEventRecord(z->ev[2], gq));
+  P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
 
   // ---- stream g2: G2 bucket stages.  Held back until the QAP front end is done: the G2 accumulation
   // fills every CU with ~4 ms workgroups, and the NTT passes of the (longer) g1 chain measured 8× slower

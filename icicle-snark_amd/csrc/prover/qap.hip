@@ -23,21 +23,27 @@ __device__ __forceinline__ void st(fe* p, const fe& v)
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-__device__ __forceinline__ fe row_dot(const fe* w, const uint32_t* rowptr, const uint32_t* cols, const fe* vals, uint32_t row)
-{
-  fe acc = Fr::zero();
-  const uint32_t lo = rowptr[row], hi = rowptr[row + 1];
-  for (uint32_t k = lo; k < hi; k++) acc = Fr::add(acc, Fr::mul(ld(vals + k), ld(w + cols[k]))); // coef·R ⊗ w = coef·w
-  return acc;
-}
-
 __global__ __launch_bounds__(256) void qap_spmv_kernel(const fe* __restrict__ w, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ cols,
                                                         const fe* __restrict__ vals, uint32_t n, fe* __restrict__ d_vec)
 {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
-  fe a = row_dot(w, rowptr, cols, vals, c);
-  fe b = row_dot(w, rowptr, cols, vals, n + c);
+  // rows c (A) and n + c (B) advance in lockstep so that the dependent loads (rowptr → column → witness) of the
+  // two rows are in flight together
+  uint32_t ka = rowptr[c], kb = rowptr[n + c];
+  const uint32_t ha = rowptr[c + 1], hb = rowptr[n + c + 1];
+  fe a = Fr::zero(), b = Fr::zero();
+  while (ka < ha || kb < hb) {
+    const bool da = ka < ha, db = kb < hb;
+    const uint32_t ia = da ? ka : 0u, ib = db ? kb : 0u;
+    const uint32_t ca = cols[ia], cb = cols[ib];
+    const fe va = ld(vals + ia), vb = ld(vals + ib);
+    const fe wa = ld(w + ca), wb = ld(w + cb);
+    if (da) a = Fr::add(a, Fr::mul(va, wa)); // coef·R ⊗ w = coef·w
+    if (db) b = Fr::add(b, Fr::mul(vb, wb));
+    ka++;
+    kb++;
+  }
   st(d_vec + c, b);                  // slot 0 = B   (src/proof_helper.rs:94-96)
   st(d_vec + (size_t)n + c, a);      // slot 1 = A   (:97-99)
   st(d_vec + 2 * (size_t)n + c, Fr::mul(Fr::mul(a, b), Fr::r2())); // slot 2 = A∘B (:108-114)

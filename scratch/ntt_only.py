@@ -1,5 +1,5 @@
 import sys, importlib, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 K = importlib.import_module("icicle-snark_amd")
 K.set_device("HIP", 0)
