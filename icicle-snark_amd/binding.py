@@ -95,6 +95,9 @@ bn254_vector_add bn254_vector_sub bn254_vector_mul bn254_scalar_convert_montgome
 bn254_affine_convert_montgomery bn254_g2_affine_convert_montgomery
 bn254_ntt bn254_ntt_init_domain bn254_ntt_release_domain bn254_get_root_of_unity bn254_get_root_of_unity_from_domain
 bn254_msm bn254_g2_msm bn254_pairing
+bn254_vector_div bn254_vector_accumulate bn254_vector_sum bn254_vector_product bn254_scalar_add_vec bn254_scalar_sub_vec
+bn254_scalar_mul_vec bn254_projective_convert_montgomery bn254_g2_projective_convert_montgomery
+bn254_msm_precompute_bases bn254_g2_msm_precompute_bases
 bn254_pairing_target_field_add bn254_pairing_target_field_sub bn254_pairing_target_field_mul bn254_pairing_target_field_inv
 bn254_pairing_target_field_pow bn254_pairing_target_field_from_u32 bn254_pairing_target_field_generate_scalars
 icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
@@ -254,6 +257,63 @@ def add_scalars(a, b, out=None, stream=None, is_async=False):
     return out
 
 
+def vec_op2(name: str, a, b, n=None, batch_size=1, columns_batch=False, out=None, stream=None, is_async=False):
+    """element-wise a ∘ b for name in add/sub/mul/div over n·batch_size elements (icicle-core vec_ops/mod.rs)"""
+    total = _n_of(a)
+    if out is None:
+        out = np.empty((total, 4), dtype=np.uint64)
+    cfg = VecOpsConfig.default()
+    cfg.is_a_on_device, cfg.is_b_on_device, cfg.is_result_on_device = _on_dev(a), _on_dev(b), _on_dev(out)
+    cfg.is_async, cfg.batch_size, cfg.columns_batch = is_async, batch_size, columns_batch
+    cfg.stream = stream.handle if stream else None
+    n = total // batch_size if n is None else n
+    check(getattr(lib(), "bn254_vector_" + name)(ptr_of(a), ptr_of(b), C.c_uint64(n), C.byref(cfg), ptr_of(out)), name)
+    return out
+
+
+def accumulate_scalars(a, b, stream=None, is_async=False):
+    """a += b in place — vector_accumulate"""
+    cfg = VecOpsConfig.default()
+    cfg.is_a_on_device, cfg.is_b_on_device, cfg.is_result_on_device = _on_dev(a), _on_dev(b), _on_dev(a)
+    cfg.is_async = is_async
+    cfg.stream = stream.handle if stream else None
+    check(lib().bn254_vector_accumulate(ptr_of(a), ptr_of(b), C.c_uint64(_n_of(a)), C.byref(cfg)), "vector_accumulate")
+    return a
+
+
+def scalar_vec_op(name: str, scalars, v, batch_size=1, columns_batch=False, out=None, stream=None, is_async=False):
+    """out(b, i) = scalars[b] ∘ v(b, i) for name in add/sub/mul — scalar_{add,sub,mul}_vec"""
+    total = _n_of(v)
+    if out is None:
+        out = np.empty((total, 4), dtype=np.uint64)
+    cfg = VecOpsConfig.default()
+    cfg.is_a_on_device, cfg.is_b_on_device, cfg.is_result_on_device = _on_dev(scalars), _on_dev(v), _on_dev(out)
+    cfg.is_async, cfg.batch_size, cfg.columns_batch = is_async, batch_size, columns_batch
+    cfg.stream = stream.handle if stream else None
+    check(getattr(lib(), f"bn254_scalar_{name}_vec")(ptr_of(scalars), ptr_of(v), C.c_uint64(total // batch_size), C.byref(cfg), ptr_of(out)), name)
+    return out
+
+
+def reduce_scalars(name: str, v, batch_size=1, columns_batch=False, stream=None, is_async=False):
+    """Σ / Π of every batch vector, name in sum/product → (batch_size, 4) array"""
+    out = np.empty((batch_size, 4), dtype=np.uint64)
+    cfg = VecOpsConfig.default()
+    cfg.is_a_on_device, cfg.is_result_on_device = _on_dev(v), False
+    cfg.is_async, cfg.batch_size, cfg.columns_batch = is_async, batch_size, columns_batch
+    cfg.stream = stream.handle if stream else None
+    check(getattr(lib(), "bn254_vector_" + name)(ptr_of(v), C.c_uint64(_n_of(v) // batch_size), C.byref(cfg), ptr_of(out)), name)
+    return out
+
+
+def projective_convert_montgomery(group: str, a: np.ndarray, to_mont: bool) -> np.ndarray:
+    per = 96 if group == "g1" else 192
+    out = np.empty_like(a)
+    cfg = VecOpsConfig.default()
+    name = "bn254_projective_convert_montgomery" if group == "g1" else "bn254_g2_projective_convert_montgomery"
+    check(getattr(lib(), name)(ptr_of(a), C.c_size_t(a.nbytes // per), C.c_bool(to_mont), C.byref(cfg), ptr_of(out)), name)
+    return out
+
+
 def scalar_convert_montgomery(a, to_mont: bool, out=None, stream=None, is_async=False):
     if out is None:
         out = np.empty_like(a) if isinstance(a, np.ndarray) else a
@@ -295,7 +355,7 @@ def release_domain():
     check(lib().bn254_ntt_release_domain(), "ntt_release_domain")
 
 
-def ntt(inp, inverse: bool, out=None, batch_size=1, size=None, stream=None, is_async=False, coset_gen=None, ordering=0):
+def ntt(inp, inverse: bool, out=None, batch_size=1, size=None, stream=None, is_async=False, coset_gen=None, ordering=0, columns_batch=False):
     if size is None:
         size = _n_of(inp) // batch_size
     if out is None:
@@ -305,6 +365,7 @@ def ntt(inp, inverse: bool, out=None, batch_size=1, size=None, stream=None, is_a
     cfg.are_inputs_on_device, cfg.are_outputs_on_device = _on_dev(inp), _on_dev(out)
     cfg.is_async = is_async
     cfg.ordering = ordering
+    cfg.columns_batch = columns_batch
     cfg.stream = stream.handle if stream else None
     if coset_gen is not None:
         cg = np.ascontiguousarray(coset_gen, dtype=np.uint64).view(np.uint32)
@@ -316,15 +377,16 @@ def ntt(inp, inverse: bool, out=None, batch_size=1, size=None, stream=None, is_a
 
 # --------------------------------------------------------------------------------------------- MSM
 def msm(group: str, scalars, bases, out=None, stream=None, is_async=False, c=0, size=None,
-        scalars_mont=False, points_mont=False, ext=None):
+        scalars_mont=False, points_mont=False, ext=None, batch_size=1, shared_points=True, precompute_factor=1):
     """msm() — icicle-core/src/msm/mod.rs:106-154. Returns the projective result (3,4)/(6,4) u64 when `out` is None."""
     if size is None:
-        size = _n_of(scalars)
+        size = _n_of(scalars) // batch_size
     host_out = out is None
     if host_out:
-        out = np.zeros((3, 4) if group == "g1" else (6, 4), dtype=np.uint64)
+        out = np.zeros(((3, 4) if group == "g1" else (6, 4)) if batch_size == 1 else ((batch_size, 3, 4) if group == "g1" else (batch_size, 6, 4)), dtype=np.uint64)
     cfg = MSMConfig.default()
     cfg.c = c
+    cfg.batch_size, cfg.are_points_shared_in_batch, cfg.precompute_factor = batch_size, shared_points, precompute_factor
     cfg.are_scalars_on_device, cfg.are_points_on_device, cfg.are_results_on_device = _on_dev(scalars), _on_dev(bases), _on_dev(out)
     cfg.are_scalars_montgomery_form, cfg.are_points_montgomery_form = scalars_mont, points_mont
     cfg.is_async = is_async
@@ -332,6 +394,18 @@ def msm(group: str, scalars, bases, out=None, stream=None, is_async=False, c=0, 
     cfg.ext = ext
     name = "bn254_msm" if group == "g1" else "bn254_g2_msm"
     check(getattr(lib(), name)(ptr_of(scalars), ptr_of(bases), C.c_int(size), C.byref(cfg), ptr_of(out)), name)
+    return out
+
+
+def msm_precompute_bases(group: str, bases: np.ndarray, precompute_factor: int, c=0, points_mont=False) -> np.ndarray:
+    """msm_precompute_bases — icicle-core/src/msm/mod.rs:156-190 (host arrays in and out)"""
+    per = 64 if group == "g1" else 128
+    n = bases.nbytes // per
+    out = np.empty((n * precompute_factor,) + bases.shape[1:], dtype=np.uint64)
+    cfg = MSMConfig.default()
+    cfg.c, cfg.precompute_factor, cfg.are_points_montgomery_form = c, precompute_factor, points_mont
+    name = "bn254_msm_precompute_bases" if group == "g1" else "bn254_g2_msm_precompute_bases"
+    check(getattr(lib(), name)(ptr_of(np.ascontiguousarray(bases)), C.c_int(n), C.byref(cfg), ptr_of(out)), name)
     return out
 
 

@@ -13,7 +13,7 @@ size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bp
 }
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof)
 {
-  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, s, (G1::X*)d_partials, prof);
+  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, 1, s, (G1::X*)d_partials, prof);
 }
 eIcicleError msm_g1_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G1>(d_points, n, from_form, s); }
 void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out)
@@ -26,6 +26,10 @@ void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, b
 ISNARK_API eIcicleError bn254_msm(const bn254_scalar_t* scalars, const bn254_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_projective_t* results)
 {
   return msm_impl<G1>(scalars, bases, msm_size, cfg, results);
+}
+ISNARK_API eIcicleError bn254_msm_precompute_bases(const bn254_affine_t* bases, int nof_bases, const MSMConfig* cfg, bn254_affine_t* out)
+{
+  return precompute_impl<G1, FqOps>(bases, nof_bases, cfg, out);
 }
 ISNARK_API eIcicleError icicle_snark_last_msm_timings(float out_ms[4])
 {

@@ -5,7 +5,7 @@
 namespace isnark {
 eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof)
 {
-  return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, s, (G2::X*)d_partials, prof);
+  return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, 1, s, (G2::X*)d_partials, prof);
 }
 eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G2>(d_points, n, from_form, s); }
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out)
@@ -18,6 +18,10 @@ void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, b
 ISNARK_API eIcicleError bn254_g2_msm(const bn254_scalar_t* scalars, const bn254_g2_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_g2_projective_t* results)
 {
   return msm_impl<G2>(scalars, bases, msm_size, cfg, results);
+}
+ISNARK_API eIcicleError bn254_g2_msm_precompute_bases(const bn254_g2_affine_t* bases, int nof_bases, const MSMConfig* cfg, bn254_g2_affine_t* out)
+{
+  return precompute_impl<G2, Fq2Ops>(bases, nof_bases, cfg, out);
 }
 ISNARK_API eIcicleError icicle_snark_g2_generator_mul(const bn254_scalar_t* s, uint64_t n, icicleStreamHandle stream, bn254_g2_affine_t* out)
 {

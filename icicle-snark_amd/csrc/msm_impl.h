@@ -70,23 +70,23 @@ template <> struct Lazy<G2> { typedef G2L type; };
 // `form`: encoding of the affine bases in memory — 0 standard, 1 Montgomery R = 2^256 (zkey files), 2 internal
 // (packed canonical Montgomery R' = 2^261, produced once by msm_points_to_internal; no per-load conversion)
 template <class C>
-__device__ __forceinline__ typename C::A fetch_base(const typename C::A* bases, uint32_t e, uint32_t skip_below)
+__device__ __forceinline__ typename C::A fetch_base(const typename C::A* bases, uint32_t e, uint32_t skip_below, uint32_t stride)
 {
   const uint32_t idx = e & 0x7fffffffu;
-  return bases[idx < skip_below ? 0u : idx - skip_below]; // entries below skip_below are ignored by the caller
+  return bases[(size_t)(idx < skip_below ? 0u : idx - skip_below) * stride]; // entries below skip_below are ignored by the caller
 }
 template <class C>
-__device__ __forceinline__ typename Lazy<C>::type::A load_base_lazy(const typename C::A* bases, uint32_t e, uint32_t skip_below, int form, bool& is_zero)
+__device__ __forceinline__ typename Lazy<C>::type::A load_base_lazy(const typename C::A* bases, uint32_t e, uint32_t skip_below, uint32_t stride, int form, bool& is_zero)
 {
   typedef typename Lazy<C>::type CL;
-  const typename C::A p = fetch_base<C>(bases, e, skip_below);
+  const typename C::A p = fetch_base<C>(bases, e, skip_below, stride);
   is_zero = (e & 0x7fffffffu) < skip_below || C::aff_is_zero(p); // scalar outside this base set (C MSM), or the identity
   return CL::load_affine(p, form, (e >> 31) != 0);
 }
 
 template <class C>
 __global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, int form,
+                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, uint32_t stride, int form,
                                                               typename C::X* __restrict__ buckets)
 {
   typedef typename Lazy<C>::type CL;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(cons
       const uint32_t e = e_nxt;
       if (k + 1 < cnt) e_nxt = idx[k + 1];
       bool z;
-      const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, form, z);
+      const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, stride, form, z);
       if (!z) CL::x_madd(acc, p);
     }
   } else {
@@ -112,12 +112,12 @@ __global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(cons
     // flight while the current mixed addition (~9 k cycles per wave) runs; without it every iteration starts with two
     // dependent memory latencies (H accumulation alone: 4.0 → 3.0 ms)
     uint32_t e_cur = cnt ? idx[0] : 0u, e_nxt = cnt > 1 ? idx[1] : 0u;
-    typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below);
+    typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride);
     for (uint32_t k = 0; k < cnt; k++) {
       const typename C::A pk = pk_cur;
       const uint32_t e = e_cur;
       e_cur = e_nxt;
-      if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below);
+      if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride);
       if (k + 2 < cnt) e_nxt = idx[k + 2];
       const bool z = (e & 0x7fffffffu) < skip_below || C::aff_is_zero(pk);
       if (!z) CL::x_madd(acc, CL::load_affine(pk, form, (e >> 31) != 0));
@@ -159,7 +159,7 @@ __device__ __forceinline__ typename C::X block_reduce(typename C::X v, typename 
 template <class C>
 __global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                                     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint2* __restrict__ items, uint32_t item_cap,
-                                                                    uint32_t skip_below, int pts_mont, typename C::X* __restrict__ item_partials)
+                                                                    uint32_t skip_below, uint32_t stride, int pts_mont, typename C::X* __restrict__ item_partials)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typenam
     typename CL::X lacc = CL::x_zero();
     for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
       bool z;
-      const typename CL::A p = load_base_lazy<C>(bases, sorted[k], skip_below, pts_mont, z);
+      const typename CL::A p = load_base_lazy<C>(bases, sorted[k], skip_below, stride, pts_mont, z);
       if (!z) CL::x_madd(lacc, p);
     }
     typename C::X acc = block_reduce<C>(CL::x_store(lacc), sh, blockDim.x);
@@ -357,17 +357,17 @@ eIcicleError points_to_internal_run(void* d_points, uint32_t n, int from_form, h
 // (msm_g2_acc.hip, Fq2 arithmetic inlined)
 template <class C>
 struct AccumulateLauncher {
-  static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, hipStream_t s, typename C::X* buckets)
+  static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets)
   {
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, mont_pt, buckets);
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, mont_pt, buckets);
   }
 };
 #if defined(ISNARK_G2_ACC_EXTERN)
 template <>
 struct AccumulateLauncher<G2> {
-  static void launch(const SortPlan* pl, const G2::A* d_points, int mont_pt, uint32_t skip_below, hipStream_t s, G2::X* buckets)
+  static void launch(const SortPlan* pl, const G2::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, G2::X* buckets)
   {
-    isnark::msm_g2_accumulate_launch(pl, d_points, mont_pt, skip_below, s, buckets);
+    isnark::msm_g2_accumulate_launch(pl, d_points, mont_pt, skip_below, stride, s, buckets);
   }
 };
 #endif
@@ -390,7 +390,7 @@ ReduceShape reduce_shape(const MsmGeom& g)
 
 // stages 4, 4b, 5 for one base set
 template <class C>
-eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, hipStream_t s, typename C::X* d_partials, MsmProfile* prof)
+eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof)
 {
   typedef typename C::X X;
   const MsmGeom& g = pl->g;
@@ -398,12 +398,12 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   WsScoped<X> buckets, item_partials;
   HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);
-  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, s, buckets.p);
+  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
   HIP_TRY(item_partials.alloc(pl->item_cap, s), ICICLE_ALLOCATION_FAILED);
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, mont_pt, item_partials.p);
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, mont_pt, item_partials.p);
   hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
@@ -427,7 +427,12 @@ typename C::P msm_host_tail(const typename C::X* part, uint32_t W, uint32_t bpw,
   return C::p_from_mont(C::x_to_projective(acc));
 }
 
-// the extern "C" entry (bn254_msm / bn254_g2_msm): sort + bucket stages + device tail
+// the extern "C" entry (bn254_msm / bn254_g2_msm): sort + bucket stages + device tail.
+// batch_size > 1 (msm.h:21-53): `batch_size` scalar vectors of msm_size elements, one result each; the bases are
+// shared (are_points_shared_in_batch) or one set per batch element.  The batch elements run back to back on the
+// caller's stream.  precompute_factor f > 1: `bases` came from msm_precompute_bases and holds f points per original
+// base, [f·i] being the base itself; this backend reads only those (stride f) — the extra multiples trade memory for a
+// cheaper bucket reduction in the reference's backends, which is not where the time goes here.
 template <class C, class AT, class PT>
 eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_size, const MSMConfig* cfg, PT* results)
 {
@@ -436,50 +441,114 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   typedef typename C::P P;
   static_assert(sizeof(A) == sizeof(AT) && sizeof(P) == sizeof(PT), "ABI layout");
   if (!cfg || !results || (msm_size > 0 && (!scalars || !bases))) return ICICLE_INVALID_POINTER;
-  if (msm_size < 0) return ICICLE_INVALID_ARGUMENT;
-  if (cfg->batch_size > 1 || cfg->precompute_factor > 1) {
-    set_last_error("msm: batch_size > 1 / precompute_factor > 1 are not implemented");
-    return ICICLE_API_NOT_IMPLEMENTED;
-  }
+  if (msm_size < 0 || cfg->batch_size < 0 || cfg->precompute_factor < 0) return ICICLE_INVALID_ARGUMENT;
   ICICLE_TRY(require_device());
   hipStream_t s = (hipStream_t)cfg->stream;
   const uint32_t L = (uint32_t)msm_size;
+  const uint32_t batch = cfg->batch_size > 1 ? (uint32_t)cfg->batch_size : 1;
+  const uint32_t stride = cfg->precompute_factor > 1 ? (uint32_t)cfg->precompute_factor : 1;
+  const bool shared = cfg->are_points_shared_in_batch || batch == 1;
   const bool profile = getenv("ICICLE_SNARK_PROFILE") != nullptr;
 
   Staged ss, sb, sr;
-  ICICLE_TRY(ss.in(scalars, (size_t)L * sizeof(fe), cfg->are_scalars_on_device, s));
-  ICICLE_TRY(sb.in(bases, (size_t)L * sizeof(A), cfg->are_points_on_device, s));
-  ICICLE_TRY(sr.out(results, sizeof(P), cfg->are_results_on_device, s));
+  ICICLE_TRY(ss.in(scalars, (size_t)L * batch * sizeof(fe), cfg->are_scalars_on_device, s));
+  ICICLE_TRY(sb.in(bases, (size_t)L * stride * (shared ? 1 : batch) * sizeof(A), cfg->are_points_on_device, s));
+  ICICLE_TRY(sr.out(results, (size_t)batch * sizeof(P), cfg->are_results_on_device, s));
 
   int lbf = 10;
   ext_get_int(cfg->ext, "large_bucket_factor", &lbf);
-  MsmProfile* prof = msm_profile_next();
-  SortPlan pl;
-  (void)hipEventRecord(prof->ev[0], s);
-  ICICLE_TRY(msm_sort_run(ss.ptr<fe>(), L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl));
-  prof->L = L;
-  prof->nbuckets = pl.nbuckets;
-  prof->c = pl.g.c;
-  prof->W = pl.g.W;
-  prof->is_g2 = sizeof(A) > 64;
-  const ReduceShape rs = reduce_shape<X>(pl.g);
-  WsScoped<X> partials;
-  HIP_TRY(partials.alloc((size_t)pl.g.W * rs.bpw, s), ICICLE_ALLOCATION_FAILED);
-  ICICLE_TRY(msm_buckets_run<C>(&pl, sb.ptr<A>(), cfg->are_points_montgomery_form, 0, s, partials.p, prof));
-  hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, (int)rs.bpw, pl.g.c, sr.ptr<P>());
-  ICICLE_TRY(check_launch("msm_tail"));
-  (void)hipEventRecord(prof->ev[3], s);
-  prof->valid = true;
-  partials.release();
-  msm_sort_release(&pl);
+  MsmProfile* prof = nullptr;
+  for (uint32_t bi = 0; bi < batch; bi++) {
+    prof = msm_profile_next();
+    SortPlan pl;
+    (void)hipEventRecord(prof->ev[0], s);
+    ICICLE_TRY(msm_sort_run(ss.ptr<fe>() + (size_t)bi * L, L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl));
+    prof->L = L;
+    prof->nbuckets = pl.nbuckets;
+    prof->c = pl.g.c;
+    prof->W = pl.g.W;
+    prof->is_g2 = sizeof(A) > 64;
+    const ReduceShape rs = reduce_shape<X>(pl.g);
+    WsScoped<X> partials;
+    HIP_TRY(partials.alloc((size_t)pl.g.W * rs.bpw, s), ICICLE_ALLOCATION_FAILED);
+    const A* pts = sb.ptr<A>() + (shared ? 0 : (size_t)bi * L * stride);
+    ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, stride, s, partials.p, prof));
+    hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, (int)rs.bpw, pl.g.c, sr.ptr<P>() + bi);
+    ICICLE_TRY(check_launch("msm_tail"));
+    (void)hipEventRecord(prof->ev[3], s);
+    prof->valid = true;
+  }
   ICICLE_TRY(sr.finish());
-  if (profile) {
+  if (profile && prof) {
     HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
     (void)hipEventElapsedTime(&g_last_msm_ms[0], prof->ev[0], prof->ev[1]);
     (void)hipEventElapsedTime(&g_last_msm_ms[1], prof->ev[1], prof->ev[2]);
     (void)hipEventElapsedTime(&g_last_msm_ms[2], prof->ev[2], prof->ev[3]);
     (void)hipEventElapsedTime(&g_last_msm_ms[3], prof->ev[0], prof->ev[3]);
   }
+  return end_call(s, cfg->is_async);
+}
+
+// msm_precompute_bases (msm.h, icicle/src/msm.cpp:45-72): output[f·i + j] = 2^(j·shift)·P_i, j < f, with
+// shift = c·⌈W / f⌉ for this backend's window geometry of an MSM of nof_bases elements (cfg->c if given).
+// Input and output honour are_points_montgomery_form / are_points_on_device (the output flag is are_results_on_device).
+template <class C>
+__global__ __launch_bounds__(256) void precompute_kernel(const typename C::A* __restrict__ in, uint32_t n, int f, int shift, int mont, typename C::P* __restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  typename C::A a = in[i];
+  const bool zero = C::aff_is_zero(a);
+  if (!mont) a = C::aff_to_mont(a);
+  typename C::X x = zero ? C::x_zero() : C::x_from_affine(a);
+  for (int j = 0; j < f; j++) {
+    out[(size_t)i * f + j] = C::x_to_projective(x); // Montgomery projective; identity → (0, 1, 0)
+    if (j + 1 < f)
+      for (int k = 0; k < shift; k++) x = C::x_dbl(x);
+  }
+}
+template <class A>
+__global__ __launch_bounds__(256) void affine_to_mont_kernel(A* pts, uint64_t ncoord)
+{
+  fe* c = reinterpret_cast<fe*>(pts);
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncoord) c[i] = Fq::to_mont(c[i]);
+}
+template <class C, class F, class AT>
+eIcicleError precompute_impl(const AT* bases, int nof_bases, const MSMConfig* cfg, AT* out)
+{
+  typedef typename C::A A;
+  typedef typename C::P P;
+  if (!cfg || (nof_bases > 0 && (!bases || !out))) return ICICLE_INVALID_POINTER;
+  if (nof_bases < 0) return ICICLE_INVALID_ARGUMENT;
+  ICICLE_TRY(require_device());
+  const int f = cfg->precompute_factor > 1 ? cfg->precompute_factor : 1;
+  const uint32_t n = (uint32_t)nof_bases;
+  hipStream_t s = (hipStream_t)cfg->stream;
+  Staged sb, so;
+  ICICLE_TRY(sb.in(bases, (size_t)n * sizeof(A), cfg->are_points_on_device, s));
+  ICICLE_TRY(so.out(out, (size_t)n * f * sizeof(A), cfg->are_results_on_device, s));
+  if (n) {
+    const MsmGeom g = msm_geometry(n, cfg->c);
+    const int shift = g.c * ((g.W + f - 1) / f);
+    const uint64_t m = (uint64_t)n * f;
+    WsScoped<P> proj;
+    WsScoped<typename F::T> scratch;
+    HIP_TRY(proj.alloc(m, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(scratch.alloc(m, s), ICICLE_ALLOCATION_FAILED);
+    hipLaunchKernelGGL((precompute_kernel<C>), dim3((n + 255) / 256), dim3(256), 0, s, sb.ptr<A>(), n, f, shift, cfg->are_points_montgomery_form ? 1 : 0, proj.p);
+    ICICLE_TRY(check_launch("msm_precompute"));
+    const int chunk = 32;
+    const uint64_t nthreads = (m + chunk - 1) / chunk;
+    hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, proj.p, m, chunk, so.ptr<A>(), scratch.p);
+    ICICLE_TRY(check_launch("batch_to_affine"));
+    if (cfg->are_points_montgomery_form) {
+      const uint64_t nc = m * (sizeof(A) / sizeof(fe));
+      hipLaunchKernelGGL((affine_to_mont_kernel<A>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, so.ptr<A>(), nc);
+      ICICLE_TRY(check_launch("affine_to_mont"));
+    }
+  }
+  ICICLE_TRY(so.finish());
   return end_call(s, cfg->is_async);
 }
 

@@ -75,7 +75,7 @@ void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, b
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out);
 
 // G2 bucket accumulation, compiled with inlined Fq2 arithmetic (msm_g2_acc.hip)
-void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* buckets);
+void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, uint32_t stride, hipStream_t s, void* buckets);
 
 bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
 bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);

@@ -301,6 +301,19 @@ __global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ 
   }
 }
 
+// natural row-major (b·n + i)  ↔  caller layout (bit-reversed index and/or columns_batch).  scatter = 0: out[b·n + i] =
+// in[caller(b, i)] ; scatter = 1: out[caller(b, i)] = in[b·n + i]
+__global__ __launch_bounds__(256) void relayout_kernel(const fe* __restrict__ in, fe* __restrict__ out, uint64_t n, int batch, int logn, int rev, int cols, int scatter)
+{
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * (uint64_t)batch) return;
+  const uint64_t b = t / n, i = t % n;
+  const uint64_t j = rev ? (logn ? (uint64_t)(__brevll(i) >> (64 - logn)) : 0) : i;
+  const uint64_t c = cols ? b + j * (uint64_t)batch : b * n + j;
+  if (scatter) g_put(out + c, g_get(in + t));
+  else g_put(out + t, g_get(in + c));
+}
+
 // coset pre/post multiplication x[j] *= g^(±j) (NTTConfig.coset_gen ≠ 1)
 __global__ void coset_mul_kernel(fe* data, uint64_t n, int batch, const fe* gpow2 /* g^(±2^j), Montgomery */, int logn)
 {
@@ -427,14 +440,16 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
     set_last_error("ntt: size %d is not a power of two", size);
     return ICICLE_INVALID_ARGUMENT;
   }
-  if (cfg->ordering != kNN) {
-    set_last_error("ntt: only Ordering::kNN is implemented");
-    return ICICLE_API_NOT_IMPLEMENTED;
+  if ((int)cfg->ordering < (int)kNN || (int)cfg->ordering > (int)kMN) {
+    set_last_error("ntt: unknown ordering %d", (int)cfg->ordering);
+    return ICICLE_INVALID_ARGUMENT;
   }
-  if (cfg->columns_batch) {
-    set_last_error("ntt: columns_batch is not implemented");
-    return ICICLE_API_NOT_IMPLEMENTED;
-  }
+  // Orderings (icicle/include/icicle/ntt.h:32-43): the transform itself runs natural → natural; bit-reversed inputs /
+  // outputs and the columns_batch layout (element i of batch b at b + i·batch) are handled by one re-layout pass on
+  // either side.  kNM / kMN ("mixed" digit order, defined by the CUDA backend's radix plan) are taken as kNR / kRN,
+  // exactly as the reference's radix-2 CPU backend does (ntt.h:32).
+  const bool rev_in = cfg->ordering == kRN || cfg->ordering == kRR || cfg->ordering == kMN;
+  const bool rev_out = cfg->ordering == kNR || cfg->ordering == kRR || cfg->ordering == kNM;
   ICICLE_TRY(require_device());
   const int logn = ilog2((uint64_t)size);
   Domain dom;
@@ -456,7 +471,20 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
   ICICLE_TRY(sin.in(input, total * sizeof(fe), cfg->are_inputs_on_device, s));
   ICICLE_TRY(sout.out(output, total * sizeof(fe), cfg->are_outputs_on_device, s));
   const fe* d_in = sin.ptr<fe>();
-  fe* d_out = sout.ptr<fe>();
+  fe* d_final = sout.ptr<fe>();
+  const bool cols = cfg->columns_batch && batch > 1;
+  WsScoped<fe> pre_block, post_block;
+  if (rev_in || cols) {
+    HIP_TRY(pre_block.alloc(total, s), ICICLE_ALLOCATION_FAILED);
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_in, pre_block.p, n, batch, logn, rev_in ? 1 : 0, cols ? 1 : 0, 0);
+    ICICLE_TRY(check_launch("ntt_relayout_in"));
+    d_in = pre_block.p;
+  }
+  fe* d_out = d_final;
+  if (rev_out || cols) {
+    HIP_TRY(post_block.alloc(total, s), ICICLE_ALLOCATION_FAILED);
+    d_out = post_block.p;
+  }
 
   // coset generator (NTTConfig.coset_gen): forward evaluates on g·H (x_j *= g^j first), inverse
   // interpolates from g·H (multiply by g^-j afterwards) — ntt.h:52-64, mixed_radix_ntt.cu:911-1017.
@@ -564,6 +592,12 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
     hipLaunchKernelGGL(coset_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_out, n, batch, d_gpow, logn);
     ICICLE_TRY(check_launch("coset_mul"));
   }
+  if (rev_out || cols) {
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_out, d_final, n, batch, logn, rev_out ? 1 : 0, cols ? 1 : 0, 1);
+    ICICLE_TRY(check_launch("ntt_relayout_out"));
+  }
+  pre_block.release();
+  post_block.release();
   scratch_block.release();
   if (d_gpow) {
     HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);

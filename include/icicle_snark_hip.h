@@ -210,11 +210,23 @@ void bn254_pairing_target_field_generate_scalars(bn254_fq12_t* out, int size);
 eIcicleError bn254_vector_add(const bn254_scalar_t* a, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
 eIcicleError bn254_vector_sub(const bn254_scalar_t* a, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
 eIcicleError bn254_vector_mul(const bn254_scalar_t* a, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
+/* remaining vec ops of the wrapper crate: icicle/src/vec_ops.cpp:9-34 (Σ, Π per batch vector), :55-65 (a += b),
+ * :102-113 (a·b⁻¹, inverse(0) = 0), :118-161 (scalar[b] ∘ vector(b, ·)); batch layout per VecOpsConfig.columns_batch */
+eIcicleError bn254_vector_div(const bn254_scalar_t* a, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
+eIcicleError bn254_vector_accumulate(bn254_scalar_t* a, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg);
+eIcicleError bn254_vector_sum(const bn254_scalar_t* a, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
+eIcicleError bn254_vector_product(const bn254_scalar_t* a, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
+eIcicleError bn254_scalar_add_vec(const bn254_scalar_t* scalar, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
+eIcicleError bn254_scalar_sub_vec(const bn254_scalar_t* scalar, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
+eIcicleError bn254_scalar_mul_vec(const bn254_scalar_t* scalar, const bn254_scalar_t* b, uint64_t n, const VecOpsConfig* cfg, bn254_scalar_t* out);
 eIcicleError bn254_scalar_convert_montgomery(const bn254_scalar_t* in, uint64_t n, bool is_to_montgomery, const VecOpsConfig* cfg, bn254_scalar_t* out);
 
 /* ---- Montgomery conversion of points: icicle/src/curves/montgomery_conversion.cpp:13-33 ---- */
 eIcicleError bn254_affine_convert_montgomery(const bn254_affine_t* in, uint64_t n, bool is_into, const VecOpsConfig* cfg, bn254_affine_t* out);
 eIcicleError bn254_g2_affine_convert_montgomery(const bn254_g2_affine_t* in, size_t n, bool is_into, const VecOpsConfig* cfg, bn254_g2_affine_t* out);
+/* icicle/src/curves/montgomery_conversion.cpp:47-74 */
+eIcicleError bn254_projective_convert_montgomery(const bn254_projective_t* in, size_t n, bool is_into, const VecOpsConfig* cfg, bn254_projective_t* out);
+eIcicleError bn254_g2_projective_convert_montgomery(const bn254_g2_projective_t* in, size_t n, bool is_into, const VecOpsConfig* cfg, bn254_g2_projective_t* out);
 
 /* ---- NTT: icicle/src/ntt.cpp:10-63 (CUDA: ntt.cuh:441-758, mixed_radix_ntt.cu) ---- */
 eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir dir, const NTTConfig* cfg, bn254_scalar_t* output);
@@ -226,6 +238,10 @@ eIcicleError bn254_get_root_of_unity_from_domain(uint64_t logn, bn254_scalar_t* 
 /* ---- MSM: icicle/src/msm.cpp:12-32 (CUDA: cuda_msm.cuh:960-1443) ---- */
 eIcicleError bn254_msm(const bn254_scalar_t* scalars, const bn254_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_projective_t* results);
 eIcicleError bn254_g2_msm(const bn254_scalar_t* scalars, const bn254_g2_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_g2_projective_t* results);
+/* icicle/src/msm.cpp:45-72: output[f·i + j] = 2^(j·shift)·P_i for f = cfg->precompute_factor; pass the result as `bases`
+ * of an MSM with the same precompute_factor (and c).  Output residency: cfg->are_results_on_device. */
+eIcicleError bn254_msm_precompute_bases(const bn254_affine_t* bases, int nof_bases, const MSMConfig* cfg, bn254_affine_t* output_bases);
+eIcicleError bn254_g2_msm_precompute_bases(const bn254_g2_affine_t* bases, int nof_bases, const MSMConfig* cfg, bn254_g2_affine_t* output_bases);
 
 /* ------------------------------------------------------------------------------------------------
  * Extensions (not in the reference; prefixed icicle_snark_).  Used by this repository's own prover
