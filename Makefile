@@ -9,7 +9,7 @@ LIBDIR  := $(PKG)/lib
 OBJDIR  := build/obj
 CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -Iinclude -I$(SRC) -Wno-unused-result
 
-SRCS := $(SRC)/runtime.cpp $(SRC)/host_ffi.cpp $(SRC)/vec_ops.hip $(SRC)/ntt.hip $(SRC)/msm_sort.hip $(SRC)/msm_g1.hip $(SRC)/msm_g2.hip $(SRC)/msm_g2_acc.hip $(wildcard $(SRC)/prover/*.cpp) $(wildcard $(SRC)/prover/*.hip)
+SRCS := $(SRC)/runtime.cpp $(SRC)/host_ffi.cpp $(SRC)/vec_ops.hip $(SRC)/ntt.hip $(SRC)/msm_sort.hip $(SRC)/msm_g1.hip $(SRC)/msm_g2.hip $(SRC)/msm_g2_acc.hip $(SRC)/microbench.hip $(wildcard $(SRC)/prover/*.cpp) $(wildcard $(SRC)/prover/*.hip)
 OBJS := $(patsubst $(SRC)/%,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(SRC)/*.h) $(wildcard $(SRC)/prover/*.h) include/icicle_snark_hip.h $(wildcard include/*.h)
 

@@ -203,6 +203,8 @@ def main():
         skew_ms = (time.perf_counter() - t2) * 1e3 / 3
         cm.prove_mem(key, wtns)   # restore the resident witness
 
+    hbm_copy_gbps, mad_tops = K.microbench() if rank == 0 else (None, None)
+
     out = None
     if rank == 0:
         g = acc_geom[0]
@@ -242,7 +244,12 @@ def main():
                          # launch; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-ops/s (v_mad_u64_u32 measured at 4 cycles
                          # per wave64, scratch/mulbench4.hip)
                          "alu": {"achieved_tmad_per_s": g["L"] * g["W"] * 1548 / (kern_ms * 1e-3) / 1e12, "peak_tmad_per_s": 39.3216,
-                                 "frac": g["L"] * g["W"] * 1548 / (kern_ms * 1e-3) / 1e12 / 39.3216}},
+                                 "frac": g["L"] * g["W"] * 1548 / (kern_ms * 1e-3) / 1e12 / 39.3216,
+                                 # measured on this box in this run (csrc/microbench.hip): eight independent v_mad_u64_u32 chains per lane
+                                 "measured_peak_tmad_per_s": mad_tops,
+                                 "frac_of_measured": g["L"] * g["W"] * 1548 / (kern_ms * 1e-3) / 1e12 / mad_tops},
+                         # device-to-device copy rate (read + write bytes) measured in this run: the practical HBM ceiling
+                         "hbm_copy_gbps_measured": hbm_copy_gbps, "frac_of_measured_copy": achieved / hbm_copy_gbps},
         }
         if world == 1 and not args.no_cpu_baseline:
             cm.evict(key)

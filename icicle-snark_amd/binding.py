@@ -101,7 +101,7 @@ bn254_msm_precompute_bases bn254_g2_msm_precompute_bases
 bn254_pairing_target_field_add bn254_pairing_target_field_sub bn254_pairing_target_field_mul bn254_pairing_target_field_inv
 bn254_pairing_target_field_pow bn254_pairing_target_field_from_u32 bn254_pairing_target_field_generate_scalars
 icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
-icicle_snark_msm_profile
+icicle_snark_msm_profile icicle_snark_microbench
 """.split()
 
 _lib = None
@@ -421,6 +421,13 @@ def msm_profile(back: int = 0):
     geom = (C.c_uint32 * 5)()
     check(lib().icicle_snark_msm_profile(back, ms, geom), "msm_profile")
     return list(ms), dict(L=geom[0], nbuckets=geom[1], c=geom[2], W=geom[3], is_g2=bool(geom[4]))
+
+
+def microbench():
+    """(device-to-device copy GB/s counting read + write, v_mad_u64_u32 lane-ops/s in 10^12) measured now"""
+    out = (C.c_double * 2)()
+    check(lib().icicle_snark_microbench(out), "microbench")
+    return float(out[0]), float(out[1])
 
 
 def generator_mul(group: str, scalars: np.ndarray) -> np.ndarray:
