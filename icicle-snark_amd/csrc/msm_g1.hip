@@ -7,13 +7,22 @@ thread_local float g_last_msm_ms[4] = {0, 0, 0, 0};
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bpw)
 {
   const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g) : reduce_shape<G1::X>(pl->g);
-  if (W) *W = (uint32_t)pl->g.W;
+  if (W) *W = (uint32_t)pl->g.Wb;
   if (bpw) *bpw = rs.bpw;
-  return (size_t)pl->g.W * rs.bpw * (g2 ? sizeof(G2::X) : sizeof(G1::X));
+  return (size_t)pl->g.Wb * rs.bpw * (g2 ? sizeof(G2::X) : sizeof(G1::X)) * (pl->g.tab ? 2 : 1);
 }
-eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof)
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len)
 {
-  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, 1, s, (G1::X*)d_partials, prof);
+  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_partials, prof);
+}
+eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
+{
+  return build_table_run<G1, FqOps>(d_points, n, from_form, g, s, d_table);
+}
+void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t bpw, uint32_t NBb, bn254_projective_t* out)
+{
+  G1::P p = msm_host_tail_tab<G1>((const G1::X*)h_partials, Wb, bpw, NBb);
+  memcpy(out, &p, sizeof p);
 }
 eIcicleError msm_g1_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G1>(d_points, n, from_form, s); }
 void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out)

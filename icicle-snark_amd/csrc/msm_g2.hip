@@ -3,9 +3,18 @@
 #include "msm_impl.h"
 
 namespace isnark {
-eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof)
+eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len)
 {
-  return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, 1, s, (G2::X*)d_partials, prof);
+  return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_partials, prof);
+}
+eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
+{
+  return build_table_run<G2, Fq2Ops>(d_points, n, from_form, g, s, d_table);
+}
+void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t bpw, uint32_t NBb, bn254_g2_projective_t* out)
+{
+  G2::P p = msm_host_tail_tab<G2>((const G2::X*)h_partials, Wb, bpw, NBb);
+  memcpy(out, &p, sizeof p);
 }
 eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G2>(d_points, n, from_form, s); }
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out)

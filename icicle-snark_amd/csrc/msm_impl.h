@@ -69,24 +69,29 @@ template <> struct Lazy<G2> { typedef G2L type; };
 #endif
 // `form`: encoding of the affine bases in memory — 0 standard, 1 Montgomery R = 2^256 (zkey files), 2 internal
 // (packed canonical Montgomery R' = 2^261, produced once by msm_points_to_internal; no per-load conversion)
+// `ib` = 0: classic entry (point index; base = bases[(i − skip)·stride]).  ib > 0: table mode, entry = i | w << ib and
+// the bases are W rows of `stride` points, row w holding 2^(c·w)·P (base = bases[w·stride + i − skip]).
+__device__ __forceinline__ uint32_t entry_point(uint32_t e, int ib) { return ib ? (e & ((1u << ib) - 1)) : (e & 0x7fffffffu); }
 template <class C>
-__device__ __forceinline__ typename C::A fetch_base(const typename C::A* bases, uint32_t e, uint32_t skip_below, uint32_t stride)
+__device__ __forceinline__ typename C::A fetch_base(const typename C::A* bases, uint32_t e, uint32_t skip_below, uint32_t stride, int ib)
 {
-  const uint32_t idx = e & 0x7fffffffu;
-  return bases[(size_t)(idx < skip_below ? 0u : idx - skip_below) * stride]; // entries below skip_below are ignored by the caller
+  const uint32_t i = entry_point(e, ib);
+  const uint32_t j = i < skip_below ? 0u : i - skip_below; // entries below skip_below are ignored by the caller
+  if (ib) return bases[(size_t)((e & 0x7fffffffu) >> ib) * stride + j];
+  return bases[(size_t)j * stride];
 }
 template <class C>
-__device__ __forceinline__ typename Lazy<C>::type::A load_base_lazy(const typename C::A* bases, uint32_t e, uint32_t skip_below, uint32_t stride, int form, bool& is_zero)
+__device__ __forceinline__ typename Lazy<C>::type::A load_base_lazy(const typename C::A* bases, uint32_t e, uint32_t skip_below, uint32_t stride, int ib, int form, bool& is_zero)
 {
   typedef typename Lazy<C>::type CL;
-  const typename C::A p = fetch_base<C>(bases, e, skip_below, stride);
-  is_zero = (e & 0x7fffffffu) < skip_below || C::aff_is_zero(p); // scalar outside this base set (C MSM), or the identity
+  const typename C::A p = fetch_base<C>(bases, e, skip_below, stride, ib);
+  is_zero = entry_point(e, ib) < skip_below || C::aff_is_zero(p); // scalar outside this base set (C MSM), or the identity
   return CL::load_affine(p, form, (e >> 31) != 0);
 }
 
 template <class C>
 __global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, uint32_t stride, int form,
+                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, uint32_t stride, int ib, int form,
                                                               typename C::X* __restrict__ buckets)
 {
   typedef typename Lazy<C>::type CL;
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(cons
       const uint32_t e = e_nxt;
       if (k + 1 < cnt) e_nxt = idx[k + 1];
       bool z;
-      const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, stride, form, z);
+      const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, stride, ib, form, z);
       if (!z) CL::x_madd(acc, p);
     }
   } else {
@@ -112,14 +117,14 @@ __global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(cons
     // flight while the current mixed addition (~9 k cycles per wave) runs; without it every iteration starts with two
     // dependent memory latencies (H accumulation alone: 4.0 → 3.0 ms)
     uint32_t e_cur = cnt ? idx[0] : 0u, e_nxt = cnt > 1 ? idx[1] : 0u;
-    typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride);
+    typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
     for (uint32_t k = 0; k < cnt; k++) {
       const typename C::A pk = pk_cur;
       const uint32_t e = e_cur;
       e_cur = e_nxt;
-      if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride);
+      if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
       if (k + 2 < cnt) e_nxt = idx[k + 2];
-      const bool z = (e & 0x7fffffffu) < skip_below || C::aff_is_zero(pk);
+      const bool z = entry_point(e, ib) < skip_below || C::aff_is_zero(pk);
       if (!z) CL::x_madd(acc, CL::load_affine(pk, form, (e >> 31) != 0));
     }
   }
@@ -159,7 +164,7 @@ __device__ __forceinline__ typename C::X block_reduce(typename C::X v, typename 
 template <class C>
 __global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                                     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint2* __restrict__ items, uint32_t item_cap,
-                                                                    uint32_t skip_below, uint32_t stride, int pts_mont, typename C::X* __restrict__ item_partials)
+                                                                    uint32_t skip_below, uint32_t stride, int ib, int pts_mont, typename C::X* __restrict__ item_partials)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typenam
     typename CL::X lacc = CL::x_zero();
     for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
       bool z;
-      const typename CL::A p = load_base_lazy<C>(bases, sorted[k], skip_below, stride, pts_mont, z);
+      const typename CL::A p = load_base_lazy<C>(bases, sorted[k], skip_below, stride, ib, pts_mont, z);
       if (!z) CL::x_madd(lacc, p);
     }
     typename C::X acc = block_reduce<C>(CL::x_store(lacc), sh, blockDim.x);
@@ -220,7 +225,7 @@ __device__ __forceinline__ typename Lazy<C>::type::X block_reduce_lazy(typename 
 // Σ_b (b+1)·B_b per window.  grid = (blocks per window, W); each thread owns K = 2^k_log buckets.
 // Buckets arrive in the internal encoding; partial sums leave as ec.h XYZZ (Montgomery R = 2^256) for the tails.
 template <class C>
-__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials)
+__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials, int emit_line)
 {
   typedef typename Lazy<C>::type CL;
   typedef typename CL::X X;
@@ -245,6 +250,12 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C
   }
   tri = block_reduce_lazy<C>(tri, sh, blockDim.x);
   if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(tri);
+  if (emit_line) {
+    // table mode: the pseudo-windows are slices of ONE bucket set, the tail also needs Σ B_b of every slice
+    __syncthreads();
+    line = block_reduce_lazy<C>(line, sh, blockDim.x);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(line);
+  }
 }
 
 // window sums → Horner → projective standard form.  One workgroup of 64 threads.
@@ -345,6 +356,62 @@ __global__ __launch_bounds__(64) void batch_to_affine_kernel(const typename C::P
 }
 
 
+// table mode, cold path: rows[w·n + i] = 2^(c·w)·P_i (w < W) as Montgomery-256 projective points; the caller turns
+// them into affine (batch inversion) and into the internal encoding.  One thread per base, W·c doublings.
+template <class C>
+__global__ __launch_bounds__(256) void msm_table_rows_kernel(const typename C::A* __restrict__ pts, uint32_t n, int from_form, int c, int W, typename C::P* __restrict__ rows)
+{
+  typedef typename Lazy<C>::type CL;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const typename C::A p = pts[i];
+  typename CL::X x = CL::x_zero();
+  if (!C::aff_is_zero(p)) {
+    const typename CL::A a = CL::load_affine(p, from_form, false);
+    CL::x_madd(x, a);
+  }
+  for (int w = 0; w < W; w++) {
+    rows[(size_t)w * n + i] = C::x_to_projective(CL::x_store(x)); // identity → (0, 1, 0)
+    if (w + 1 < W)
+      for (int k = 0; k < c; k++) x = CL::x_dbl(x);
+  }
+}
+template <class C, class F>
+eIcicleError build_table_run(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
+{
+  typedef typename C::A A;
+  typedef typename C::P P;
+  *d_table = nullptr;
+  const uint64_t m = (uint64_t)n * g.W;
+  A* table = nullptr;
+  HIP_TRY(hipMalloc((void**)&table, (m ? m : 1) * sizeof(A)), ICICLE_ALLOCATION_FAILED);
+  if (n) {
+    P* rows = nullptr;
+    typename F::T* scratch = nullptr;
+    HIP_TRY(hipMalloc((void**)&rows, m * sizeof(P)), ICICLE_ALLOCATION_FAILED);
+    if (hipMalloc((void**)&scratch, m * sizeof(typename F::T)) != hipSuccess) {
+      (void)hipFree(rows);
+      (void)hipFree(table);
+      return ICICLE_ALLOCATION_FAILED;
+    }
+    hipLaunchKernelGGL((msm_table_rows_kernel<C>), dim3((n + 255) / 256), dim3(256), 0, s, (const A*)d_points, n, from_form, g.c, g.W, rows);
+    const int chunk = 32;
+    const uint64_t nthreads = (m + chunk - 1) / chunk;
+    hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, rows, m, chunk, table, scratch);
+    hipLaunchKernelGGL((msm_points_to_internal_kernel<C>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, table, (uint32_t)m, 0);
+    const eIcicleError e = check_launch("msm_build_table");
+    const hipError_t he = hipStreamSynchronize(s);
+    (void)hipFree(rows);
+    (void)hipFree(scratch);
+    if (e != ICICLE_SUCCESS || he != hipSuccess) {
+      (void)hipFree(table);
+      return e != ICICLE_SUCCESS ? e : ICICLE_SYNCHRONIZATION_FAILED;
+    }
+  }
+  *d_table = table;
+  return ICICLE_SUCCESS;
+}
+
 template <class C>
 eIcicleError points_to_internal_run(void* d_points, uint32_t n, int from_form, hipStream_t s)
 {
@@ -359,7 +426,7 @@ template <class C>
 struct AccumulateLauncher {
   static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets)
   {
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, mont_pt, buckets);
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, buckets);
   }
 };
 #if defined(ISNARK_G2_ACC_EXTERN)
@@ -380,8 +447,10 @@ template <class X>
 ReduceShape reduce_shape(const MsmGeom& g)
 {
   ReduceShape r;
-  r.k_log = (g.c - 1) > 11 ? (g.c - 1) - 11 : 0;
-  r.tpw = g.NB >> r.k_log;                               // reduce threads per window
+  int lnb = 0;
+  while ((1u << lnb) < g.NBb) lnb++;
+  r.k_log = lnb > 11 ? lnb - 11 : 0;
+  r.tpw = g.NBb >> r.k_log;                              // reduce threads per (pseudo-)window
   const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256;   // LDS tree buffer ≤ 32 KiB
   r.rblock = r.tpw < rb_max ? r.tpw : rb_max;
   r.bpw = r.tpw / r.rblock;
@@ -403,13 +472,37 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
   HIP_TRY(item_partials.alloc(pl->item_cap, s), ICICLE_ALLOCATION_FAILED);
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, mont_pt, item_partials.p);
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
   hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.W), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NB, rs.k_log, d_partials);
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NBb, rs.k_log, d_partials, g.tab);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
+}
+
+// host tail, table mode: partials = [Wb·bpw triangle sums | Wb·bpw plain sums] of the slices of the single bucket set;
+// Σ_b (b+1)·B_b = Σ_v S_v + NBb · Σ_v v·T_v
+template <class C>
+typename C::P msm_host_tail_tab(const typename C::X* part, uint32_t Wb, uint32_t bpw, uint32_t NBb)
+{
+  typedef typename C::X X;
+  X S = C::x_zero(), run = C::x_zero(), U = C::x_zero();
+  for (int v = (int)Wb - 1; v >= 0; v--) {
+    X sv = C::x_zero(), tv = C::x_zero();
+    for (uint32_t k = 0; k < bpw; k++) {
+      sv = C::x_add(sv, part[(size_t)v * bpw + k]);
+      tv = C::x_add(tv, part[(size_t)Wb * bpw + (size_t)v * bpw + k]);
+    }
+    S = C::x_add(S, sv);
+    if (v >= 1) {
+      run = C::x_add(run, tv); // Σ_{u ≥ v} T_u
+      U = C::x_add(U, run);    // after the loop: Σ_v v·T_v
+    }
+  }
+  for (uint32_t m = NBb; m > 1; m >>= 1) U = C::x_dbl(U);
+  S = C::x_add(S, U);
+  return C::p_from_mont(C::x_to_projective(S));
 }
 
 // host tail: Σ partials per window, Horner, standard-form projective (identity → (0,1,0))

@@ -12,9 +12,18 @@ namespace isnark {
 constexpr uint32_t MSM_LARGE_CHUNK = 4096; // entries per work item of a large bucket (256 threads × 16 additions)
 
 struct MsmGeom {
-  int c, W;
-  uint32_t NB;   // buckets per window = 2^(c-1)
+  int c, W;      // digit width and digits per scalar
+  uint32_t NB;   // 2^(c-1): magnitudes of a signed digit (= buckets per window in the classic layout)
   uint32_t H[9]; // Σ_w 2^(c·w + c − 1)
+  // Fixed-base TABLE mode (the prover's cached keys): the bases are stored as W rows 2^(c·w)·P_i, every digit of
+  // every window then lands in ONE bucket set of NB buckets (bucket = |digit| − 1) and no Horner pass over windows
+  // is left.  The number of mixed additions is still one per non-zero digit, but with a single bucket set the digit
+  // can be 4 bits wider for the same number of buckets: 13 instead of 16 digits per 254-bit scalar (−19 % additions)
+  // at the price of W× the base memory — 8 GB of the 288 GB at 1.6 M constraints.
+  int tab;       // 0 classic (bucket = w·NB + |d| − 1, entry = point index), 1 table mode (bucket = |d| − 1, entry = i | w << IB)
+  int IB;        // table mode: bits of the point index inside an entry
+  int Wb;        // bucket array viewed as Wb pseudo-windows of NBb buckets (classic: W × NB) for the reduction kernel
+  uint32_t NBb;
 };
 
 // Result of the recode + counting-sort stage for one scalar vector (device arrays, workspace arena).
@@ -38,12 +47,13 @@ struct SortPlan {
   ~SortPlan(); // = msm_sort_release(this): the workspace goes back to the arena on every path
 };
 
-// geometry for a length-L MSM (c_cfg > 0 forces the window size)
-MsmGeom msm_geometry(uint32_t L, int c_cfg);
+// geometry for a length-L MSM (c_cfg > 0 forces the window size); tab != 0 asks for the table mode (falls back to
+// the classic layout when the entry encoding would not fit)
+MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab = 0);
 // recode → histogram → scan → scatter on stream s.  Workspace comes from the arena of stream s and is
 // returned by msm_sort_release (which only marks it reusable by later work on that stream; idempotent, also
 // run by ~SortPlan).
-eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl);
+eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl, int tab = 0);
 void msm_sort_release(SortPlan* pl);
 
 // ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,
@@ -59,7 +69,8 @@ MsmProfile* msm_profile_next();
 
 // Bucket stages for one base set on stream s (may differ from the plan's stream; the caller orders them):
 // accumulate (+ large buckets) → per-window reduction.  Writes W·bpw XYZZ partial sums (Montgomery form) to
-// d_partials (device, caller-provided, ≥ msm_partials_bytes()).  Entries whose scalar index is < skip_below
+// d_partials (device, caller-provided, ≥ msm_partials_bytes(); table mode: Wb·bpw triangle sums followed by Wb·bpw plain
+// sums, and `d_points` is the table with `points_form` = 2, rows of `row_len` points).  Entries whose scalar index is < skip_below
 // are ignored and the base index is (scalar index − skip_below): lets the C MSM (witness[n_public+1..])
 // share the witness sort.
 // `points_form` below: 0 standard form, 1 Montgomery R = 2^256 (as stored in zkey files), 2 the internal encoding of the
@@ -67,9 +78,15 @@ MsmProfile* msm_profile_next();
 // in place (once per key; the identity (0,0) is preserved) so that the hot loop loads points without a conversion.
 eIcicleError msm_g1_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s);
 eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s);
+// table mode (MsmGeom.tab): d_table = W rows of n points, row w = 2^(c·w)·P in the internal encoding (hipMalloc'ed,
+// owned by the caller); `g` = msm_geometry(n_scalars, 0, 1) of the scalar vector the table will be used with.
+eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
+eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
+void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t bpw, uint32_t NBb, bn254_projective_t* out);
+void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t bpw, uint32_t NBb, bn254_g2_projective_t* out);
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bpw);
-eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
-eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof);
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1);
+eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1);
 // host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective
 void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out);
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out);

@@ -77,6 +77,10 @@ __device__ __forceinline__ uint32_t digit(const uint32_t t[9], int w, const MsmG
   return d < 0 ? ((uint32_t)(-d) | 0x80000000u) : (uint32_t)d;
 }
 
+// bucket of digit magnitude bk+1 of window w, and the entry that names the point
+__device__ __forceinline__ uint32_t bucket_id(const MsmGeom& g, int w, uint32_t bk) { return g.tab ? bk : (uint32_t)w * g.NB + bk; }
+__device__ __forceinline__ uint32_t entry_idx(const MsmGeom& g, int w, uint32_t i) { return g.tab ? (i | ((uint32_t)w << g.IB)) : i; }
+
 // zero `n` u32 words (a kernel instead of hipMemsetAsync keeps every dependency on the compute queue)
 __global__ __launch_bounds__(256) void msm_zero_kernel(uint32_t* __restrict__ p, uint32_t n)
 {
@@ -101,15 +105,15 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe* __restrict__ sc
       const uint32_t d = digit(t, w, g);
       if (d) {
         const uint32_t bk = (d & 0x7fffffffu) - 1;
-        if (w < 2 && bk < HIST_HOT && bk < g.NB) atomicAdd(&hot[w * HIST_HOT + bk], 1u);
-        else atomicAdd(&counts[(uint32_t)w * g.NB + bk], 1u);
+        if ((g.tab || w < 2) && bk < HIST_HOT && bk < g.NB) atomicAdd(&hot[(g.tab ? 0 : w) * HIST_HOT + bk], 1u);
+        else atomicAdd(&counts[bucket_id(g, w, bk)], 1u);
       }
     }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < 2 * HIST_HOT; k += blockDim.x) {
     const uint32_t v = hot[k];
-    if (v) atomicAdd(&counts[(k / HIST_HOT) * g.NB + (k % HIST_HOT)], v);
+    if (v) atomicAdd(&counts[bucket_id(g, (int)(k / HIST_HOT), k % HIST_HOT)], v);
   }
 }
 
@@ -122,9 +126,9 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const fe* __restrict__
   for (int w = 0; w < g.W; w++) {
     const uint32_t d = digit(t, w, g);
     if (d) {
-      const uint32_t pos = atomicAdd(&cursor[(uint32_t)w * g.NB + ((d & 0x7fffffffu) - 1)], 1u);
+      const uint32_t pos = atomicAdd(&cursor[bucket_id(g, w, (d & 0x7fffffffu) - 1)], 1u);
       const uint32_t sign = (d >> 31) ^ neg;
-      sorted[pos] = i | (sign << 31);
+      sorted[pos] = entry_idx(g, w, i) | (sign << 31);
     }
   }
 }
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void msm_part_init_kernel(const uint32_t* __re
                                                             uint32_t nparts, uint32_t nb, uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ total)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < nparts) part_cursor[p] = offsets[(p / NP) * g.NB + ((p % NP) << low_bits)];
+  if (p < nparts) part_cursor[p] = offsets[p << low_bits]; // partition p = buckets [p·2^low_bits, (p+1)·2^low_bits)
   if (p == 0) *total = offsets[nb - 1] + counts[nb - 1];
 }
 
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __r
       recode(scalars, i, g, mont, t, neg);
       for (int w = 0; w < g.W; w++) {
         const uint32_t d = digit(t, w, g);
-        if (d) atomicAdd(&hist[(uint32_t)w * NP + (((d & 0x7fffffffu) - 1) >> low_bits)], 1u);
+        if (d) atomicAdd(&hist[bucket_id(g, w, (d & 0x7fffffffu) - 1) >> low_bits], 1u);
       }
     }
   }
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __r
   }
   __syncthreads();
   const uint32_t low_mask = (1u << low_bits) - 1;
+  const int fs = 31 - low_bits; // entry = index bits [0, fs) | low bucket bits [fs, 31) | sign
   for (int u = 0; u < PA_PER_THREAD; u++) {
     const uint32_t i = first + u * PA_THREADS + threadIdx.x;
     if (i < L) {
@@ -310,9 +315,9 @@ __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __r
       for (int w = 0; w < g.W; w++) {
         const uint32_t d = digit(t, w, g);
         if (d) {
-          const uint32_t bk = (d & 0x7fffffffu) - 1;
-          const uint32_t pos = atomicAdd(&cur[(uint32_t)w * NP + (bk >> low_bits)], 1u);
-          tmp[pos] = i | ((bk & low_mask) << 24) | (((d >> 31) ^ neg) << 31);
+          const uint32_t bk = bucket_id(g, w, (d & 0x7fffffffu) - 1);
+          const uint32_t pos = atomicAdd(&cur[bk >> low_bits], 1u);
+          tmp[pos] = entry_idx(g, w, i) | ((bk & low_mask) << fs) | (((d >> 31) ^ neg) << 31);
         }
       }
     }
@@ -325,8 +330,10 @@ __global__ __launch_bounds__(256) void msm_bucket_sort_kernel(const uint32_t* __
 {
   __shared__ uint32_t hist[128], cur[128];
   const uint32_t part = blockIdx.x;
-  const uint32_t b0 = (part / NP) * g.NB + ((part % NP) << low_bits);
+  const uint32_t b0 = part << low_bits;
   const uint32_t nbk = 1u << low_bits;
+  const int fs = 31 - low_bits;
+  const uint32_t fmask = nbk - 1;
   const uint32_t start = offsets[b0];
   const uint32_t end = b0 + nbk < nb ? offsets[b0 + nbk] : *total;
   // this workgroup's share: every PB_SPLIT-th 256-entry stripe of the partition
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void msm_bucket_sort_kernel(const uint32_t* __
   if (first - threadIdx.x >= end) return; // nothing for this workgroup (uniform across the workgroup)
   if (threadIdx.x < 128) hist[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t e = first; e < end; e += stride) atomicAdd(&hist[(tmp[e] >> 24) & 0x7f], 1u);
+  for (uint32_t e = first; e < end; e += stride) atomicAdd(&hist[(tmp[e] >> fs) & fmask], 1u);
   __syncthreads();
   if (threadIdx.x < nbk) {
     const uint32_t h = hist[threadIdx.x];
@@ -343,8 +350,8 @@ __global__ __launch_bounds__(256) void msm_bucket_sort_kernel(const uint32_t* __
   __syncthreads();
   for (uint32_t e = first; e < end; e += stride) {
     const uint32_t v = tmp[e];
-    const uint32_t pos = atomicAdd(&cur[(v >> 24) & 0x7f], 1u);
-    sorted[pos] = v & 0x80ffffffu;
+    const uint32_t pos = atomicAdd(&cur[(v >> fs) & fmask], 1u);
+    sorted[pos] = v & ~(fmask << fs);
   }
 }
 
@@ -357,17 +364,38 @@ int ilog2_ceil(uint64_t x)
 
 } // namespace
 
-MsmGeom msm_geometry(uint32_t L, int c_cfg)
+MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
 {
   // window size: as the reference, ≈ log2(L) − 4 (cuda_msm.cuh:45-48), capped so that bucket magnitudes fit
   // 15 bits + sign
   MsmGeom g;
+  memset(&g, 0, sizeof g);
   int c = c_cfg > 0 ? c_cfg : ilog2_ceil(L ? L : 1) - 4;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
+  if (tab) {
+    // one bucket set: as many buckets as the classic layout has over all its windows (≈ 2^(c+3)) → digits 4 bits wider
+    const int ct = c + 4 > 20 ? 20 : c + 4;
+    const int Wt = 254 / ct + 1;
+    const int ib = ilog2_ceil(L ? L : 1), wb = ilog2_ceil((uint64_t)Wt);
+    int low = (ct - 1) - 13;
+    if (low < 0) low = 0;
+    if (low > 7) low = 7;
+    if (c_cfg <= 0 && ib + wb + low <= 31) c = ct;
+    else tab = 0;
+    g.IB = ib;
+  }
+  g.tab = tab ? 1 : 0;
   g.c = c;
   g.W = 254 / c + 1;
   g.NB = 1u << (c - 1);
+  if (g.tab) {
+    g.NBb = g.NB > 32768u ? 32768u : g.NB;
+    g.Wb = (int)(g.NB / g.NBb);
+  } else {
+    g.NBb = g.NB;
+    g.Wb = g.W;
+  }
   uint32_t H[10] = {0};
   for (int w = 0; w < g.W; w++) {
     const int bit = w * c + c - 1;
@@ -377,25 +405,31 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg)
   return g;
 }
 
-eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl)
+eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl, int tab)
 {
-  pl->g = msm_geometry(L, c_cfg);
+  pl->g = msm_geometry(L, c_cfg, tab);
   const MsmGeom& g = pl->g;
   pl->L = L;
   pl->stream = s;
-  const uint32_t nb = g.NB * (uint32_t)g.W;
+  const uint32_t nb = g.NBb * (uint32_t)g.Wb;
   pl->nbuckets = nb;
   // large-bucket threshold (the reference: large_bucket_factor(10) × average, cuda_msm.cuh:205-220)
-  const uint64_t avg = L / g.NB + 1;
+  const uint64_t avg = (g.tab ? (uint64_t)L * g.W : (uint64_t)L) / g.NB + 1;
   uint32_t thr = (uint32_t)(avg * (uint64_t)(lbf > 0 ? lbf : 10));
   if (thr < 512) thr = 512;
   pl->large_thr = thr;
   const uint32_t nblocks = (nb + SCAN_B - 1) / SCAN_B;
   const uint64_t nentries = (uint64_t)L * g.W;
-  // bucket index = partition (top ≤ 8 bits) | low bits
-  const int low_bits = (g.c - 1) > 8 ? (g.c - 1) - 8 : 0;
-  const uint32_t NP = g.NB >> low_bits, nparts = NP * (uint32_t)g.W;
-  const bool two_level = L <= (1u << 24) && (size_t)nparts * 8 <= 64 * 1024;
+  // bucket index = partition | low bits (≤ 128 buckets per partition; ≤ 8192 partitions: two u32 per partition in LDS)
+  int low_bits = (g.c - 1) > 8 ? (g.c - 1) - 8 : 0;
+  if (g.tab) {
+    low_bits = (g.c - 1) - 13;
+    if (low_bits < 0) low_bits = 0;
+    if (low_bits > 7) low_bits = 7;
+  }
+  const uint32_t NP = g.NBb >> low_bits, nparts = nb >> low_bits;
+  const int idx_bits = g.tab ? g.IB + ilog2_ceil((uint64_t)g.W) : ilog2_ceil(L ? L : 1);
+  const bool two_level = idx_bits + low_bits <= 31 && low_bits <= 7 && (size_t)nparts * 8 <= 64 * 1024;
   const uint32_t oblk = (nb + ORDER_BINS - 1) / ORDER_BINS;           // workgroups of the size-order pass
   const uint32_t om = oblk * ORDER_BINS, oscan = (om + SCAN_B - 1) / SCAN_B;
   // work items of large buckets: ≤ entries/CHUNK full chunks + one partial chunk per large bucket (≤ entries/thr of those)

@@ -162,7 +162,7 @@ constexpr size_t PARTIALS_STRIDE = 64 * 16 * 256; // ≥ W·bpw·sizeof(XYZZ) fo
 
 struct Shard {
   uint32_t lo = 0, hi = 0; // [lo, hi) of the full base array
-  void* d_points = nullptr;
+  void* d_points = nullptr; // internal encoding; in table mode W rows of len() points (row w = 2^(c·w)·P, msm_plan.h)
   uint32_t len() const { return hi - lo; }
 };
 
@@ -174,6 +174,7 @@ struct ZKeyCache {
   G2::P vk_beta_2, vk_gamma_2, vk_delta_2;
   // device
   int device_id = 0, shard_rank = 0, shard_count = 1;
+  MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM, fixed at cache build
   uint32_t* d_rowptr = nullptr; // 2n+1
   uint32_t* d_cols = nullptr;   // n_coef
   fe* d_vals = nullptr;         // n_coef, Montgomery form
@@ -434,14 +435,29 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
   }
   lap("device CSR build");
-  // bases: the file's Montgomery form (R = 2^256) → the bucket kernels' internal encoding (R' = 2^261), once, in place
-  P_ICICLE(msm_g1_points_to_internal(z->A.d_points, z->A.len(), 1, nullptr));
-  P_ICICLE(msm_g1_points_to_internal(z->B1.d_points, z->B1.len(), 1, nullptr));
-  P_ICICLE(msm_g2_points_to_internal(z->B2.d_points, z->B2.len(), 1, nullptr));
-  P_ICICLE(msm_g1_points_to_internal(z->C.d_points, z->C.len(), 1, nullptr));
-  P_ICICLE(msm_g1_points_to_internal(z->H.d_points, z->H.len(), 1, nullptr));
+  // bases: the file's Montgomery form (R = 2^256) → the bucket kernels' internal encoding (R' = 2^261), once.  Table mode
+  // (msm_plan.h; ICICLE_SNARK_TABLES=0 disables it): every base array becomes W rows 2^(c·w)·P so that all digits of a
+  // scalar share one bucket set — 13 instead of 16 mixed additions per scalar at 1.6 M constraints for 13× the base memory.
+  {
+    const bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
+    z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
+    z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
+    struct Job { Shard* sh; bool g2; const MsmGeom* g; };
+    const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_w}, {&z->B2, true, &z->geom_w}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
+    for (const Job& j : jobs5) {
+      if (j.g->tab) {
+        void* table = nullptr;
+        P_ICICLE(j.g2 ? msm_g2_build_table(j.sh->d_points, j.sh->len(), 1, *j.g, nullptr, &table) : msm_g1_build_table(j.sh->d_points, j.sh->len(), 1, *j.g, nullptr, &table));
+        P_HIP(hipFree(j.sh->d_points));
+        j.sh->d_points = table;
+        z->device_bytes += (uint64_t)j.sh->len() * (j.g->W - 1) * (j.g2 ? 128 : 64);
+      } else {
+        P_ICICLE(j.g2 ? msm_g2_points_to_internal(j.sh->d_points, j.sh->len(), 1, nullptr) : msm_g1_points_to_internal(j.sh->d_points, j.sh->len(), 1, nullptr));
+      }
+    }
+  }
   P_HIP(hipStreamSynchronize(nullptr));
-  lap("points to internal form");
+  lap("points to internal form / tables");
 
   P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
@@ -624,7 +640,8 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   MsmProfile* prof[5]; // A, B1, B2, C, H
   for (auto& p : prof) p = msm_profile_next();
   (void)hipEventRecord(prof[2]->ev[0], g2);
-  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 10, 0, g2, &plan_w));
+  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 10, 0, g2, &plan_w, z->geom_w.tab));
+  if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
   P_HIP(hipEventRecord(z->ev_sort, g2));
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
     p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
@@ -657,7 +674,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
   P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
   fill(prof[2], plan_w, 1);
-  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2])); // commitment_b — src/proof_helper.rs:206
+  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len())); // commitment_b — src/proof_helper.rs:206
   (void)hipEventRecord(prof[2]->ev[3], g2);
   prof[2]->valid = true;
   P_HIP(hipEventRecord(z->ev_g2done, g2));
@@ -665,7 +682,8 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
   P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
   (void)hipEventRecord(prof[4]->ev[0], g3);
-  P_ICICLE(msm_sort_run(z->d_vec + n + z->H.lo, z->H.len(), 0, 10, 0, g3, &plan_h));
+  P_ICICLE(msm_sort_run(z->d_vec + n + z->H.lo, z->H.len(), 0, 10, 0, g3, &plan_h, z->geom_h.tab));
+  if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
   P_HIP(hipEventRecord(z->ev_sort_h, g3));
 
   // ---- groth16_commitments — src/proof_helper.rs:198-205.  A, B1, C share the witness sort and run on three
@@ -681,7 +699,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
     P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
     if (k) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
     (void)hipEventRecord(p->ev[0], st3[k]);
-    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p));
+    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len()));
     (void)hipEventRecord(p->ev[3], st3[k]);
     p->valid = true;
   }
@@ -689,7 +707,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_HIP(hipEventRecord(z->ev_g5done, z->s_g5));
   P_HIP(hipStreamWaitEvent(g1, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
-  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4]));
+  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
   (void)hipEventRecord(prof[4]->ev[3], g1);
   prof[4]->valid = true;
   // Each MSM's partial sums go to pinned memory on ITS OWN stream as soon as its reduction is done, and a host
@@ -715,10 +733,13 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
     const int cw = plan_w.g.c, ch = plan_h.g.c;
     hipEvent_t* evd = z->ev_done;
     const int dev = z->device_id;
+    const MsmGeom gw = plan_w.g, gh = plan_h.g;
     auto g1tail = [&](int k, uint32_t W, uint32_t bpw, int c, size_t off) {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[k]);
-      msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, bpw, c, (bn254_projective_t*)(out_points + off));
+      const MsmGeom& gg = k == 4 ? gh : gw;
+      if (gg.tab) msm_g1_host_tail_tab(HP + k * PARTIALS_STRIDE, W, bpw, gg.NBb, (bn254_projective_t*)(out_points + off));
+      else msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, bpw, c, (bn254_projective_t*)(out_points + off));
     };
     std::thread t0(g1tail, 0, Ww, bw1, cw, (size_t)0);
     std::thread t1(g1tail, 1, Ww, bw1, cw, (size_t)96);
@@ -726,7 +747,8 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
     std::thread t2([&] {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[2]);
-      msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, bw2, cw, (bn254_g2_projective_t*)(out_points + 192));
+      if (gw.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Ww, bw2, gw.NBb, (bn254_g2_projective_t*)(out_points + 192));
+      else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, bw2, cw, (bn254_g2_projective_t*)(out_points + 192));
     });
     g1tail(4, Wh, bh, ch, 480);
     t0.join(); t1.join(); t2.join(); t3.join();
