@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE prove out of a rocprofv3 --kernel-trace run (rocpd sqlite): start/end of every dispatch of
 the last complete prove relative to its first kernel, grouped by stream (queue), plus the busy-union of the GPU.
-usage: timeline_rocpd.py <dir with *_results.db>"""
+usage: timeline_rocpd.py <dir with *_results.db> [prove index, default 4 = inside bench.py's timed loop]"""
 import glob
 import sqlite3
 import sys
@@ -19,8 +19,9 @@ def main():
     # a prove starts with qap_spmv_kernel; take the last complete one
     starts = [i for i, r in enumerate(rows) if "qap_spmv" in r[0]]
     # the witness sort (msm recode/hist) of the same prove is enqueued just before the spmv on another stream
-    i0 = starts[-2] if len(starts) > 1 else starts[-1]
-    i1 = starts[-1]
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    k = min(k, len(starts) - 2)
+    i0, i1 = starts[k], starts[k + 1]
     # include kernels launched shortly before the spmv (sort on stream g2)
     t_spmv = rows[i0][1]
     lo = i0
