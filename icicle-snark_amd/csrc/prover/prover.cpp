@@ -183,7 +183,6 @@ struct ZKeyCache {
   fe* d_vec = nullptr;     // 3n
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
-  fe* h_witness = nullptr;      // pinned staging, n_vars
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
   hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
              ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -201,7 +200,6 @@ struct ZKeyCache {
     for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_partials})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
-    if (h_witness) (void)hipHostFree(h_witness);
     if (s_qap) (void)icicle_destroy_stream(s_qap);
     if (s_g1) (void)icicle_destroy_stream(s_g1);
     if (s_g2) (void)icicle_destroy_stream(s_g2);
@@ -249,31 +247,39 @@ struct UploadJob {
 constexpr int UPLOAD_THREADS = 8;
 constexpr size_t UPLOAD_CHUNK = 2u << 20;
 
-struct UploadPool { // pinned staging, allocated once per process
+struct UploadPool { // pinned staging and events, allocated once per process
   std::mutex mu;
   uint8_t* pinned = nullptr;
+  hipEvent_t events[UPLOAD_THREADS][2] = {};
 };
 UploadPool g_upload;
 
-int staged_upload(int device_id, const std::vector<UploadJob>& jobs)
+// `lanes`: streams to enqueue the DMAs on (one worker thread per lane, ≤ UPLOAD_THREADS).  nullptr: the call creates
+// UPLOAD_THREADS short-lived streams itself (cold path; stream creation costs milliseconds, and idle streams would
+// occupy hardware-queue slots that the prover's own streams need — runtime.cpp, GPU_MAX_HW_QUEUES).  The per-prove
+// witness upload passes the prover's own streams, idle at that point.  Returns after every DMA has completed.
+int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in = nullptr, int n_lanes = 0)
 {
   std::lock_guard<std::mutex> lk(g_upload.mu);
   UploadPool& P = g_upload;
-  if (!P.pinned) P_HIP(hipHostMalloc((void**)&P.pinned, UPLOAD_THREADS * 2 * UPLOAD_CHUNK, hipHostMallocPortable));
-  // streams and events live only for this call: idle streams would still occupy hardware-queue slots that the
-  // prover's own streams need (runtime.cpp, GPU_MAX_HW_QUEUES)
+  if (!P.pinned) {
+    P_HIP(hipHostMalloc((void**)&P.pinned, UPLOAD_THREADS * 2 * UPLOAD_CHUNK, hipHostMallocPortable));
+    for (int t = 0; t < UPLOAD_THREADS; t++)
+      for (int k = 0; k < 2; k++) P_HIP(hipEventCreateWithFlags(&P.events[t][k], hipEventDisableTiming));
+  }
   struct Lanes {
     hipStream_t streams[UPLOAD_THREADS] = {};
-    hipEvent_t events[UPLOAD_THREADS][2] = {};
+    bool own = false;
+    hipEvent_t (*events)[2] = nullptr;
     ~Lanes()
     {
-      for (int t = 0; t < UPLOAD_THREADS; t++) {
-        if (streams[t]) (void)hipStreamDestroy(streams[t]);
-        for (int k = 0; k < 2; k++)
-          if (events[t][k]) (void)hipEventDestroy(events[t][k]);
-      }
+      if (own)
+        for (int t = 0; t < UPLOAD_THREADS; t++)
+          if (streams[t]) (void)hipStreamDestroy(streams[t]);
     }
   } lanes;
+  lanes.events = P.events;
+  const int max_lanes = lanes_in ? (n_lanes < UPLOAD_THREADS ? n_lanes : UPLOAD_THREADS) : UPLOAD_THREADS;
   std::vector<UploadJob> chunks;
   for (const UploadJob& j : jobs)
     for (size_t off = 0; off < j.n; off += UPLOAD_CHUNK)
@@ -307,11 +313,12 @@ int staged_upload(int device_id, const std::vector<UploadJob>& jobs)
     if (e != hipSuccess) err = (int)e;
   };
   std::vector<std::thread> th;
-  const int nt = chunks.size() < (size_t)UPLOAD_THREADS ? (int)chunks.size() : UPLOAD_THREADS;
-  for (int t = 0; t < nt; t++) {
-    P_HIP(hipStreamCreateWithFlags(&lanes.streams[t], hipStreamNonBlocking));
-    P_HIP(hipEventCreateWithFlags(&lanes.events[t][0], hipEventDisableTiming));
-    P_HIP(hipEventCreateWithFlags(&lanes.events[t][1], hipEventDisableTiming));
+  const int nt = chunks.size() < (size_t)max_lanes ? (int)chunks.size() : max_lanes;
+  if (lanes_in) {
+    for (int t = 0; t < nt; t++) lanes.streams[t] = lanes_in[t];
+  } else {
+    lanes.own = true;
+    for (int t = 0; t < nt; t++) P_HIP(hipStreamCreateWithFlags(&lanes.streams[t], hipStreamNonBlocking));
   }
   for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
   if (nt > 0) worker(0);
@@ -463,7 +470,6 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
   P_HIP(hipMalloc((void**)&z->d_partials, 5 * PARTIALS_STRIDE));
   P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE));
-  P_HIP(hipHostMalloc((void**)&z->h_witness, (size_t)z->n_vars * 32));
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
   // six streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
   // Stream priorities were tried (QAP chain high, G2 low, …): every variant was 1-2 ms slower than equal priorities.
@@ -473,6 +479,14 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g4));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g5));
+  {
+    // the first host→device copy on a stream sets up its DMA queue (milliseconds, measured 20 ms over six streams): do
+    // it here, not inside the first prove that brings a new witness
+    const hipStream_t all[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
+    for (int rep = 0; rep < 2; rep++)
+      for (hipStream_t st : all) P_HIP(hipMemcpyAsync(z->d_partials, z->h_partials, 4096, hipMemcpyHostToDevice, st));
+    for (hipStream_t st : all) P_HIP(hipStreamSynchronize(st));
+  }
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
@@ -618,17 +632,23 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
 
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
   hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3;
+  double h2d_host_ms = 0;
   if (wtns) {
     Wtns w;
     if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
     // src/proof_helper.rs:253-262
     if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
     if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
-    // witness → pinned staging → device (stream g1), B2 MSM (stream g2) waits on the upload only
-    memcpy(z->h_witness, w.values, (size_t)nv * 32);
+    // witness → device through the parallel pinned-staging uploader of the cold path (three workers on prover streams, 2 MB
+    // chunks): a single memcpy into one pinned buffer + one DMA took 4 ms for the 51 MB of benchmark/1600k
+    const auto tu = std::chrono::steady_clock::now();
+    // three lanes: 51 MB in 1.4 ms, stable; with six, one upload in four stalled for ~15 ms on the GPU box (host threads
+    // of this call, the MSM tails and the runtime's own compete for the container's CPU quota)
+    const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
+    if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, 3)) return rc;
+    h2d_host_ms = ms_since(tu);
   }
   P_HIP(hipEventRecord(z->ev[0], g1));
-  if (wtns) P_HIP(hipMemcpyAsync(z->d_witness, z->h_witness, (size_t)nv * 32, hipMemcpyHostToDevice, g1));
   z->witness_resident = true;
   P_HIP(hipEventRecord(z->ev_witness, g1));
   P_HIP(hipEventRecord(z->ev[1], g1));
@@ -765,7 +785,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
     (void)hipEventElapsedTime(&b, z->ev[1], z->ev[2]);
     (void)hipEventElapsedTime(&c, z->ev[2], z->ev[3]);
-    tm->h2d_ms = a;
+    tm->h2d_ms = h2d_host_ms + a;
     tm->qap_ms = b;
     tm->msm_ms = c;
     tm->total_ms = ms_since(t0);
