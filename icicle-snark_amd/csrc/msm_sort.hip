@@ -267,17 +267,9 @@ __global__ __launch_bounds__(ORDER_BINS) void msm_order_scatter_kernel(const uin
 //  A  (msm_partition_kernel)   a workgroup takes 4096 scalars × all windows, counts its digits per PARTITION
 //     (the top ≤8 bits of the bucket index; LDS atomics), reserves a run per partition with one global atomic,
 //     and writes (index | low bucket bits | sign) into that run — ≈16 consecutive entries (64 B) per partition.
-//  B  (msm_bucket_sort_kernel) one workgroup per partition (≈8 K entries, 32 KB, L2-resident) places the entries
-//     at offsets[bucket] + rank with LDS cursors for the ≤128 buckets of the partition.
+//  B  (msm_fine_count_kernel, msm_fine_place_kernel) 8 workgroups per partition (≈8 K entries, 32 KB, L2-resident)
+//     count the ≤128 buckets of the partition in LDS, derive their offsets and place the entries at offset + rank.
 constexpr int PA_THREADS = 256, PA_PER_THREAD = 16, PA_SCALARS = PA_THREADS * PA_PER_THREAD;
-
-__global__ __launch_bounds__(256) void msm_part_init_kernel(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, MsmGeom g, int low_bits, uint32_t NP,
-                                                            uint32_t nparts, uint32_t nb, uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ total)
-{
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < nparts) part_cursor[p] = offsets[p << low_bits]; // partition p = buckets [p·2^low_bits, (p+1)·2^low_bits)
-  if (p == 0) *total = offsets[nb - 1] + counts[nb - 1];
-}
 
 __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_bits, uint32_t NP, uint32_t nparts,
                                                                     uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ tmp)
@@ -324,28 +316,123 @@ __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __r
   }
 }
 
-constexpr int PB_SPLIT = 8; // workgroups per partition (a witness-like scalar set puts a third of all entries into ONE partition)
-__global__ __launch_bounds__(256) void msm_bucket_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, MsmGeom g, int low_bits,
-                                                              uint32_t NP, uint32_t nb, const uint32_t* __restrict__ total, uint32_t* __restrict__ sorted)
+
+// ---- counts and offsets from the partitions (no global histogram) ------------------------------------------------
+// The per-digit global atomics of msm_hist_kernel (25.6 M at 1.6 M constraints, 1.1 ms, and the main source of
+// interference with the kernels running beside the sort) are only needed by the one-level scatter.  The two-level
+// path counts digits per PARTITION in LDS (coarse histogram: one global atomic per workgroup and partition), scans
+// the ≤ 8192 partition totals in one workgroup, partitions, and then derives the per-bucket counts and offsets
+// inside each partition (≤ 128 buckets, LDS).
+__global__ __launch_bounds__(PA_THREADS) void msm_coarse_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_bits, uint32_t nparts,
+                                                                      uint32_t* __restrict__ part_count)
 {
-  __shared__ uint32_t hist[128], cur[128];
-  const uint32_t part = blockIdx.x;
-  const uint32_t b0 = part << low_bits;
-  const uint32_t nbk = 1u << low_bits;
+  extern __shared__ uint32_t sh[];
+  for (uint32_t p = threadIdx.x; p < nparts; p += PA_THREADS) sh[p] = 0;
+  __syncthreads();
+  const uint32_t first = blockIdx.x * PA_SCALARS;
+  for (int u = 0; u < PA_PER_THREAD; u++) {
+    const uint32_t i = first + u * PA_THREADS + threadIdx.x;
+    if (i < L) {
+      uint32_t t[9], neg;
+      recode(scalars, i, g, mont, t, neg);
+      for (int w = 0; w < g.W; w++) {
+        const uint32_t d = digit(t, w, g);
+        if (d) atomicAdd(&sh[bucket_id(g, w, (d & 0x7fffffffu) - 1) >> low_bits], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < nparts; p += PA_THREADS) {
+    const uint32_t h = sh[p];
+    if (h) atomicAdd(&part_count[p], h);
+  }
+}
+// exclusive scan of the partition totals, one workgroup (nparts ≤ 8192 = 256 threads × 32)
+__global__ __launch_bounds__(SCAN_T) void msm_part_scan_kernel(const uint32_t* __restrict__ part_count, uint32_t nparts, uint32_t* __restrict__ part_start, uint32_t* __restrict__ part_cursor)
+{
+  __shared__ uint32_t sh[SCAN_T];
+  const uint32_t per = (nparts + SCAN_T - 1) / SCAN_T, lo = threadIdx.x * per;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < per; k++)
+    if (lo + k < nparts) s += part_count[lo + k];
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(s, sh, &total);
+  for (uint32_t k = 0; k < per; k++)
+    if (lo + k < nparts) {
+      part_start[lo + k] = run;
+      part_cursor[lo + k] = run;
+      run += part_count[lo + k];
+    }
+  if (threadIdx.x == 0) part_start[nparts] = total;
+}
+constexpr int PB_SPLIT = 8; // workgroups per partition (a witness-like scalar set puts a third of all entries into ONE partition)
+__global__ __launch_bounds__(256) void msm_fine_count_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, int low_bits, uint32_t* __restrict__ counts)
+{
+  __shared__ uint32_t hist[128];
+  const uint32_t part = blockIdx.x, b0 = part << low_bits, nbk = 1u << low_bits;
   const int fs = 31 - low_bits;
   const uint32_t fmask = nbk - 1;
-  const uint32_t start = offsets[b0];
-  const uint32_t end = b0 + nbk < nb ? offsets[b0 + nbk] : *total;
-  // this workgroup's share: every PB_SPLIT-th 256-entry stripe of the partition
+  const uint32_t start = part_start[part], end = part_start[part + 1];
   const uint32_t stride = blockDim.x * gridDim.y, first = start + blockIdx.y * blockDim.x + threadIdx.x;
-  if (first - threadIdx.x >= end) return; // nothing for this workgroup (uniform across the workgroup)
+  if (first - threadIdx.x >= end) return;
   if (threadIdx.x < 128) hist[threadIdx.x] = 0;
   __syncthreads();
   for (uint32_t e = first; e < end; e += stride) atomicAdd(&hist[(tmp[e] >> fs) & fmask], 1u);
   __syncthreads();
   if (threadIdx.x < nbk) {
     const uint32_t h = hist[threadIdx.x];
-    cur[threadIdx.x] = h ? atomicAdd(&cursor[b0 + threadIdx.x], h) : 0; // cursor[] starts at offsets[] (scan_finish)
+    if (h) atomicAdd(&counts[b0 + threadIdx.x], h);
+  }
+}
+// offsets of the partition's buckets (every workgroup recomputes them from the counts; split 0 publishes them and
+// registers large buckets), then this workgroup's stripe of entries is placed.  cursor[] starts at zero.
+__global__ __launch_bounds__(256) void msm_fine_place_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ counts,
+                                                             uint32_t* __restrict__ cursor, int low_bits, uint32_t thr, uint32_t* __restrict__ offsets, uint32_t* __restrict__ n_large,
+                                                             uint32_t* __restrict__ large_list, uint32_t* __restrict__ large_first, uint2* __restrict__ large_items, uint32_t item_cap,
+                                                             uint32_t* __restrict__ sorted)
+{
+  __shared__ uint32_t offs[128], hist[128], cur[128];
+  const uint32_t part = blockIdx.x, b0 = part << low_bits, nbk = 1u << low_bits;
+  const int fs = 31 - low_bits;
+  const uint32_t fmask = nbk - 1;
+  const uint32_t start = part_start[part], end = part_start[part + 1];
+  const uint32_t mine = threadIdx.x < nbk ? counts[b0 + threadIdx.x] : 0;
+  if (threadIdx.x < 128) {
+    offs[threadIdx.x] = mine;
+    hist[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (uint32_t d = 1; d < 128; d <<= 1) { // inclusive scan over ≤ 128 counters
+    uint32_t x = 0;
+    if (threadIdx.x < 128 && threadIdx.x >= d) x = offs[threadIdx.x - d];
+    __syncthreads();
+    if (threadIdx.x < 128) offs[threadIdx.x] += x;
+    __syncthreads();
+  }
+  if (threadIdx.x < nbk) {
+    const uint32_t o = start + offs[threadIdx.x] - mine;
+    cur[threadIdx.x] = o;
+    if (blockIdx.y == 0) {
+      offsets[b0 + threadIdx.x] = o;
+      if (mine > thr) {
+        // a large bucket becomes ⌈count / MSM_LARGE_CHUNK⌉ work items, each summed by one workgroup
+        const uint32_t li = atomicAdd(n_large, 1u);
+        const uint32_t nch = (mine + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK;
+        const uint32_t firsti = atomicAdd(n_large + 2, nch);
+        large_list[li] = b0 + threadIdx.x;
+        large_first[li] = firsti;
+        for (uint32_t q = 0; q < nch && firsti + q < item_cap; q++) large_items[firsti + q] = make_uint2(b0 + threadIdx.x, q);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t stride = blockDim.x * gridDim.y, first = start + blockIdx.y * blockDim.x + threadIdx.x;
+  if (first - threadIdx.x >= end) return; // nothing for this workgroup (uniform across the workgroup)
+  for (uint32_t e = first; e < end; e += stride) atomicAdd(&hist[(tmp[e] >> fs) & fmask], 1u);
+  __syncthreads();
+  if (threadIdx.x < nbk) {
+    const uint32_t h = hist[threadIdx.x];
+    cur[threadIdx.x] += h ? atomicAdd(&cursor[b0 + threadIdx.x], h) : 0;
   }
   __syncthreads();
   for (uint32_t e = first; e < end; e += stride) {
@@ -434,8 +521,10 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   const uint32_t om = oblk * ORDER_BINS, oscan = (om + SCAN_B - 1) / SCAN_B;
   // work items of large buckets: ≤ entries/CHUNK full chunks + one partial chunk per large bucket (≤ entries/thr of those)
   pl->item_cap = (uint32_t)(nentries / MSM_LARGE_CHUNK + nentries / thr + 2);
-  // layout: counts | offsets | cursor | large_list | order | large_first | n_large[4] | bsum[nblocks] | part_cursor[nparts] | blockhist[om] | obsum[oscan] | large_items[2·item_cap]
-  HIP_TRY(ws_alloc((void**)&pl->ws, ((size_t)nb * 6 + 4 + nblocks + nparts + om + oscan + 2 * (size_t)pl->item_cap + 2) * 4, s), ICICLE_ALLOCATION_FAILED);
+  // layout: counts | offsets | cursor | large_list | order | large_first | n_large[4] | bsum[nblocks] | part_count[nparts] | part_start[nparts+1] |
+  //         part_cursor[nparts] | blockhist[om] | obsum[oscan] | large_items[2·item_cap]
+  const size_t head = (size_t)nb * 6 + 4 + nblocks + 3 * (size_t)nparts + 1 + om + oscan;
+  HIP_TRY(ws_alloc((void**)&pl->ws, (head + 2 * (size_t)pl->item_cap + 2) * 4, s), ICICLE_ALLOCATION_FAILED);
   pl->counts = pl->ws;
   pl->offsets = pl->counts + nb;
   uint32_t* cursor = pl->offsets + nb;
@@ -444,10 +533,12 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->large_first = pl->order + nb;
   pl->n_large = pl->large_first + nb;
   uint32_t* bsum = pl->n_large + 4;
-  uint32_t* part_cursor = bsum + nblocks;
+  uint32_t* part_count = bsum + nblocks;
+  uint32_t* part_start = part_count + nparts;
+  uint32_t* part_cursor = part_start + nparts + 1;
   uint32_t* blockhist = part_cursor + nparts;
   uint32_t* obsum = blockhist + om;
-  pl->large_items = reinterpret_cast<uint2*>(obsum + oscan + ((nb * 6 + 4 + nblocks + nparts + om + oscan) & 1)); // 8-byte aligned
+  pl->large_items = reinterpret_cast<uint2*>(obsum + oscan + (head & 1)); // 8-byte aligned
   HIP_TRY(ws_alloc((void**)&pl->sorted, (size_t)(nentries ? nentries : 1) * 4, s), ICICLE_ALLOCATION_FAILED);
   uint32_t* tmp = nullptr;
   WsScoped<uint32_t> tmp_block;
@@ -456,21 +547,28 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     tmp = tmp_block;
   }
 
-  unsigned zb = (nb + 255) / 256;
+  unsigned zb = (3 * nb + 255) / 256;
   if (zb > 1024) zb = 1024;
-  hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, nb);
-  hipLaunchKernelGGL(msm_zero_kernel, dim3(1), dim3(64), 0, s, pl->n_large, 4u);
+  hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, 3 * nb); // counts | offsets | cursor
+  hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + nblocks + nparts); // n_large | bsum | part_count
   const unsigned lgrid = (L + 255) / 256;
-  if (L) hipLaunchKernelGGL(msm_hist_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, pl->counts);
-  hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum);
-  hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
-  hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list, pl->large_first, pl->large_items, pl->item_cap);
-  if (L && two_level) {
-    hipLaunchKernelGGL(msm_part_init_kernel, dim3((nparts + 255) / 256), dim3(256), 0, s, pl->offsets, pl->counts, g, low_bits, NP, nparts, nb, part_cursor, pl->n_large + 1);
-    hipLaunchKernelGGL(msm_partition_kernel, dim3((L + PA_SCALARS - 1) / PA_SCALARS), dim3(PA_THREADS), (size_t)nparts * 8, s, d_scalars, L, g, mont_sc, low_bits, NP, nparts, part_cursor, tmp);
-    hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nparts, PB_SPLIT), dim3(256), 0, s, tmp, pl->offsets, cursor, g, low_bits, NP, nb, pl->n_large + 1, pl->sorted);
-  } else if (L) {
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
+  if (two_level) {
+    // counts and offsets come out of the partitions: no per-digit global atomics
+    const unsigned pgrid = (L + PA_SCALARS - 1) / PA_SCALARS;
+    if (L) hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(pgrid), dim3(PA_THREADS), (size_t)nparts * 4, s, d_scalars, L, g, mont_sc, low_bits, nparts, part_count);
+    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(SCAN_T), 0, s, part_count, nparts, part_start, part_cursor);
+    if (L) {
+      hipLaunchKernelGGL(msm_partition_kernel, dim3(pgrid), dim3(PA_THREADS), (size_t)nparts * 8, s, d_scalars, L, g, mont_sc, low_bits, NP, nparts, part_cursor, tmp);
+      hipLaunchKernelGGL(msm_fine_count_kernel, dim3(nparts, PB_SPLIT), dim3(256), 0, s, tmp, part_start, low_bits, pl->counts);
+    }
+    hipLaunchKernelGGL(msm_fine_place_kernel, dim3(nparts, PB_SPLIT), dim3(256), 0, s, tmp, part_start, pl->counts, cursor, low_bits, thr, pl->offsets, pl->n_large, pl->large_list,
+                       pl->large_first, pl->large_items, pl->item_cap, pl->sorted);
+  } else {
+    if (L) hipLaunchKernelGGL(msm_hist_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, pl->counts);
+    hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum);
+    hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
+    hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list, pl->large_first, pl->large_items, pl->item_cap);
+    if (L) hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
   }
   // bucket ids by decreasing size
   hipLaunchKernelGGL(msm_order_hist_kernel, dim3(oblk), dim3(ORDER_BINS), 0, s, pl->counts, nb, oblk, blockhist);
