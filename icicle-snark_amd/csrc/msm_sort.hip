@@ -461,14 +461,22 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   if (tab) {
-    // one bucket set: as many buckets as the classic layout has over all its windows (≈ 2^(c+3)) → digits 4 bits wider
-    const int ct = c + 4 > 20 ? 20 : c + 4;
-    const int Wt = 254 / ct + 1;
-    const int ib = ilog2_ceil(L ? L : 1), wb = ilog2_ceil((uint64_t)Wt);
-    int low = (ct - 1) - 13;
-    if (low < 0) low = 0;
-    if (low > 7) low = 7;
-    if (c_cfg <= 0 && ib + wb + low <= 31) c = ct;
+    // one bucket set: as many buckets as the classic layout has over all its windows (≈ 2^(c+3)) → digits up to 4 bits
+    // wider; the widest digit whose entry (point index | window | low bucket bits | sign) still fits 32 bits is taken
+    const int ib = ilog2_ceil(L ? L : 1);
+    int ct = 0;
+    if (c_cfg <= 0) {
+      for (int t = c + 4 > 20 ? 20 : c + 4; t > c; t--) {
+        int low = (t - 1) - 13;
+        if (low < 0) low = 0;
+        if (low > 7) low = 7;
+        if (ib + ilog2_ceil((uint64_t)(254 / t + 1)) + low <= 31) {
+          ct = t;
+          break;
+        }
+      }
+    }
+    if (ct) c = ct;
     else tab = 0;
     g.IB = ib;
   }
