@@ -111,7 +111,21 @@ def main():
         # torch's own HIP runtime is never initialised in this process (it bundles a different ROCm).
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        exch = P.RcclExchange(local_rank, max_bytes=4096)
+        exch, err = None, None
+        try:
+            exch = P.RcclExchange(local_rank, max_bytes=4096)
+        except Exception as e:   # noqa: BLE001 — any failure of the data plane is reported and agreed on below
+            err = e
+        # every rank must take the same path: if RCCL did not come up on any of them, all exchange the 576-byte blocks
+        # over the gloo control plane instead (same Exchange interface; the result is identical, and it is said so)
+        import torch
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            log(f"RCCL exchange unavailable ({err!r} on this rank): falling back to the gloo all-gather for the 576-byte blocks")
+            if exch is not None:
+                exch.close()
+            exch = P.GlooExchange()
     else:
         exch = P.LocalExchange()
     N = args.constraints
@@ -230,6 +244,7 @@ def main():
             "config": {"workload": f"benchmark/{N // 1000}k squaring chain (BN254, {N} constraints, domain 2^{info.domain_size.bit_length() - 1}), "
                                    "cached zkey, witness resident in HBM, random r/s",
                        "constraints": N, "msm_sharding": f"point-range x{world}" if world > 1 else "none",
+                       "exchange": type(exch).__name__,
                        "prove_ms_with_witness_over_pcie": pcie_ms,
                        # cold path, reported separately: zkey bytes in host memory → device-resident cache
                        "cold_cache_build_ms": cold_ms, "cache_device_mb": info.device_bytes / 1e6,

@@ -101,11 +101,17 @@ class RcclExchange:
         ident = [None]
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
-            self._check(self.lib.icicle_snark_rccl_unique_id(buf), "unique_id")
-            ident = [bytes(buf)]
-        dist.broadcast_object_list(ident, src=0)
+            if self.lib.icicle_snark_rccl_unique_id(buf) == 0:
+                ident = [bytes(buf)]
+        dist.broadcast_object_list(ident, src=0)      # None tells every rank that rank 0 could not create the id
+        if ident[0] is None:
+            raise RuntimeError("rccl unique_id: " + self.lib.icicle_snark_rccl_last_error().decode())
         self.comm = C.c_void_p()
         self._check(self.lib.icicle_snark_rccl_init(ident[0], self.rank, self.world, device_id, C.c_size_t(max_bytes), C.byref(self.comm)), "init")
+        # one round trip before anything relies on the communicator
+        got = self.allgather(bytes([self.rank & 0xff]) * 8)
+        if got != b"".join(bytes([r & 0xff]) * 8 for r in range(self.world)):
+            raise RuntimeError("rccl all-gather self-test returned wrong data")
 
     def _check(self, rc, what):
         if rc != 0:
