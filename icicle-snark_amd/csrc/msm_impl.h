@@ -449,9 +449,17 @@ ReduceShape reduce_shape(const MsmGeom& g)
   ReduceShape r;
   int lnb = 0;
   while ((1u << lnb) < g.NBb) lnb++;
-  r.k_log = lnb > 11 ? lnb - 11 : 0;
+  // buckets per thread: 16 for the large bucket sets; fewer when that would leave the GPU mostly empty (the kernel is a
+  // latency-bound chain of 2K + log₂(first index) + log₂(block) point additions per thread) — aim at ≥ 32 K threads
+  int ltot = 0;
+  while ((1u << ltot) < g.NBb * (uint32_t)g.Wb) ltot++;
+  int k = ltot - 15;
+  if (k < 0) k = 0;
+  if (k > 4) k = 4;
+  const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256;   // LDS tree buffer ≤ 36 KiB
+  while (k < 4 && (uint64_t)g.Wb * (g.NBb >> k) / rb_max > 128) k++; // ≤ 128 partial sums per kind for the host tail
+  r.k_log = k < lnb ? k : lnb;
   r.tpw = g.NBb >> r.k_log;                              // reduce threads per (pseudo-)window
-  const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256;   // LDS tree buffer ≤ 32 KiB
   r.rblock = r.tpw < rb_max ? r.tpw : rb_max;
   r.bpw = r.tpw / r.rblock;
   return r;

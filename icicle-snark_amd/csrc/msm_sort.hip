@@ -475,6 +475,9 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
           break;
         }
       }
+      // same number of digits with a narrower digit: fewer buckets, and the top digit keeps enough bits to spread over
+      // many buckets (c = 18 leaves it 2 bits — three buckets then hold a quarter of all entries each; c = 17 leaves 16)
+      while (ct > c + 1 && 254 / (ct - 1) + 1 == 254 / ct + 1) ct--;
     }
     if (ct) c = ct;
     else tab = 0;
