@@ -8,8 +8,9 @@ size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bp
 {
   const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g) : reduce_shape<G1::X>(pl->g);
   if (W) *W = (uint32_t)pl->g.Wb;
-  if (bpw) *bpw = rs.bpw;
-  return (size_t)pl->g.Wb * rs.bpw * (g2 ? sizeof(G2::X) : sizeof(G1::X)) * (pl->g.tab ? 2 : 1);
+  if (bpw) *bpw = 1; // the workgroups' partial sums are folded on the device (msm_partials_fold_kernel)
+  (void)rs;
+  return (size_t)pl->g.Wb * (g2 ? sizeof(G2::X) : sizeof(G1::X)) * (pl->g.tab ? 2 : 1);
 }
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len)
 {

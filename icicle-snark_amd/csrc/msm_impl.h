@@ -465,6 +465,18 @@ ReduceShape reduce_shape(const MsmGeom& g)
   return r;
 }
 
+// the partial sums of one (pseudo-)window's workgroups → one sum, on the device: the tails then see one element per
+// window and kind (a host thread needed 1.3 ms for the 256 G2 additions of a small bucket set)
+template <class C>
+__global__ __launch_bounds__(256) void msm_partials_fold_kernel(const typename C::X* __restrict__ raw, uint32_t bpw, typename C::X* __restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
+  typename C::X v = raw[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * bpw + threadIdx.x];
+  v = block_reduce<C>(v, sh, (int)bpw);
+  if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = v;
+}
+
 // stages 4, 4b, 5 for one base set
 template <class C>
 eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof)
@@ -484,7 +496,14 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NBb, rs.k_log, d_partials, g.tab);
+  WsScoped<X> raw;
+  X* red_out = d_partials;
+  if (rs.bpw > 1) {
+    HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * (g.tab ? 2 : 1), s), ICICLE_ALLOCATION_FAILED);
+    red_out = raw.p;
+  }
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NBb, rs.k_log, red_out, g.tab);
+  if (rs.bpw > 1) hipLaunchKernelGGL((msm_partials_fold_kernel<C>), dim3(g.Wb, g.tab ? 2 : 1), dim3(rs.bpw), rs.bpw * sizeof(X), s, raw.p, rs.bpw, d_partials);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
 }
@@ -571,10 +590,11 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     prof->is_g2 = sizeof(A) > 64;
     const ReduceShape rs = reduce_shape<X>(pl.g);
     WsScoped<X> partials;
-    HIP_TRY(partials.alloc((size_t)pl.g.W * rs.bpw, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(partials.alloc((size_t)pl.g.W, s), ICICLE_ALLOCATION_FAILED);
+    (void)rs;
     const A* pts = sb.ptr<A>() + (shared ? 0 : (size_t)bi * L * stride);
     ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, stride, s, partials.p, prof));
-    hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, (int)rs.bpw, pl.g.c, sr.ptr<P>() + bi);
+    hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, 1, pl.g.c, sr.ptr<P>() + bi);
     ICICLE_TRY(check_launch("msm_tail"));
     (void)hipEventRecord(prof->ev[3], s);
     prof->valid = true;

@@ -725,10 +725,14 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   }
   P_HIP(hipEventRecord(z->ev_g4done, z->s_g4));
   P_HIP(hipEventRecord(z->ev_g5done, z->s_g5));
-  P_HIP(hipStreamWaitEvent(g1, z->ev_sort_h, 0));
+  // H: behind A on g1 for the large circuits (measured at 1.6 M constraints: five concurrent accumulations are slower
+  // than four followed by one, 17.7 vs 17.4 ms); on g3 right behind its own sort for the small ones and for multi-GPU
+  // shards, where the GPU is far from full and only the length of the chains counts (200 k: 4.3 → 3.9 ms)
+  hipStream_t gh = z->H.len() <= (1u << 19) ? g3 : g1;
+  if (gh == g1) P_HIP(hipStreamWaitEvent(g1, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
-  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, g1, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
-  (void)hipEventRecord(prof[4]->ev[3], g1);
+  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
+  (void)hipEventRecord(prof[4]->ev[3], gh);
   prof[4]->valid = true;
   // Each MSM's partial sums go to pinned memory on ITS OWN stream as soon as its reduction is done, and a host
   // thread per MSM waits for that copy and runs the Horner tail — the tails of the early finishers (B2, A, B1, C)
@@ -736,18 +740,18 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   uint32_t Ww = 0, bw1 = 0, bw2 = 0, Wh = 0, bh = 0;
   const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Ww, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
   const size_t sizes[5] = {by1, by1, by2, by1, byh};
-  hipStream_t st5[5] = {g1, z->s_g4, g2, z->s_g5, g1};
-  // the A copy must not wait for H (same stream): A's partials were complete at ev_a_done, copy them on g3 instead
-  P_HIP(hipStreamWaitEvent(g3, prof[0]->ev[3], 0));
-  st5[0] = g3;
-  P_HIP(hipStreamWaitEvent(g1, z->ev_g2done, 0));
-  P_HIP(hipStreamWaitEvent(g1, z->ev_g4done, 0));
-  P_HIP(hipStreamWaitEvent(g1, z->ev_g5done, 0));
+  hipStream_t st5[5] = {g1, z->s_g4, g2, z->s_g5, gh};
+  if (gh == g1) {
+    // the A copy must not wait for H (same stream): A's partials were complete at its ev[3], copy them on g3 instead
+    P_HIP(hipStreamWaitEvent(g3, prof[0]->ev[3], 0));
+    st5[0] = g3;
+  }
   for (int k = 0; k < 5; k++) {
     P_HIP(hipMemcpyAsync(z->h_partials + k * PARTIALS_STRIDE, DP + k * PARTIALS_STRIDE, sizes[k], hipMemcpyDeviceToHost, st5[k]));
     P_HIP(hipEventRecord(z->ev_done[k], st5[k]));
   }
-  P_HIP(hipEventRecord(z->ev[3], g1)); // end of the MSM phase on the longest chain (timing only)
+  for (int k = 0; k < 5; k++) P_HIP(hipStreamWaitEvent(g1, z->ev_done[k], 0));
+  P_HIP(hipEventRecord(z->ev[3], g1)); // end of the MSM phase: every chain has delivered its partial sums (timing only)
   {
     const uint8_t* HP = z->h_partials;
     const int cw = plan_w.g.c, ch = plan_h.g.c;
