@@ -163,6 +163,7 @@ constexpr size_t PARTIALS_STRIDE = 64 * 16 * 256; // ≥ W·bpw·sizeof(XYZZ) fo
 struct Shard {
   uint32_t lo = 0, hi = 0; // [lo, hi) of the full base array
   void* d_points = nullptr; // internal encoding; in table mode W rows of len() points (row w = 2^(c·w)·P, msm_plan.h)
+  uint32_t stride = 1, first = 0; // H of a power-of-two shard count: elements first + k·stride, k < len() (lo = 0, hi = len)
   uint32_t len() const { return hi - lo; }
 };
 
@@ -181,6 +182,7 @@ struct ZKeyCache {
   Shard A, B1, B2, C, H;
   fe* d_witness = nullptr; // n_vars
   fe* d_vec = nullptr;     // 3n
+  fe* d_fold = nullptr;    // 3·n/G: folded rows of a strided H shard (qap_coset_fold3)
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
@@ -197,7 +199,7 @@ struct ZKeyCache {
     if (s_g3) (void)hipStreamSynchronize(s_g3);
     if (s_g4) (void)hipStreamSynchronize(s_g4);
     if (s_g5) (void)hipStreamSynchronize(s_g5);
-    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_partials})
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_partials})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
     if (s_qap) (void)icicle_destroy_stream(s_qap);
@@ -432,9 +434,35 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   if (int rc = alloc_shard(z->B1, s6, 64, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
   if (int rc = alloc_shard(z->B2, s7, 128, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
   if (int rc = alloc_shard(z->C, s8, 64, z->n_vars - skip, clo, chi, z->device_bytes, jobs)) return rc;
-  if (int rc = alloc_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes, jobs)) return rc;
+  // H: a power-of-two shard count takes the residue class k ≡ rank (mod count) instead of a contiguous range — the rank
+  // then needs the coset evaluations only at those k, which the folded forward transform delivers at 1/count of the cost
+  // (qap.h: qap_coset_fold3); the whole section is uploaded once and the class is gathered on the device
+  const bool h_strided = count > 1 && (count & (count - 1)) == 0 && n / (uint32_t)count >= 1024;
+  void* h_full = nullptr;
+  struct FreeFull {
+    void** p;
+    ~FreeFull() { if (*p) (void)hipFree(*p); }
+  } free_full{&h_full};
+  if (h_strided) {
+    if (s9->size != (uint64_t)n * 64) return fail(ERR_FORMAT, "zkey: point section size mismatch");
+    const uint32_t m = n / (uint32_t)count;
+    P_HIP(hipMalloc(&h_full, (size_t)n * 64));
+    P_HIP(hipMalloc(&z->H.d_points, (size_t)m * 64));
+    z->H.lo = 0;
+    z->H.hi = m;
+    z->H.stride = (uint32_t)count;
+    z->H.first = (uint32_t)rank;
+    jobs.push_back({h_full, s9->p, (size_t)n * 64});
+    z->device_bytes += (size_t)m * 64;
+  } else if (int rc = alloc_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes, jobs)) return rc;
   lap("point buffers (hipMalloc)");
   if (int rc = staged_upload(device_id, jobs)) return rc;
+  if (h_strided) {
+    P_HIP(qap_gather_strided((const fe*)h_full, (fe*)z->H.d_points, 2, z->H.len(), z->H.stride, z->H.first, nullptr));
+    P_HIP(hipStreamSynchronize(nullptr));
+    P_HIP(hipFree(h_full));
+    h_full = nullptr;
+  }
   lap("staged upload");
   {
     uint32_t first_bad = 0;
@@ -468,6 +496,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
 
   P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
+  if (z->H.stride > 1) P_HIP(hipMalloc((void**)&z->d_fold, (size_t)z->H.len() * 3 * 32));
   P_HIP(hipMalloc((void**)&z->d_partials, 5 * PARTIALS_STRIDE));
   P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE));
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
@@ -683,9 +712,19 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
   int dom_log = 0;
   const fe* tw = ntt_domain_table(&dom_log);
-  P_HIP(qap_coset_mul3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, gq));                                   // :121-141
-  P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kForward, &nc, (bn254_scalar_t*)z->d_vec)); // :145
-  P_HIP(qap_final(z->d_vec, n, gq));                                                                        // :154-167
+  const fe* d_hscalars = z->d_vec + n + z->H.lo; // slot 1 of the result, this rank's range
+  if (z->H.stride > 1) {
+    // strided H shard: coset keys, the fold over the shard count and the twist in one pass, then a size-n/G transform
+    const uint32_t m = z->H.len();
+    P_HIP(qap_coset_fold3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, z->H.stride, z->H.first, z->d_fold, gq));
+    P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_fold, (int)m, kForward, &nc, (bn254_scalar_t*)z->d_fold));
+    P_HIP(qap_final(z->d_fold, m, gq));
+    d_hscalars = z->d_fold + m;
+  } else {
+    P_HIP(qap_coset_mul3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, gq));                                   // :121-141
+    P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kForward, &nc, (bn254_scalar_t*)z->d_vec)); // :145
+    P_HIP(qap_final(z->d_vec, n, gq));                                                                        // :154-167
+  }
   P_HIP(hipEventRecord(z->ev[2], gq));
   P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
 
@@ -702,7 +741,7 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
   P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
   (void)hipEventRecord(prof[4]->ev[0], g3);
-  P_ICICLE(msm_sort_run(z->d_vec + n + z->H.lo, z->H.len(), 0, 10, 0, g3, &plan_h, z->geom_h.tab));
+  P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 10, 0, g3, &plan_h, z->geom_h.tab));
   if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
   P_HIP(hipEventRecord(z->ev_sort_h, g3));
 

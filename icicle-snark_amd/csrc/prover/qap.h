@@ -17,6 +17,15 @@ hipError_t qap_coset_mul3(bn254::fe* d_vec, const bn254::fe* keys, uint32_t key_
 // slot1 = slot0∘slot1 − slot2 — src/proof_helper.rs:154-167 (slot0 is left untouched)
 hipError_t qap_final(bn254::fe* d_vec, uint32_t n, hipStream_t s);
 
+// Multi-GPU shards (power-of-two count G, rank r): the rank needs the coset evaluations only at k ≡ r (mod G).  With
+// m = n/G and j = j' + t·m:  X[r + G·k'] = Σ_{j'<m} ω_m^{j'k'} · z[j'],  z[j'] = Σ_{t<G} x[j' + t·m] · ω_2n^e,
+// e = (j' + t·m) + 2m·(t·r mod G) + 2·(j'·r mod n)   (coset key g^j, ω_G^{tr} and ω_n^{j'r} in one table look-up).
+// Writes the three folded rows [3][m] to `out`; a size-m forward NTT (batch 3) of `out` then gives the rank's slice at
+// the cost of one multiplication per coefficient instead of a full size-n transform.  tw = ω_N^i table, N = 2n·tw_scale.
+hipError_t qap_coset_fold3(const bn254::fe* d_vec, const bn254::fe* tw, uint32_t tw_scale, uint32_t n, uint32_t G, uint32_t r, bn254::fe* out, hipStream_t s);
+// dst[k] = src[first + k·stride] for elements of `elem_fe` field elements (strided point-range shard of the H bases)
+hipError_t qap_gather_strided(const bn254::fe* src, bn254::fe* dst, uint32_t elem_fe, uint32_t count, uint32_t stride, uint32_t first, hipStream_t s);
+
 // cold path (csr.hip): CSR of zkey section 4 built on the device from the raw 44-byte records
 // {m:u32 c:u32 s:u32 value[32 B]} (src/cache.rs:126-166); vals come out as Montgomery-form coefficients (:214).
 // rowptr has 2n+1 entries.  *first_bad = index of the first out-of-range record, 0xffffffff if none.  Synchronises `s`.

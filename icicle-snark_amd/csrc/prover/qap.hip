@@ -69,9 +69,49 @@ __global__ __launch_bounds__(256) void qap_final_kernel(fe* d_vec, uint32_t n)
   st(d_vec + (size_t)n + i, Fr::sub(Fr::mul(Fr::mul(a, b), Fr::r2()), c));
 }
 
+__global__ __launch_bounds__(256) void qap_coset_fold3_kernel(const fe* __restrict__ d_vec, const fe* __restrict__ tw, uint32_t tw_scale, uint32_t n, uint32_t G, uint32_t r,
+                                                               fe* __restrict__ out)
+{
+  const uint32_t m = n / G;
+  const uint32_t jp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (jp >= m) return;
+  const uint32_t row = blockIdx.y;
+  const fe* x = d_vec + (size_t)row * n;
+  const uint32_t two_n = 2 * n;
+  const uint32_t base_e = (uint32_t)(((uint64_t)jp * r % n) * 2 % two_n); // 2·(j'·r mod n)
+  fe acc = Fr::zero();
+  for (uint32_t t = 0; t < G; t++) {
+    const uint32_t idx = jp + t * m;
+    const uint32_t e = (uint32_t)(((uint64_t)idx + (uint64_t)2 * m * ((t * r) % G) + base_e) % two_n);
+    acc = Fr::add(acc, Fr::mul(ld(x + idx), ld(tw + (size_t)e * tw_scale))); // standard × Montgomery twiddle = standard
+  }
+  st(out + (size_t)row * m + jp, acc);
+}
+
+__global__ __launch_bounds__(256) void qap_gather_strided_kernel(const fe* __restrict__ src, fe* __restrict__ dst, uint32_t elem_fe, uint32_t count, uint32_t stride, uint32_t first)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)count * elem_fe) return;
+  const uint64_t k = i / elem_fe, c = i % elem_fe;
+  st(dst + i, ld(src + ((uint64_t)first + k * stride) * elem_fe + c));
+}
+
 } // namespace
 
 namespace isnark {
+
+hipError_t qap_coset_fold3(const fe* d_vec, const fe* tw, uint32_t tw_scale, uint32_t n, uint32_t G, uint32_t r, fe* out, hipStream_t s)
+{
+  const uint32_t m = n / G;
+  hipLaunchKernelGGL(qap_coset_fold3_kernel, dim3((m + 255) / 256, 3), dim3(256), 0, s, d_vec, tw, tw_scale, n, G, r, out);
+  return hipGetLastError();
+}
+hipError_t qap_gather_strided(const fe* src, fe* dst, uint32_t elem_fe, uint32_t count, uint32_t stride, uint32_t first, hipStream_t s)
+{
+  const uint64_t total = (uint64_t)count * elem_fe;
+  if (total) hipLaunchKernelGGL(qap_gather_strided_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, elem_fe, count, stride, first);
+  return hipGetLastError();
+}
 
 hipError_t qap_spmv(const fe* witness, const uint32_t* rowptr, const uint32_t* cols, const fe* vals, uint32_t n, fe* d_vec, hipStream_t s)
 {

@@ -104,6 +104,32 @@ def test_sharded_commitments_sum_to_the_unsharded_proof(gpu, cm, O, S):
     assert got == want
 
 
+@pytest.mark.parametrize("count", [2, 4, 8])
+def test_power_of_two_shards_use_residue_classes_of_h(gpu, cm, O, S, count):
+    """power-of-two shard counts: H is split by k mod count and every rank runs the folded forward transform
+    (qap_coset_fold3 + a size-n/count NTT) instead of the full one; the partial commitments still sum to the unsharded
+    proof, which equals the oracle's."""
+    K = gpu
+    N = 20000                                         # domain 2^15: n / count >= 1024 for every count tested
+    r1, w = S.squaring_chain(N)
+    zkey, _ = S.setup(r1, _fbm(K), points_to_mont=lambda a: O.fq_convert_montgomery(a, True))
+    wtns = S.write_wtns(w)
+    key = f"full{count}"
+    cm.load(key, zkey)
+    want, public, _ = cm.prove_mem(key, wtns, 21, 34)
+    proof, pub = O.groth16_prove(zkey, wtns, 21, 34)
+    assert json.loads(want) == proof and json.loads(public) == pub
+    blocks = b""
+    for rank in range(count):
+        cm.load(f"p2shard{count}_{rank}", zkey, shard_rank=rank, shard_count=count)
+        blk, _ = cm.commitments(f"p2shard{count}_{rank}", wtns)
+        blocks += blk
+        cm.evict(f"p2shard{count}_{rank}")
+    got, _ = cm.assemble(key, wtns, K.sum_commitments(blocks, count), 21, 34)
+    assert got == want
+    cm.evict(key)
+
+
 def test_cli_repl_protocol(gpu, O, S, tmp_path):
     """the `prove` worker: same stdin protocol and sentinels as src/main.rs:121-186."""
     K = gpu
