@@ -474,9 +474,23 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   // (msm_plan.h; ICICLE_SNARK_TABLES=0 disables it): every base array becomes W rows 2^(c·w)·P so that all digits of a
   // scalar share one bucket set — 13 instead of 16 mixed additions per scalar at 1.6 M constraints for 13× the base memory.
   {
-    const bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
+    bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
     z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
     z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
+    if (tables) {
+      // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
+      // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
+      size_t free_b = 0, total_b = 0;
+      P_HIP(hipMemGetInfo(&free_b, &total_b));
+      const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W;
+      const uint64_t need = ww * ((uint64_t)z->A.len() * 64 * 2 + (uint64_t)z->C.len() * 64 + (uint64_t)z->B2.len() * 128) + wh * (uint64_t)z->H.len() * 64 +
+                            ww * (uint64_t)z->B2.len() * (192 + 64) + ((uint64_t)n * 128 + (uint64_t)z->n_vars * 32 + (64u << 20));
+      if (need > free_b) {
+        tables = false;
+        z->geom_w = msm_geometry(z->A.len(), 0, 0);
+        z->geom_h = msm_geometry(z->H.len(), 0, 0);
+      }
+    }
     struct Job { Shard* sh; bool g2; const MsmGeom* g; };
     const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_w}, {&z->B2, true, &z->geom_w}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
     for (const Job& j : jobs5) {
