@@ -225,7 +225,7 @@ __device__ __forceinline__ typename Lazy<C>::type::X block_reduce_lazy(typename 
 // Σ_b (b+1)·B_b per window.  grid = (blocks per window, W); each thread owns K = 2^k_log buckets.
 // Buckets arrive in the internal encoding; partial sums leave as ec.h XYZZ (Montgomery R = 2^256) for the tails.
 template <class C>
-__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials, int emit_line)
+__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials, int emit_line, int internal)
 {
   typedef typename Lazy<C>::type CL;
   typedef typename CL::X X;
@@ -249,12 +249,13 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C
     tri = CL::x_add(tri, m);
   }
   tri = block_reduce_lazy<C>(tri, sh, blockDim.x);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(tri);
+  // `internal`: the partial sums go to msm_partials_fold_kernel (internal encoding, no conversion); else they are final
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = internal ? CL::x_store_internal(tri) : CL::x_store(tri);
   if (emit_line) {
     // table mode: the pseudo-windows are slices of ONE bucket set, the tail also needs Σ B_b of every slice
     __syncthreads();
     line = block_reduce_lazy<C>(line, sh, blockDim.x);
-    if (threadIdx.x == 0) partials[(size_t)gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(line);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = internal ? CL::x_store_internal(line) : CL::x_store(line);
   }
 }
 
@@ -470,11 +471,14 @@ ReduceShape reduce_shape(const MsmGeom& g)
 template <class C>
 __global__ __launch_bounds__(256) void msm_partials_fold_kernel(const typename C::X* __restrict__ raw, uint32_t bpw, typename C::X* __restrict__ out)
 {
+  typedef typename Lazy<C>::type CL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
-  typename C::X v = raw[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * bpw + threadIdx.x];
-  v = block_reduce<C>(v, sh, (int)bpw);
-  if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = v;
+  typename CL::X* sh = reinterpret_cast<typename CL::X*>(smem);
+  // on the lazy field like the reduction itself: the 8×32 G2 addition (out-of-line Fq2 calls, scratch) made this tiny
+  // kernel take 1.9 ms next to a running accumulation
+  typename CL::X v = CL::x_load_internal(raw[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * bpw + threadIdx.x]);
+  v = block_reduce_lazy<C>(v, sh, (int)bpw);
+  if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(v);
 }
 
 // stages 4, 4b, 5 for one base set
@@ -502,8 +506,8 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
     HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * (g.tab ? 2 : 1), s), ICICLE_ALLOCATION_FAILED);
     red_out = raw.p;
   }
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NBb, rs.k_log, red_out, g.tab);
-  if (rs.bpw > 1) hipLaunchKernelGGL((msm_partials_fold_kernel<C>), dim3(g.Wb, g.tab ? 2 : 1), dim3(rs.bpw), rs.bpw * sizeof(X), s, raw.p, rs.bpw, d_partials);
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NBb, rs.k_log, red_out, g.tab, rs.bpw > 1 ? 1 : 0);
+  if (rs.bpw > 1) hipLaunchKernelGGL((msm_partials_fold_kernel<C>), dim3(g.Wb, g.tab ? 2 : 1), dim3(rs.bpw), rs.bpw * sizeof(typename Lazy<C>::type::X), s, raw.p, rs.bpw, d_partials);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
 }
