@@ -31,6 +31,8 @@
 // Algorithmic bytes of the scatter pass: 16·L·W (index pairs, here 4·L·W written +
 // 4·L·W read thanks to the implicit key) + the L·W·P gather of step 4.
 #pragma once
+#include <atomic>
+#include <mutex>
 #include <string.h>
 #include <vector>
 
@@ -551,7 +553,42 @@ typename C::P msm_host_tail(const typename C::X* part, uint32_t W, uint32_t bpw,
   return C::p_from_mont(C::x_to_projective(acc));
 }
 
-// the extern "C" entry (bn254_msm / bn254_g2_msm): sort + bucket stages + device tail.
+// Horner over the window sums on the HOST, in stream order.  The chain of c·(W−1) ≈ 240 dependent doublings takes one
+// GPU lane 2.5 ms (G1) / 9 ms (G2) — a host core does it in 0.1–0.3 ms.  The W partial sums (≤ 16 KiB) are copied to a
+// pinned slot, a host function enqueued with hipLaunchHostFunc computes the result there, and (for a device-resident
+// result) a 96/192-byte copy brings it back; everything stays asynchronous on the caller's stream.
+struct TailSlot {
+  unsigned char partials[64 * 256]; // W ≤ 64 windows (c ≥ 4) of ≤ 256-byte XYZZ
+  unsigned char result[192];
+  void* host_dst; // result requested in host memory: written by the host function itself
+  int W, c;
+};
+constexpr int TAIL_SLOTS = 128; // ring: a slot is reused after 128 further MSM calls of this process
+inline TailSlot* tail_slot_next()
+{
+  static TailSlot* ring = nullptr;
+  static std::atomic<unsigned> next{0};
+  static std::mutex mu;
+  if (!ring) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ring) {
+      TailSlot* p = nullptr;
+      if (hipHostMalloc((void**)&p, sizeof(TailSlot) * TAIL_SLOTS, hipHostMallocPortable) != hipSuccess) return nullptr;
+      ring = p;
+    }
+  }
+  return ring + (next.fetch_add(1) % TAIL_SLOTS);
+}
+template <class C>
+void host_tail_callback(void* ud)
+{
+  TailSlot* t = (TailSlot*)ud;
+  typename C::P p = msm_host_tail<C>((const typename C::X*)t->partials, (uint32_t)t->W, 1, t->c);
+  memcpy(t->result, &p, sizeof p);
+  if (t->host_dst) memcpy(t->host_dst, &p, sizeof p);
+}
+
+// the extern "C" entry (bn254_msm / bn254_g2_msm): sort + bucket stages + tail.
 // batch_size > 1 (msm.h:21-53): `batch_size` scalar vectors of msm_size elements, one result each; the bases are
 // shared (are_points_shared_in_batch) or one set per batch element.  The batch elements run back to back on the
 // caller's stream.  precompute_factor f > 1: `bases` came from msm_precompute_bases and holds f points per original
@@ -574,10 +611,9 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   const bool shared = cfg->are_points_shared_in_batch || batch == 1;
   const bool profile = getenv("ICICLE_SNARK_PROFILE") != nullptr;
 
-  Staged ss, sb, sr;
+  Staged ss, sb;
   ICICLE_TRY(ss.in(scalars, (size_t)L * batch * sizeof(fe), cfg->are_scalars_on_device, s));
   ICICLE_TRY(sb.in(bases, (size_t)L * stride * (shared ? 1 : batch) * sizeof(A), cfg->are_points_on_device, s));
-  ICICLE_TRY(sr.out(results, (size_t)batch * sizeof(P), cfg->are_results_on_device, s));
 
   int lbf = 10;
   ext_get_int(cfg->ext, "large_bucket_factor", &lbf);
@@ -598,12 +634,32 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     (void)rs;
     const A* pts = sb.ptr<A>() + (shared ? 0 : (size_t)bi * L * stride);
     ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, stride, s, partials.p, prof));
-    hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, 1, pl.g.c, sr.ptr<P>() + bi);
-    ICICLE_TRY(check_launch("msm_tail"));
+    TailSlot* slot = pl.g.W <= 64 ? tail_slot_next() : nullptr;
+    if (slot) {
+      slot->W = pl.g.W;
+      slot->c = pl.g.c;
+      slot->host_dst = cfg->are_results_on_device ? nullptr : (void*)(results + bi);
+      HIP_TRY(hipMemcpyAsync(slot->partials, partials.p, (size_t)pl.g.W * sizeof(X), hipMemcpyDeviceToHost, s), ICICLE_COPY_FAILED);
+      HIP_TRY(hipLaunchHostFunc(s, host_tail_callback<C>, slot), ICICLE_UNKNOWN_ERROR);
+      if (cfg->are_results_on_device) HIP_TRY(hipMemcpyAsync(results + bi, slot->result, sizeof(P), hipMemcpyHostToDevice, s), ICICLE_COPY_FAILED);
+    } else {
+      // no pinned slot: single-lane Horner on the device (2.5 ms G1 / 9 ms G2)
+      WsScoped<P> dres;
+      P* dst = reinterpret_cast<P*>(results + bi);
+      if (!cfg->are_results_on_device) {
+        HIP_TRY(dres.alloc(1, s), ICICLE_ALLOCATION_FAILED);
+        dst = dres.p;
+      }
+      hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, 1, pl.g.c, dst);
+      ICICLE_TRY(check_launch("msm_tail"));
+      if (!cfg->are_results_on_device) {
+        HIP_TRY(hipMemcpyAsync(results + bi, dres.p, sizeof(P), hipMemcpyDeviceToHost, s), ICICLE_COPY_FAILED);
+        HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
+      }
+    }
     (void)hipEventRecord(prof->ev[3], s);
     prof->valid = true;
   }
-  ICICLE_TRY(sr.finish());
   if (profile && prof) {
     HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
     (void)hipEventElapsedTime(&g_last_msm_ms[0], prof->ev[0], prof->ev[1]);
