@@ -99,6 +99,7 @@ def main():
     if os.environ.get("ICICLE_SNARK_BENCH_DEVICE"):
         local_rank = int(os.environ["ICICLE_SNARK_BENCH_DEVICE"])
     use_gloo = os.environ.get("ICICLE_SNARK_BENCH_EXCHANGE") == "gloo"
+    rccl_hung = False
     K.set_device("HIP", local_rank)
     if world > 1 and use_gloo:
         import torch.distributed as dist
@@ -111,11 +112,23 @@ def main():
         # torch's own HIP runtime is never initialised in this process (it bundles a different ROCm).
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        exch, err = None, None
-        try:
-            exch = P.RcclExchange(local_rank, max_bytes=4096)
-        except Exception as e:   # noqa: BLE001 — any failure of the data plane is reported and agreed on below
-            err = e
+        # the communicator is brought up on a helper thread with a deadline: an RCCL bootstrap that never returns
+        # (a fabric or driver problem) must not hang the bench; the abandoned thread is left behind and the process
+        # leaves through os._exit at the end
+        import threading
+        box = {}
+
+        def bring_up():
+            try:
+                box["exch"] = P.RcclExchange(local_rank, max_bytes=4096)
+            except Exception as e:   # noqa: BLE001 — any failure of the data plane is reported and agreed on below
+                box["err"] = e
+        th = threading.Thread(target=bring_up, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("ICICLE_SNARK_RCCL_TIMEOUT", "120")))
+        exch, err = box.get("exch"), box.get("err")
+        if th.is_alive():
+            err, rccl_hung = TimeoutError("RCCL bootstrap did not finish in time"), True
         # every rank must take the same path: if RCCL did not come up on any of them, all exchange the 576-byte blocks
         # over the gloo control plane instead (same Exchange interface; the result is identical, and it is said so)
         import torch
@@ -275,6 +288,9 @@ def main():
     exch.close()
     if world > 1:
         dist.destroy_process_group()
+        if rccl_hung:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)   # a thread is still inside the RCCL bootstrap
 
 
 if __name__ == "__main__":
