@@ -23,7 +23,7 @@ struct Comm {
   uint8_t* d_out = nullptr;
   uint8_t* h_pin = nullptr;
   size_t cap = 0;
-  int world = 1;
+  int world = 1, device = 0;
 };
 int fail(const char* what, int code)
 {
@@ -49,6 +49,7 @@ API int icicle_snark_rccl_init(const uint8_t id_bytes[NCCL_UNIQUE_ID_BYTES], int
   if (hipSetDevice(device_id) != hipSuccess) return fail("hipSetDevice", -1);
   Comm* c = new Comm();
   c->world = world;
+  c->device = device_id;
   c->cap = max_bytes_per_rank;
   ncclUniqueId id;
   memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
@@ -67,6 +68,7 @@ API int icicle_snark_rccl_allgather(void* comm, const void* in, size_t bytes, vo
 {
   Comm* c = (Comm*)comm;
   if (!c || bytes > c->cap) return fail("allgather: bad arguments", -1);
+  if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice", -1); // the active device is per thread
   memcpy(c->h_pin, in, bytes);
   if (hipMemcpyAsync(c->d_in, c->h_pin, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail("H2D", -1);
   ncclResult_t r = ncclAllGather(c->d_in, c->d_out, bytes, ncclUint8, c->comm, c->stream);
@@ -82,6 +84,7 @@ API int icicle_snark_rccl_allreduce_max(void* comm, double* value)
 {
   Comm* c = (Comm*)comm;
   if (!c) return fail("allreduce: null comm", -1);
+  if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice", -1); // the active device is per thread
   memcpy(c->h_pin, value, 8);
   if (hipMemcpyAsync(c->d_in, c->h_pin, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail("H2D", -1);
   ncclResult_t r = ncclAllReduce(c->d_in, c->d_out, 1, ncclDouble, ncclMax, c->comm, c->stream);
@@ -96,6 +99,7 @@ API int icicle_snark_rccl_destroy(void* comm)
 {
   Comm* c = (Comm*)comm;
   if (!c) return 0;
+  (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   ncclCommDestroy(c->comm);
   (void)hipFree(c->d_in);
