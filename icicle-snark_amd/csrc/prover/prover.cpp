@@ -658,7 +658,40 @@ __attribute__((visibility("default"))) int groth16_cache_info(const Groth16Cache
   return 0;
 }
 
+} // extern "C"
+
+namespace {
+// blinding terms that do not depend on the commitments: δ1·r, δ1·s, δ2·s, δ1·r·s (src/proof_helper.rs:280-283);
+// groth16_prove_mem computes them on a host thread while the GPU works
+struct Blinding {
+  bn254_scalar_t r, s;
+  bn254_projective_t d1r, d1s, d1rs;
+  bn254_g2_projective_t d2s;
+};
+// The two scalar multiplications of the proof's C term that need a commitment — (A + α1 + δ1·r)·s and
+// (B1 + β1 + δ1·s)·r, src/proof_helper.rs:284-287 — only need A and B1, which are complete milliseconds before H:
+// the host threads that finish those two MSMs go on to compute them while the GPU still works (single-GPU prove only;
+// a sharded prove has to sum the commitments of all ranks first).
+struct EarlyTerms {
+  const Blinding* bl = nullptr;
+  std::atomic<bool> bl_ready{false};
+  bn254_projective_t ta, tb;
+  std::atomic<int> done{0};
+};
+int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, uint8_t* out_points, Groth16Timings* tm, EarlyTerms* et);
+} // namespace
+
+extern "C" {
+
 __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, uint8_t out_points[GROTH16_COMMITMENTS_BYTES], Groth16Timings* tm)
+{
+  return commitments_impl(cm, key, wtns, wtns_len, out_points, tm, nullptr);
+}
+
+} // extern "C"
+
+namespace {
+int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, uint8_t* out_points, Groth16Timings* tm, EarlyTerms* et)
 {
   if (!cm || !out_points) return fail(ERR_ARG, "null argument");
   std::lock_guard<std::mutex> lk(cm->mu);
@@ -817,6 +850,15 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
       const MsmGeom& gg = k == 4 ? gh : gw;
       if (gg.tab) msm_g1_host_tail_tab(HP + k * PARTIALS_STRIDE, W, bpw, gg.NBb, (bn254_projective_t*)(out_points + off));
       else msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, bpw, c, (bn254_projective_t*)(out_points + off));
+      if (et && k < 2) {
+        while (!et->bl_ready.load(std::memory_order_acquire)) std::this_thread::yield();
+        bn254_projective_t p;
+        memcpy(&p, out_points + off, sizeof p);
+        bn254_ecadd(&p, (const bn254_projective_t*)(k == 0 ? &z->vk_alpha_1 : &z->vk_beta_1), &p);
+        bn254_ecadd(&p, k == 0 ? &et->bl->d1r : &et->bl->d1s, &p);
+        bn254_mul_scalar(&p, k == 0 ? &et->bl->s : &et->bl->r, k == 0 ? &et->ta : &et->tb);
+        et->done.fetch_add(1, std::memory_order_release);
+      }
     };
     std::thread t0(g1tail, 0, Ww, bw1, cw, (size_t)0);
     std::thread t1(g1tail, 1, Ww, bw1, cw, (size_t)96);
@@ -849,6 +891,9 @@ __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManag
   }
   return 0;
 }
+} // namespace
+
+extern "C" {
 
 __attribute__((visibility("default"))) int groth16_sum_commitments(const uint8_t* blocks, int count, uint8_t out[GROTH16_COMMITMENTS_BYTES])
 {
@@ -870,13 +915,6 @@ __attribute__((visibility("default"))) int groth16_sum_commitments(const uint8_t
 } // extern "C"
 
 namespace {
-// blinding terms that do not depend on the commitments: δ1·r, δ1·s, δ2·s, δ1·r·s (src/proof_helper.rs:280-283);
-// groth16_prove_mem computes them on a host thread while the GPU works
-struct Blinding {
-  bn254_scalar_t r, s;
-  bn254_projective_t d1r, d1s, d1rs;
-  bn254_g2_projective_t d2s;
-};
 void compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_in, Blinding* b)
 {
   bn254_scalar_t rs[2];
@@ -892,7 +930,7 @@ void compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_
   bn254_mul_scalar(&b->d1r, &b->s, &b->d1rs);
   bn254_g2_mul_scalar(delta2, &b->s, &b->d2s);
 }
-int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap);
+int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap, const EarlyTerms* et = nullptr);
 } // namespace
 
 extern "C" {
@@ -911,7 +949,7 @@ __attribute__((visibility("default"))) int groth16_assemble_proof(Groth16CacheMa
 } // extern "C"
 
 namespace {
-int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap)
+int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap, const EarlyTerms* et)
 {
   Wtns w;
   if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
@@ -936,7 +974,10 @@ int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t
   bn254_ecadd(&pi_b1, beta1, &pi_b1);
   bn254_ecadd(&pi_b1, &bl.d1s, &pi_b1);         // pi_b1 = B1 + β1 + δ1·s
   bn254_ecadd(&pi_c, &pi_h, &pi_c);             // C + H
-  {
+  if (et && et->done.load(std::memory_order_acquire) == 2) {
+    bn254_ecadd(&pi_c, &et->ta, &pi_c); // computed by the tail threads of A and B1 while H was still running
+    bn254_ecadd(&pi_c, &et->tb, &pi_c);
+  } else {
     P1 ta, tb;
     std::thread th([&] { bn254_mul_scalar(&pi_a, &bl.s, &ta); }); // pi_a·s  ∥  pi_b1·r
     bn254_mul_scalar(&pi_b1, &bl.r, &tb);
@@ -1005,11 +1046,16 @@ __attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheMa
   if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
   // r, s and the commitment-independent blinding terms on a host thread while the GPU computes the commitments
   Blinding bl;
-  std::thread th([&] { compute_blinding(z, r, s, &bl); });
-  int rc = groth16_commitments(cm, key, wtns_resident ? nullptr : wtns, wtns_len, pts, tm);
+  EarlyTerms et;
+  et.bl = &bl;
+  std::thread th([&] {
+    compute_blinding(z, r, s, &bl);
+    et.bl_ready.store(true, std::memory_order_release);
+  });
+  int rc = commitments_impl(cm, key, wtns_resident ? nullptr : wtns, wtns_len, pts, tm, z->shard_count == 1 ? &et : nullptr);
   th.join();
   if (rc) return rc;
-  rc = assemble_impl(z, wtns, wtns_len, pts, bl, proof_json, proof_cap, public_json, public_cap);
+  rc = assemble_impl(z, wtns, wtns_len, pts, bl, proof_json, proof_cap, public_json, public_cap, &et);
   if (tm) tm->total_ms = ms_since(t0);
   return rc;
 }
