@@ -170,3 +170,43 @@ def test_prover_errors(gpu, cm, S, O):
     bad[off + 4 + 3 * 44 + 4: off + 4 + 3 * 44 + 8] = (1 << 20).to_bytes(4, "little")   # record 3: c = 2^20 ≥ n
     with pytest.raises(K.ProverError, match="coefficient 3 out of range"):
         cm.load("bad-coef", bytes(bad))
+
+
+def test_repeated_and_opposite_points_in_one_bucket(gpu, cm, O, S):
+    """the exceptional cases of the bucket accumulation on the prover's table path: a run of equal witness values
+    over base points that are copies of one point (P + P: the doubling branch) or alternate P, −P (sum = identity,
+    then identity + P), in the G1 sections A / B1 / C and the G2 section B2.  Same modified zkey and witness for
+    the oracle; such a witness does not satisfy the circuit, the commitments are compared all the same."""
+    K = gpu
+    N = 600
+    r1, w = S.squaring_chain(N)
+    zkey, _ = S.setup(r1, _fbm(K), points_to_mont=lambda a: O.fq_convert_montgomery(a, True))
+    sec = O.read_sections(zkey, b"zkey")
+    z = bytearray(zkey)
+    q = O.Q_MOD
+
+    def neg(pt, coord):          # Montgomery form of −y is q − (Montgomery form of y); G2: both components of y
+        half = len(pt) // 2
+        out = bytearray(pt)
+        for k in range(half, len(pt), coord):
+            y = int.from_bytes(pt[k:k + coord], "little")
+            out[k:k + coord] = ((q - y) % q).to_bytes(coord, "little")
+        return bytes(out)
+    for sid, size, first in ((5, 64, 0), (6, 64, 0), (7, 128, 0), (8, 64, 2)):   # C starts at wire n_public + 1 = 2
+        (off, _), = sec[sid]
+        base = bytes(z[off + (20 - first) * size: off + (21 - first) * size])
+        for i in range(21, 200):      # alternate P, −P
+            z[off + (i - first) * size: off + (i - first + 1) * size] = base if i % 2 == 0 else neg(base, 32)
+        for i in range(300, 420):     # copies of P
+            z[off + (i - first) * size: off + (i - first + 1) * size] = base
+    w = list(w)
+    for i in range(20, 200):
+        w[i] = w[20]
+    for i in range(300, 420):
+        w[i] = w[300]
+    zkey2, wtns = bytes(z), S.write_wtns(w)
+    cm.load("degenerate", zkey2)
+    pj, qj, _ = cm.prove_mem("degenerate", wtns, 3, 9)
+    proof, public = O.groth16_prove(zkey2, wtns, 3, 9)
+    assert json.loads(pj) == proof and json.loads(qj) == public
+    cm.evict("degenerate")
