@@ -705,6 +705,10 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   dev.id = z->device_id;
   P_ICICLE(icicle_set_device(&dev));
   if (int rc = ensure_domain(cm, z)) return rc;
+  static const bool trace_host = getenv("ICICLE_SNARK_TRACE_HOST") != nullptr;
+  auto mark = [&](const char* what) {
+    if (trace_host) fprintf(stderr, "[host] %-12s %8.1f us\n", what, ms_since(t0) * 1e3);
+  };
 
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
   hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3;
@@ -739,6 +743,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 10, 0, g2, &plan_w, z->geom_w.tab));
   if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
   P_HIP(hipEventRecord(z->ev_sort, g2));
+  mark("wsort");
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
     p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
   };
@@ -773,6 +778,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
     P_HIP(qap_final(z->d_vec, n, gq));                                                                        // :154-167
   }
   P_HIP(hipEventRecord(z->ev[2], gq));
+  mark("qap");
   P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
 
   // ---- stream g2: G2 bucket stages.  Held back until the QAP front end is done: the G2 accumulation
@@ -784,6 +790,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   (void)hipEventRecord(prof[2]->ev[3], g2);
   prof[2]->valid = true;
   P_HIP(hipEventRecord(z->ev_g2done, g2));
+  mark("g2");
 
   // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
   P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
@@ -791,6 +798,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 10, 0, g3, &plan_h, z->geom_h.tab));
   if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
   P_HIP(hipEventRecord(z->ev_sort_h, g3));
+  mark("hsort");
 
   // ---- groth16_commitments — src/proof_helper.rs:198-205.  A, B1, C share the witness sort and run on three
   // streams (g1, g4, g5) so that the latency-bound bucket reduction of one overlaps the accumulation of the
@@ -811,6 +819,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   }
   P_HIP(hipEventRecord(z->ev_g4done, z->s_g4));
   P_HIP(hipEventRecord(z->ev_g5done, z->s_g5));
+  mark("abc");
   // H: behind A on g1 for the large circuits (measured at 1.6 M constraints: five concurrent accumulations are slower
   // than four followed by one, 17.7 vs 17.4 ms); on g3 right behind its own sort for the small ones and for multi-GPU
   // shards, where the GPU is far from full and only the length of the chains counts (200 k: 4.3 → 3.9 ms)
@@ -820,13 +829,14 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
   (void)hipEventRecord(prof[4]->ev[3], gh);
   prof[4]->valid = true;
+  mark("h");
   // Each MSM's partial sums go to pinned memory on ITS OWN stream as soon as its reduction is done, and a host
   // thread per MSM waits for that copy and runs the Horner tail — the tails of the early finishers (B2, A, B1, C)
   // overlap the GPU work still in flight; only the last one (H) is exposed.
   uint32_t Ww = 0, bw1 = 0, bw2 = 0, Wh = 0, bh = 0;
   const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Ww, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
   const size_t sizes[5] = {by1, by1, by2, by1, byh};
-  hipStream_t st5[5] = {g1, z->s_g4, g2, z->s_g5, gh};
+  hipStream_t st5[5] = {st3[0], st3[1], g2, st3[2], gh};
   if (gh == g1) {
     // the A copy must not wait for H (same stream): A's partials were complete at its ev[3], copy them on g3 instead
     P_HIP(hipStreamWaitEvent(g3, prof[0]->ev[3], 0));
@@ -838,6 +848,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   }
   for (int k = 0; k < 5; k++) P_HIP(hipStreamWaitEvent(g1, z->ev_done[k], 0));
   P_HIP(hipEventRecord(z->ev[3], g1)); // end of the MSM phase: every chain has delivered its partial sums (timing only)
+  mark("copies");
   {
     const uint8_t* HP = z->h_partials;
     const int cw = plan_w.g.c, ch = plan_h.g.c;
@@ -872,6 +883,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
     g1tail(4, Wh, bh, ch, 480);
     t0.join(); t1.join(); t2.join(); t3.join();
   }
+  mark("tails");
   P_HIP(hipStreamSynchronize(g1));
   P_HIP(hipStreamSynchronize(g2));
   P_HIP(hipStreamSynchronize(g3));
