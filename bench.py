@@ -199,10 +199,14 @@ def main():
     assert json.loads(public) == [str(pow(3, 1 << N, S.R_MOD))] and json.loads(proof)["protocol"] == "groth16"
 
     # PCIe-inclusive variant (witness handed over as a host buffer), reported separately, never as `value`
-    t1 = time.perf_counter()
-    step(first=True)
-    sync()
-    pcie_ms = (time.perf_counter() - t1) * 1e3
+    # (median of five calls: the staging threads share the host's cores with whatever else runs there)
+    samples = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        step(first=True)
+        sync()
+        samples.append((time.perf_counter() - t1) * 1e3)
+    pcie_ms = sorted(samples)[2]
 
     # witness-shape sensitivity (stand-in for the RSA/SHA-style circuits of BASELINE.json configs 4/5, whose real
     # R1CS cannot be built offline): the same key proved over a witness with 70 % of the wires in {0,1} and 10 % below
