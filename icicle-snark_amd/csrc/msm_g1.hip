@@ -4,13 +4,13 @@
 namespace isnark {
 thread_local float g_last_msm_ms[4] = {0, 0, 0, 0};
 
-size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bpw)
+size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
 {
-  const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g) : reduce_shape<G1::X>(pl->g);
+  const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g, pl->L) : reduce_shape<G1::X>(pl->g, pl->L);
   if (W) *W = (uint32_t)pl->g.Wb;
-  if (bpw) *bpw = 1; // the workgroups' partial sums are folded on the device (msm_partials_fold_kernel)
-  (void)rs;
-  return (size_t)pl->g.Wb * (g2 ? sizeof(G2::X) : sizeof(G1::X)) * (pl->g.tab ? 2 : 1);
+  if (M) *M = rs.M; // scan reduction with several workgroups per slice: the tail adds M·LL (msm_*_host_tail_tab); else 0
+  // the workgroups' partial sums are folded on the device: one element per window and kind [S | L (table mode) | LL (M > 0)]
+  return (size_t)pl->g.Wb * (g2 ? sizeof(G2::X) : sizeof(G1::X)) * (pl->g.tab ? (rs.M ? 3 : 2) : 1);
 }
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len)
 {
@@ -20,9 +20,9 @@ eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form,
 {
   return build_table_run<G1, FqOps>(d_points, n, from_form, g, s, d_table);
 }
-void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t bpw, uint32_t NBb, bn254_projective_t* out)
+void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_projective_t* out)
 {
-  G1::P p = msm_host_tail_tab<G1>((const G1::X*)h_partials, Wb, bpw, NBb);
+  G1::P p = msm_host_tail_tab<G1>((const G1::X*)h_partials, Wb, M, NBb);
   memcpy(out, &p, sizeof p);
 }
 eIcicleError msm_g1_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G1>(d_points, n, from_form, s); }

@@ -442,12 +442,18 @@ struct AccumulateLauncher<G2> {
 };
 #endif
 
+// scalar vectors up to this length leave the GPU far from full (cf. the H stream rule of the prover): the bucket
+// reduction is then a pure latency chain and the suffix-scan kernels shorten it (100 k constraints: 2.70 → 2.43 ms per
+// prove); beyond, their blockDim·log₂ extra additions cost more than the chain saves (1.6 M: 16.85 → 17.2 ms)
+constexpr uint32_t MSM_SCAN_REDUCE_MAX_L = 1u << 19;
 struct ReduceShape {
   int k_log;
   uint32_t tpw, rblock, bpw;
+  bool scan;  // small table-mode bucket set: suffix-scan kernels, factor M = rblock << k_log left to the host tail
+  uint32_t M; // 0 unless scan && bpw > 1
 };
 template <class X>
-ReduceShape reduce_shape(const MsmGeom& g)
+ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu)
 {
   ReduceShape r;
   int lnb = 0;
@@ -465,6 +471,8 @@ ReduceShape reduce_shape(const MsmGeom& g)
   r.tpw = g.NBb >> r.k_log;                              // reduce threads per (pseudo-)window
   r.rblock = r.tpw < rb_max ? r.tpw : rb_max;
   r.bpw = r.tpw / r.rblock;
+  r.scan = g.tab && L <= MSM_SCAN_REDUCE_MAX_L;
+  r.M = r.scan && r.bpw > 1 ? r.rblock << r.k_log : 0;
   return r;
 }
 
@@ -483,13 +491,126 @@ __global__ __launch_bounds__(256) void msm_partials_fold_kernel(const typename C
   if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(v);
 }
 
+// Suffix scan + two concurrent tree sums over one workgroup, shared by the bucket reduction and the fold of its
+// per-workgroup results.  In: sa[i] = t_i, sb[i] = l_i (i < n, n a power of two).  Out (valid in thread 0 after the
+// call): sa[0] = Σ_i t_i,  sb[0] = Σ_{i ≥ 1} i·l_i  (as Σ_{i ≥ 1} suffix_i, suffix_i = Σ_{u ≥ i} l_u — no scalar
+// multiplication), return value = Σ_i l_i.  Chain length: 2·log₂ n point additions (the lower half of the workgroup
+// sums sa while the upper half sums sb).
+template <class C>
+__device__ __forceinline__ typename Lazy<C>::type::X block_weighted_sums(typename Lazy<C>::type::X* sa, typename Lazy<C>::type::X* sb, int n)
+{
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
+  const int tid = threadIdx.x;
+  X suf = sb[tid];
+  for (int d = 1; d < n; d <<= 1) {
+    const bool has = tid + d < n;
+    X o = suf;
+    if (has) o = sb[tid + d];
+    __syncthreads();
+    if (has) {
+      suf = CL::x_add(suf, o);
+      sb[tid] = suf;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) sb[0] = CL::x_zero(); // weight 0
+  __syncthreads();
+  const int half = n >> 1;
+  const bool upper = half && tid >= half;
+  X* arr = upper ? sb : sa;
+  const int i = upper ? tid - half : tid;
+  for (int st = half; st > 0; st >>= 1) {
+    if (i < st) arr[i] = CL::x_add(arr[i], arr[i + st]);
+    __syncthreads();
+  }
+  return suf; // thread 0: Σ l_i
+}
+
+// Bucket reduction for SMALL bucket sets in table mode (the GPU is far from full and only the length of the dependent
+// chain counts), grid = (workgroups per window, windows), each thread owns K = 2^k_log consecutive buckets.
+// Workgroup (x, y) covers the M = blockDim·K buckets i of window y behind x·M and emits
+//   TRI = Σ_i (i+1)·B_i  (i local to the workgroup)   and   LINE = Σ_i B_i,
+// so that the window's Σ_b (b+1)·B_b = Σ_x TRI_x + M·Σ_x x·LINE_x — the weights of whole threads / workgroups come
+// from suffix sums (block_weighted_sums), not from a double-and-add per thread: a chain of 2K + 2·log₂(blockDim) + k_log
+// additions instead of 2K + 1.5·log₂(first index) + 2·log₂(blockDim), the factor M is applied by the host tail.  The
+// suffix scan costs blockDim·log₂(blockDim) additions per workgroup, which is why the large (work-bound) bucket sets
+// stay with msm_bucket_reduce_kernel.
+// final = 1 (one workgroup per window): partials = [TRI | LINE][window] as ec.h XYZZ (Montgomery R = 2^256) for the
+// tails.  final = 0: partials = [TRI | LINE][window][workgroup] in the internal encoding for msm_partials_fold_scan_kernel.
+template <class C>
+__global__ __launch_bounds__(256) void msm_bucket_reduce_scan_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials, int final)
+{
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sa = reinterpret_cast<X*>(smem);
+  X* sb = sa + blockDim.x;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // thread within the window
+  const typename C::X* B = buckets + (size_t)blockIdx.y * NB + ((size_t)t << k_log);
+  {
+    X line = CL::x_zero(), tri = CL::x_zero();
+    for (int j = (1 << k_log) - 1; j >= 0; j--) {
+      line = CL::x_add(line, CL::x_load_internal(B[j]));
+      tri = CL::x_add(tri, line);
+    }
+    sa[threadIdx.x] = tri;
+    sb[threadIdx.x] = line;
+  }
+  __syncthreads();
+  const X total = block_weighted_sums<C>(sa, sb, (int)blockDim.x);
+  if (threadIdx.x == 0) {
+    X w = sb[0]; // Σ_t t·line_t; thread t's first bucket is t·K
+    for (int j = 0; j < k_log; j++) w = CL::x_dbl(w);
+    const X tri = CL::x_add(sa[0], w);
+    const size_t nw = gridDim.y, slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (final) {
+      partials[blockIdx.y] = CL::x_store(tri);
+      partials[nw + blockIdx.y] = CL::x_store(total);
+    } else {
+      partials[slot] = CL::x_store_internal(tri);
+      partials[nw * gridDim.x + slot] = CL::x_store_internal(total);
+    }
+  }
+}
+
+// scan variant of the fold: the per-workgroup results of one (pseudo-)window → [TT | L | LL][window] for the host
+// tail: TT = Σ_x TRI_x, L = Σ_x LINE_x, LL = Σ_x x·LINE_x (the window's weighted sum is TT + M·LL, M = buckets per
+// reduction workgroup).  grid = windows, block = workgroups per window (a power of two).
+template <class C>
+__global__ __launch_bounds__(256) void msm_partials_fold_scan_kernel(const typename C::X* __restrict__ raw, uint32_t bpw, typename C::X* __restrict__ out)
+{
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sa = reinterpret_cast<X*>(smem);
+  X* sb = sa + bpw;
+  const size_t nw = gridDim.x;
+  sa[threadIdx.x] = CL::x_load_internal(raw[(size_t)blockIdx.x * bpw + threadIdx.x]);
+  sb[threadIdx.x] = CL::x_load_internal(raw[nw * bpw + (size_t)blockIdx.x * bpw + threadIdx.x]);
+  __syncthreads();
+  const X total = block_weighted_sums<C>(sa, sb, (int)bpw);
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = CL::x_store(sa[0]);
+    out[nw + blockIdx.x] = CL::x_store(total);
+    out[2 * nw + blockIdx.x] = CL::x_store(sb[0]);
+  }
+}
+
+// more than 64 KiB of dynamic LDS (two lazy XYZZ per thread) has to be allowed once per kernel
+template <class K>
+inline void allow_big_lds(K kernel, size_t bytes)
+{
+  if (bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 // stages 4, 4b, 5 for one base set
 template <class C>
 eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof)
 {
   typedef typename C::X X;
   const MsmGeom& g = pl->g;
-  const ReduceShape rs = reduce_shape<X>(g);
+  const ReduceShape rs = reduce_shape<X>(g, pl->L);
   WsScoped<X> buckets, item_partials;
   HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);
@@ -508,33 +629,46 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
     HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * (g.tab ? 2 : 1), s), ICICLE_ALLOCATION_FAILED);
     red_out = raw.p;
   }
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(typename Lazy<C>::type::X), s, buckets.p, g.NBb, rs.k_log, red_out, g.tab, rs.bpw > 1 ? 1 : 0);
-  if (rs.bpw > 1) hipLaunchKernelGGL((msm_partials_fold_kernel<C>), dim3(g.Wb, g.tab ? 2 : 1), dim3(rs.bpw), rs.bpw * sizeof(typename Lazy<C>::type::X), s, raw.p, rs.bpw, d_partials);
+  typedef typename Lazy<C>::type::X LX;
+  if (rs.scan) {
+    // small table-mode set: [TT | L | LL] (LL only with more than one workgroup per slice; the host applies M)
+    const size_t lds_r = 2 * (size_t)rs.rblock * sizeof(LX), lds_f = 2 * (size_t)rs.bpw * sizeof(LX);
+    allow_big_lds(msm_bucket_reduce_scan_kernel<C>, lds_r);
+    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, red_out, rs.bpw > 1 ? 0 : 1);
+    if (rs.bpw > 1) {
+      allow_big_lds(msm_partials_fold_scan_kernel<C>, lds_f);
+      hipLaunchKernelGGL((msm_partials_fold_scan_kernel<C>), dim3(g.Wb), dim3(rs.bpw), lds_f, s, raw.p, rs.bpw, d_partials);
+    }
+  } else {
+    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(LX), s, buckets.p, g.NBb, rs.k_log, red_out, g.tab, rs.bpw > 1 ? 1 : 0);
+    if (rs.bpw > 1) hipLaunchKernelGGL((msm_partials_fold_kernel<C>), dim3(g.Wb, g.tab ? 2 : 1), dim3(rs.bpw), rs.bpw * sizeof(LX), s, raw.p, rs.bpw, d_partials);
+  }
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
 }
 
-// host tail, table mode: partials = [Wb·bpw triangle sums | Wb·bpw plain sums] of the slices of the single bucket set;
-// Σ_b (b+1)·B_b = Σ_v S_v + NBb · Σ_v v·T_v
+// host tail, table mode: partials = [S | L | LL][slice] for the Wb slices (NBb buckets each) of the single bucket set:
+// S_v the slice's own weighted sum (short by M·LL_v when the scan kernels ran: M = buckets per reduction workgroup, a
+// power of two, else 0 and no LL), L_v = T_v its plain sum;  Σ_b (b+1)·B_b = Σ_v S_v + NBb · Σ_v v·T_v
 template <class C>
-typename C::P msm_host_tail_tab(const typename C::X* part, uint32_t Wb, uint32_t bpw, uint32_t NBb)
+typename C::P msm_host_tail_tab(const typename C::X* part, uint32_t Wb, uint32_t M, uint32_t NBb)
 {
   typedef typename C::X X;
-  X S = C::x_zero(), run = C::x_zero(), U = C::x_zero();
+  X S = C::x_zero(), run = C::x_zero(), U = C::x_zero(), LL = C::x_zero();
   for (int v = (int)Wb - 1; v >= 0; v--) {
-    X sv = C::x_zero(), tv = C::x_zero();
-    for (uint32_t k = 0; k < bpw; k++) {
-      sv = C::x_add(sv, part[(size_t)v * bpw + k]);
-      tv = C::x_add(tv, part[(size_t)Wb * bpw + (size_t)v * bpw + k]);
-    }
-    S = C::x_add(S, sv);
+    S = C::x_add(S, part[v]);
+    if (M) LL = C::x_add(LL, part[2 * (size_t)Wb + v]);
     if (v >= 1) {
-      run = C::x_add(run, tv); // Σ_{u ≥ v} T_u
-      U = C::x_add(U, run);    // after the loop: Σ_v v·T_v
+      run = C::x_add(run, part[(size_t)Wb + v]); // Σ_{u ≥ v} T_u
+      U = C::x_add(U, run);                       // after the loop: Σ_v v·T_v
     }
   }
   for (uint32_t m = NBb; m > 1; m >>= 1) U = C::x_dbl(U);
   S = C::x_add(S, U);
+  if (M) {
+    for (uint32_t m = M; m > 1; m >>= 1) LL = C::x_dbl(LL); // one chain for all slices: Σ_v M·LL_v = M·Σ_v LL_v
+    S = C::x_add(S, LL);
+  }
   return C::p_from_mont(C::x_to_projective(S));
 }
 
@@ -557,7 +691,7 @@ typename C::P msm_host_tail(const typename C::X* part, uint32_t W, uint32_t bpw,
 // GPU lane 2.5 ms (G1) / 9 ms (G2) — a host core does it in 0.1–0.3 ms.  The W partial sums (≤ 16 KiB) are copied to a
 // pinned slot, a host function enqueued with hipLaunchHostFunc computes the result there, and (for a device-resident
 // result) a 96/192-byte copy brings it back; everything stays asynchronous on the caller's stream.
-struct TailSlot {
+struct alignas(64) TailSlot {
   unsigned char partials[64 * 256]; // W ≤ 64 windows (c ≥ 4) of ≤ 256-byte XYZZ
   unsigned char result[192];
   void* host_dst; // result requested in host memory: written by the host function itself

@@ -69,8 +69,9 @@ MsmProfile* msm_profile_next();
 
 // Bucket stages for one base set on stream s (may differ from the plan's stream; the caller orders them):
 // accumulate (+ large buckets) → per-window reduction.  Writes W·bpw XYZZ partial sums (Montgomery form) to
-// d_partials (device, caller-provided, ≥ msm_partials_bytes(); table mode: Wb·bpw triangle sums followed by Wb·bpw plain
-// sums, and `d_points` is the table with `points_form` = 2, rows of `row_len` points).  Entries whose scalar index is < skip_below
+// d_partials (device, caller-provided, ≥ msm_partials_bytes(); table mode: per slice of the bucket set the weighted sum,
+// the plain sum and — small sets reduced by the suffix-scan kernels, M > 0 — the workgroup-weighted sum LL the tail still
+// has to scale by M, [S | L | LL][slice]; `d_points` is the table with `points_form` = 2, rows of `row_len` points).  Entries whose scalar index is < skip_below
 // are ignored and the base index is (scalar index − skip_below): lets the C MSM (witness[n_public+1..])
 // share the witness sort.
 // `points_form` below: 0 standard form, 1 Montgomery R = 2^256 (as stored in zkey files), 2 the internal encoding of the
@@ -82,9 +83,9 @@ eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form
 // owned by the caller); `g` = msm_geometry(n_scalars, 0, 1) of the scalar vector the table will be used with.
 eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
 eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
-void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t bpw, uint32_t NBb, bn254_projective_t* out);
-void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t bpw, uint32_t NBb, bn254_g2_projective_t* out);
-size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* bpw);
+void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_projective_t* out);
+void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_g2_projective_t* out);
+size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M);
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1);
 eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1);
 // host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective

@@ -9,7 +9,9 @@
 //   also answers for interior pointers (icicle/include/icicle/memory_tracker.h:11-55) — the Rust
 //   DeviceSlice checks this on every slice (wrappers/rust/icicle-runtime/src/memory.rs:120-125).
 #include <map>
+#include <execinfo.h>
 #include <mutex>
+#include <signal.h>
 #include <vector>
 #include <stdarg.h>
 #include <string.h>
@@ -20,7 +22,24 @@
 // a queue serialise.  The prover overlaps five streams; with four queues two of them collide and a
 // benchmark/1600k prove measured 28.5 ms instead of 25.5 ms.  Ask for eight unless the user has set the knob; this
 // runs when the library is loaded, before its first HIP call initialises the runtime.
-__attribute__((constructor)) static void isnark_runtime_env() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// ICICLE_SNARK_BACKTRACE=1: print the native stack of a crashing thread (the HIP runtime's callback threads carry no
+// Python frames) before the default action takes over
+static void isnark_segv(int sig)
+{
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+__attribute__((constructor)) static void isnark_runtime_env()
+{
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  if (getenv("ICICLE_SNARK_BACKTRACE")) {
+    signal(SIGSEGV, isnark_segv);
+    signal(SIGBUS, isnark_segv);
+  }
+}
 
 namespace isnark {
 
