@@ -779,12 +779,19 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   }
   P_HIP(hipEventRecord(z->ev[2], gq));
   mark("qap");
-  P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
+  static const int early_cfg = getenv("ICICLE_SNARK_EARLY") ? atoi(getenv("ICICLE_SNARK_EARLY")) : -1;
+  // Witness MSMs of small circuits (domain up to 2^19) leave the GPU far from full: they start right
+  // after the witness sort instead of waiting for the QAP (200 k constraints: 3.71 → 3.51 ms, 400 k: 6.69 → 6.24 ms; the QAP
+  // itself slows down — 1.1 → 3.9 ms at 400 k — which is why the large ones are held back: 800 k: 9.87 → 10.27 ms).
+  // ICICLE_SNARK_EARLY=<max scalars> moves the threshold (0 = never).
+  const uint32_t early_max = early_cfg >= 0 ? (uint32_t)early_cfg : (1u << 19);
+  const bool early = wlen <= early_max && n <= early_max; // shards of a large circuit keep the full-size inverse transform: neutral there
+  if (!early) P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
 
   // ---- stream g2: G2 bucket stages.  Held back until the QAP front end is done: the G2 accumulation
   // fills every CU with ~4 ms workgroups, and the NTT passes of the (longer) g1 chain measured 8× slower
   // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
-  P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
+  if (!early) P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
   fill(prof[2], plan_w, 1);
   P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len())); // commitment_b — src/proof_helper.rs:206
   (void)hipEventRecord(prof[2]->ev[3], g2);
@@ -811,7 +818,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
     MsmProfile* p = prof[order[k]];
     fill(p, plan_w, 0);
     P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
-    if (k) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
+    if (k && !early) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
     (void)hipEventRecord(p->ev[0], st3[k]);
     P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len()));
     (void)hipEventRecord(p->ev[3], st3[k]);
