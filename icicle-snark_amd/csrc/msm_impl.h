@@ -250,14 +250,31 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C
     }
     tri = CL::x_add(tri, m);
   }
-  tri = block_reduce_lazy<C>(tri, sh, blockDim.x);
   // `internal`: the partial sums go to msm_partials_fold_kernel (internal encoding, no conversion); else they are final
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = internal ? CL::x_store_internal(tri) : CL::x_store(tri);
-  if (emit_line) {
-    // table mode: the pseudo-windows are slices of ONE bucket set, the tail also needs Σ B_b of every slice
+  if (!emit_line) {
+    tri = block_reduce_lazy<C>(tri, sh, blockDim.x);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = internal ? CL::x_store_internal(tri) : CL::x_store(tri);
+    return;
+  }
+  // table mode: the pseudo-windows are slices of ONE bucket set, the tail also needs Σ B_b of every slice.  The two tree
+  // sums run side by side — the lower half of the workgroup folds the weighted sums, the upper half the plain ones (the
+  // launch provides 2·blockDim LDS entries) — log₂(blockDim) additions on the chain instead of twice that.
+  X* sb = sh + blockDim.x;
+  sh[threadIdx.x] = tri;
+  sb[threadIdx.x] = line;
+  __syncthreads();
+  const int half = blockDim.x >> 1;
+  const bool upper = half && (int)threadIdx.x >= half;
+  X* arr = upper ? sb : sh;
+  const int i = upper ? (int)threadIdx.x - half : (int)threadIdx.x;
+  for (int st = half; st > 0; st >>= 1) {
+    if (i < st) arr[i] = CL::x_add(arr[i], arr[i + st]);
     __syncthreads();
-    line = block_reduce_lazy<C>(line, sh, blockDim.x);
-    if (threadIdx.x == 0) partials[(size_t)gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = internal ? CL::x_store_internal(line) : CL::x_store(line);
+  }
+  if (threadIdx.x == 0) {
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partials[slot] = internal ? CL::x_store_internal(sh[0]) : CL::x_store(sh[0]);
+    partials[(size_t)gridDim.y * gridDim.x + slot] = internal ? CL::x_store_internal(sb[0]) : CL::x_store(sb[0]);
   }
 }
 
@@ -640,7 +657,9 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
       hipLaunchKernelGGL((msm_partials_fold_scan_kernel<C>), dim3(g.Wb), dim3(rs.bpw), lds_f, s, raw.p, rs.bpw, d_partials);
     }
   } else {
-    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), rs.rblock * sizeof(LX), s, buckets.p, g.NBb, rs.k_log, red_out, g.tab, rs.bpw > 1 ? 1 : 0);
+    const size_t lds_r = (g.tab ? 2 : 1) * (size_t)rs.rblock * sizeof(LX);
+    allow_big_lds(msm_bucket_reduce_kernel<C>, lds_r);
+    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, red_out, g.tab, rs.bpw > 1 ? 1 : 0);
     if (rs.bpw > 1) hipLaunchKernelGGL((msm_partials_fold_kernel<C>), dim3(g.Wb, g.tab ? 2 : 1), dim3(rs.bpw), rs.bpw * sizeof(LX), s, raw.p, rs.bpw, d_partials);
   }
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
