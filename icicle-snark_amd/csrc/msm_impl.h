@@ -224,57 +224,99 @@ __device__ __forceinline__ typename Lazy<C>::type::X block_reduce_lazy(typename 
   return v;
 }
 
-// Σ_b (b+1)·B_b per window.  grid = (blocks per window, W); each thread owns K = 2^k_log buckets.
-// Buckets arrive in the internal encoding; partial sums leave as ec.h XYZZ (Montgomery R = 2^256) for the tails.
+// two tree sums side by side over n ≤ blockDim entries (n a power of two): the lower half of the workgroup folds sa, the
+// upper half sb (only if `both`) — log₂ n additions on the chain.  Results in sa[0], sb[0]; ends with a barrier.
 template <class C>
-__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials, int emit_line, int internal)
+__device__ __forceinline__ void block_dual_tree(typename Lazy<C>::type::X* sa, typename Lazy<C>::type::X* sb, int n, bool both)
+{
+  typedef typename Lazy<C>::type CL;
+  const int half = n >> 1;
+  const bool upper = half && (int)threadIdx.x >= half;
+  typename CL::X* arr = upper ? sb : sa;
+  const int i = upper ? (int)threadIdx.x - half : (int)threadIdx.x;
+  for (int st = half; st > 0; st >>= 1) {
+    if (i < st && (both || !upper)) arr[i] = CL::x_add(arr[i], arr[i + st]);
+    __syncthreads();
+  }
+}
+
+// "last workgroup folds": a workgroup publishes its results, takes a ticket of its window, and the one that draws the
+// last ticket sums the window's gridDim.x results — no separate fold launch, whose waves (392 registers for G2) could only
+// start on a SIMD that the running accumulations had drained completely (G2 fold at 1.6 M constraints: 1.4 ms, nearly
+// all of it waiting).  Returns true in the workgroup that has to fold (after an agent-scope fence: the others' stores
+// are visible).
+__device__ __forceinline__ bool last_workgroup_of_window(uint32_t* tickets)
+{
+  __shared__ uint32_t s_ticket;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_ticket = atomicAdd(tickets + blockIdx.y, 1u);
+  }
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return false;
+  __threadfence();
+  return true;
+}
+
+// Σ_b (b+1)·B_b per window.  grid = (workgroups per window, W); each thread owns K = 2^k_log buckets.
+// Buckets arrive in the internal encoding; the window sums leave as ec.h XYZZ (Montgomery R = 2^256) for the tails:
+// out = [Σ_b (b+1)·B_b | Σ_b B_b (emit_line: table mode, the windows are slices of ONE bucket set and the tail needs both)].
+// raw / tickets: scratch for the per-workgroup results (internal encoding) and one zeroed counter per window, used when
+// gridDim.x > 1.
+template <class C>
+__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ out, int emit_line,
+                                                                typename C::X* raw, uint32_t* tickets)
 {
   typedef typename Lazy<C>::type CL;
   typedef typename CL::X X;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   X* sh = reinterpret_cast<X*>(smem);
+  X* sb = sh + blockDim.x;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // thread within the window
   const uint32_t base = t << k_log;
   const typename C::X* B = buckets + (size_t)blockIdx.y * NB + base;
-  X line = CL::x_zero(), tri = CL::x_zero();
-  for (int j = (1 << k_log) - 1; j >= 0; j--) {
-    line = CL::x_add(line, CL::x_load_internal(B[j]));
-    tri = CL::x_add(tri, line);
-  }
-  // + base·line  (double-and-add, MSB first)
-  if (base != 0 && !CL::x_is_zero(line)) {
-    X m = CL::x_zero();
-    for (int bit = 31 - __clz(base); bit >= 0; bit--) {
-      m = CL::x_dbl(m);
-      if ((base >> bit) & 1) m = CL::x_add(m, line);
+  {
+    X line = CL::x_zero(), tri = CL::x_zero();
+    for (int j = (1 << k_log) - 1; j >= 0; j--) {
+      line = CL::x_add(line, CL::x_load_internal(B[j]));
+      tri = CL::x_add(tri, line);
     }
-    tri = CL::x_add(tri, m);
+    // + base·line  (double-and-add, MSB first)
+    if (base != 0 && !CL::x_is_zero(line)) {
+      X m = CL::x_zero();
+      for (int bit = 31 - __clz(base); bit >= 0; bit--) {
+        m = CL::x_dbl(m);
+        if ((base >> bit) & 1) m = CL::x_add(m, line);
+      }
+      tri = CL::x_add(tri, m);
+    }
+    sh[threadIdx.x] = tri;
+    if (emit_line) sb[threadIdx.x] = line;
   }
-  // `internal`: the partial sums go to msm_partials_fold_kernel (internal encoding, no conversion); else they are final
-  if (!emit_line) {
-    tri = block_reduce_lazy<C>(tri, sh, blockDim.x);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = internal ? CL::x_store_internal(tri) : CL::x_store(tri);
+  __syncthreads();
+  block_dual_tree<C>(sh, sb, (int)blockDim.x, emit_line != 0);
+  const size_t nw = gridDim.y, bpw = gridDim.x;
+  if (bpw == 1) {
+    if (threadIdx.x == 0) {
+      out[blockIdx.y] = CL::x_store(sh[0]);
+      if (emit_line) out[nw + blockIdx.y] = CL::x_store(sb[0]);
+    }
     return;
   }
-  // table mode: the pseudo-windows are slices of ONE bucket set, the tail also needs Σ B_b of every slice.  The two tree
-  // sums run side by side — the lower half of the workgroup folds the weighted sums, the upper half the plain ones (the
-  // launch provides 2·blockDim LDS entries) — log₂(blockDim) additions on the chain instead of twice that.
-  X* sb = sh + blockDim.x;
-  sh[threadIdx.x] = tri;
-  sb[threadIdx.x] = line;
-  __syncthreads();
-  const int half = blockDim.x >> 1;
-  const bool upper = half && (int)threadIdx.x >= half;
-  X* arr = upper ? sb : sh;
-  const int i = upper ? (int)threadIdx.x - half : (int)threadIdx.x;
-  for (int st = half; st > 0; st >>= 1) {
-    if (i < st) arr[i] = CL::x_add(arr[i], arr[i + st]);
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    partials[slot] = internal ? CL::x_store_internal(sh[0]) : CL::x_store(sh[0]);
-    partials[(size_t)gridDim.y * gridDim.x + slot] = internal ? CL::x_store_internal(sb[0]) : CL::x_store(sb[0]);
+    raw[(size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(sh[0]);
+    if (emit_line) raw[nw * bpw + (size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(sb[0]);
+  }
+  if (!last_workgroup_of_window(tickets)) return;
+  if (threadIdx.x < bpw) {
+    sh[threadIdx.x] = CL::x_load_internal(raw[(size_t)blockIdx.y * bpw + threadIdx.x]);
+    if (emit_line) sb[threadIdx.x] = CL::x_load_internal(raw[nw * bpw + (size_t)blockIdx.y * bpw + threadIdx.x]);
+  }
+  __syncthreads();
+  block_dual_tree<C>(sh, sb, (int)bpw, emit_line != 0);
+  if (threadIdx.x == 0) {
+    out[blockIdx.y] = CL::x_store(sh[0]);
+    if (emit_line) out[nw + blockIdx.y] = CL::x_store(sb[0]);
   }
 }
 
@@ -485,27 +527,15 @@ ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu)
   const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256;   // LDS tree buffer ≤ 36 KiB
   while (k < 4 && (uint64_t)g.Wb * (g.NBb >> k) / rb_max > 128) k++; // ≤ 128 partial sums per kind for the host tail
   r.k_log = k < lnb ? k : lnb;
-  r.tpw = g.NBb >> r.k_log;                              // reduce threads per (pseudo-)window
-  r.rblock = r.tpw < rb_max ? r.tpw : rb_max;
-  r.bpw = r.tpw / r.rblock;
+  for (;; r.k_log++) {
+    r.tpw = g.NBb >> r.k_log;                            // reduce threads per (pseudo-)window
+    r.rblock = r.tpw < rb_max ? r.tpw : rb_max;
+    r.bpw = r.tpw / r.rblock;
+    if (r.bpw <= r.rblock) break; // the workgroup that finishes a window last folds its bpw results with one thread each
+  }
   r.scan = g.tab && L <= MSM_SCAN_REDUCE_MAX_L;
   r.M = r.scan && r.bpw > 1 ? r.rblock << r.k_log : 0;
   return r;
-}
-
-// the partial sums of one (pseudo-)window's workgroups → one sum, on the device: the tails then see one element per
-// window and kind (a host thread needed 1.3 ms for the 256 G2 additions of a small bucket set)
-template <class C>
-__global__ __launch_bounds__(256) void msm_partials_fold_kernel(const typename C::X* __restrict__ raw, uint32_t bpw, typename C::X* __restrict__ out)
-{
-  typedef typename Lazy<C>::type CL;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typename CL::X* sh = reinterpret_cast<typename CL::X*>(smem);
-  // on the lazy field like the reduction itself: the 8×32 G2 addition (out-of-line Fq2 calls, scratch) made this tiny
-  // kernel take 1.9 ms next to a running accumulation
-  typename CL::X v = CL::x_load_internal(raw[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * bpw + threadIdx.x]);
-  v = block_reduce_lazy<C>(v, sh, (int)bpw);
-  if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = CL::x_store(v);
 }
 
 // Suffix scan + two concurrent tree sums over one workgroup, shared by the bucket reduction and the fold of its
@@ -553,10 +583,11 @@ __device__ __forceinline__ typename Lazy<C>::type::X block_weighted_sums(typenam
 // additions instead of 2K + 1.5·log₂(first index) + 2·log₂(blockDim), the factor M is applied by the host tail.  The
 // suffix scan costs blockDim·log₂(blockDim) additions per workgroup, which is why the large (work-bound) bucket sets
 // stay with msm_bucket_reduce_kernel.
-// final = 1 (one workgroup per window): partials = [TRI | LINE][window] as ec.h XYZZ (Montgomery R = 2^256) for the
-// tails.  final = 0: partials = [TRI | LINE][window][workgroup] in the internal encoding for msm_partials_fold_scan_kernel.
+// One workgroup per window: out = [TRI | LINE][window] as ec.h XYZZ (Montgomery R = 2^256) for the tails.  Several: the
+// workgroup that draws the window's last ticket folds the others' results (raw, internal encoding) into [TT | L | LL][window].
 template <class C>
-__global__ __launch_bounds__(256) void msm_bucket_reduce_scan_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ partials, int final)
+__global__ __launch_bounds__(256) void msm_bucket_reduce_scan_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ out, typename C::X* raw,
+                                                                     uint32_t* tickets)
 {
   typedef typename Lazy<C>::type CL;
   typedef typename CL::X X;
@@ -575,42 +606,32 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_scan_kernel(const typen
     sb[threadIdx.x] = line;
   }
   __syncthreads();
-  const X total = block_weighted_sums<C>(sa, sb, (int)blockDim.x);
+  X total = block_weighted_sums<C>(sa, sb, (int)blockDim.x);
+  const size_t nw = gridDim.y, bpw = gridDim.x;
   if (threadIdx.x == 0) {
     X w = sb[0]; // Σ_t t·line_t; thread t's first bucket is t·K
     for (int j = 0; j < k_log; j++) w = CL::x_dbl(w);
     const X tri = CL::x_add(sa[0], w);
-    const size_t nw = gridDim.y, slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (final) {
-      partials[blockIdx.y] = CL::x_store(tri);
-      partials[nw + blockIdx.y] = CL::x_store(total);
+    if (bpw == 1) {
+      out[blockIdx.y] = CL::x_store(tri);
+      out[nw + blockIdx.y] = CL::x_store(total);
     } else {
-      partials[slot] = CL::x_store_internal(tri);
-      partials[nw * gridDim.x + slot] = CL::x_store_internal(total);
+      raw[(size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(tri);
+      raw[nw * bpw + (size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(total);
     }
   }
-}
-
-// scan variant of the fold: the per-workgroup results of one (pseudo-)window → [TT | L | LL][window] for the host
-// tail: TT = Σ_x TRI_x, L = Σ_x LINE_x, LL = Σ_x x·LINE_x (the window's weighted sum is TT + M·LL, M = buckets per
-// reduction workgroup).  grid = windows, block = workgroups per window (a power of two).
-template <class C>
-__global__ __launch_bounds__(256) void msm_partials_fold_scan_kernel(const typename C::X* __restrict__ raw, uint32_t bpw, typename C::X* __restrict__ out)
-{
-  typedef typename Lazy<C>::type CL;
-  typedef typename CL::X X;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  X* sa = reinterpret_cast<X*>(smem);
-  X* sb = sa + bpw;
-  const size_t nw = gridDim.x;
-  sa[threadIdx.x] = CL::x_load_internal(raw[(size_t)blockIdx.x * bpw + threadIdx.x]);
-  sb[threadIdx.x] = CL::x_load_internal(raw[nw * bpw + (size_t)blockIdx.x * bpw + threadIdx.x]);
+  if (bpw == 1 || !last_workgroup_of_window(tickets)) return;
+  // the last workgroup of the window: [TT | L | LL] = Σ_x TRI_x, Σ_x LINE_x, Σ_x x·LINE_x (the host applies M to LL)
+  if (threadIdx.x < bpw) {
+    sa[threadIdx.x] = CL::x_load_internal(raw[(size_t)blockIdx.y * bpw + threadIdx.x]);
+    sb[threadIdx.x] = CL::x_load_internal(raw[nw * bpw + (size_t)blockIdx.y * bpw + threadIdx.x]);
+  }
   __syncthreads();
-  const X total = block_weighted_sums<C>(sa, sb, (int)bpw);
+  total = block_weighted_sums<C>(sa, sb, (int)bpw);
   if (threadIdx.x == 0) {
-    out[blockIdx.x] = CL::x_store(sa[0]);
-    out[nw + blockIdx.x] = CL::x_store(total);
-    out[2 * nw + blockIdx.x] = CL::x_store(sb[0]);
+    out[blockIdx.y] = CL::x_store(sa[0]);
+    out[nw + blockIdx.y] = CL::x_store(total);
+    out[2 * nw + blockIdx.y] = CL::x_store(sb[0]);
   }
 }
 
@@ -641,26 +662,22 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
   WsScoped<X> raw;
-  X* red_out = d_partials;
+  WsScoped<uint32_t> tickets;
   if (rs.bpw > 1) {
-    HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * (g.tab ? 2 : 1), s), ICICLE_ALLOCATION_FAILED);
-    red_out = raw.p;
+    // per-workgroup results + one ticket counter per window: the workgroup that finishes a window last folds it
+    HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * 2, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(tickets.alloc((size_t)g.Wb, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMemsetAsync(tickets.p, 0, (size_t)g.Wb * sizeof(uint32_t), s), ICICLE_UNKNOWN_ERROR);
   }
   typedef typename Lazy<C>::type::X LX;
+  const size_t lds_r = 2 * (size_t)rs.rblock * sizeof(LX);
   if (rs.scan) {
     // small table-mode set: [TT | L | LL] (LL only with more than one workgroup per slice; the host applies M)
-    const size_t lds_r = 2 * (size_t)rs.rblock * sizeof(LX), lds_f = 2 * (size_t)rs.bpw * sizeof(LX);
     allow_big_lds(msm_bucket_reduce_scan_kernel<C>, lds_r);
-    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, red_out, rs.bpw > 1 ? 0 : 1);
-    if (rs.bpw > 1) {
-      allow_big_lds(msm_partials_fold_scan_kernel<C>, lds_f);
-      hipLaunchKernelGGL((msm_partials_fold_scan_kernel<C>), dim3(g.Wb), dim3(rs.bpw), lds_f, s, raw.p, rs.bpw, d_partials);
-    }
+    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, raw.p, tickets.p);
   } else {
-    const size_t lds_r = (g.tab ? 2 : 1) * (size_t)rs.rblock * sizeof(LX);
     allow_big_lds(msm_bucket_reduce_kernel<C>, lds_r);
-    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, red_out, g.tab, rs.bpw > 1 ? 1 : 0);
-    if (rs.bpw > 1) hipLaunchKernelGGL((msm_partials_fold_kernel<C>), dim3(g.Wb, g.tab ? 2 : 1), dim3(rs.bpw), rs.bpw * sizeof(LX), s, raw.p, rs.bpw, d_partials);
+    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, g.tab, raw.p, tickets.p);
   }
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
