@@ -827,11 +827,15 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   P_HIP(hipEventRecord(z->ev_g4done, z->s_g4));
   P_HIP(hipEventRecord(z->ev_g5done, z->s_g5));
   mark("abc");
-  // H: behind A on g1 for the large circuits (measured at 1.6 M constraints: five concurrent accumulations are slower
-  // than four followed by one, 17.7 vs 17.4 ms); on g3 right behind its own sort for the small ones and for multi-GPU
+  // H: behind one of the witness MSMs for the large circuits (measured at 1.6 M constraints: five concurrent accumulations
+  // are slower than four followed by one, 17.7 vs 17.4 ms) — behind B1, whose accumulation is the first of the three G1
+  // ones to start and to finish (behind A: +0.1 ms, behind C: +0.4 ms; ICICLE_SNARK_H_BEHIND=0/1/2); on g3 right behind its own sort for the small ones and for multi-GPU
   // shards, where the GPU is far from full and only the length of the chains counts (200 k: 4.3 → 3.9 ms)
-  hipStream_t gh = z->H.len() <= (1u << 19) ? g3 : g1;
-  if (gh == g1) P_HIP(hipStreamWaitEvent(g1, z->ev_sort_h, 0));
+  static const int h_behind_cfg = getenv("ICICLE_SNARK_H_BEHIND") ? atoi(getenv("ICICLE_SNARK_H_BEHIND")) : 1; // 0 = A, 1 = B1, 2 = C
+  const int h_behind = h_behind_cfg < 0 || h_behind_cfg > 2 ? 1 : h_behind_cfg;
+  const bool h_own = z->H.len() <= (1u << 19);
+  hipStream_t gh = h_own ? g3 : st3[h_behind];
+  if (!h_own) P_HIP(hipStreamWaitEvent(gh, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
   (void)hipEventRecord(prof[4]->ev[3], gh);
@@ -844,10 +848,10 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Ww, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
   const size_t sizes[5] = {by1, by1, by2, by1, byh};
   hipStream_t st5[5] = {st3[0], st3[1], g2, st3[2], gh};
-  if (gh == g1) {
-    // the A copy must not wait for H (same stream): A's partials were complete at its ev[3], copy them on g3 instead
-    P_HIP(hipStreamWaitEvent(g3, prof[0]->ev[3], 0));
-    st5[0] = g3;
+  if (!h_own) {
+    // the copy of the MSM in front of H must not wait for H (same stream): its partials were complete at its ev[3], copy them on g3 instead
+    P_HIP(hipStreamWaitEvent(g3, prof[order[h_behind]]->ev[3], 0));
+    st5[order[h_behind]] = g3;
   }
   for (int k = 0; k < 5; k++) {
     P_HIP(hipMemcpyAsync(z->h_partials + k * PARTIALS_STRIDE, DP + k * PARTIALS_STRIDE, sizes[k], hipMemcpyDeviceToHost, st5[k]));
