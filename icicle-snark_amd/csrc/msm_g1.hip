@@ -12,9 +12,9 @@ size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
   // the workgroups' partial sums are folded on the device: one element per window and kind [S | L (table mode) | LL (M > 0)]
   return (size_t)pl->g.Wb * (g2 ? sizeof(G2::X) : sizeof(G1::X)) * (pl->g.tab ? (rs.M ? 3 : 2) : 1);
 }
-eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len)
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len, int ticket_slot)
 {
-  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_partials, prof);
+  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_partials, prof, ticket_slot);
 }
 eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
 {

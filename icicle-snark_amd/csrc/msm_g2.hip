@@ -3,9 +3,9 @@
 #include "msm_impl.h"
 
 namespace isnark {
-eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len)
+eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len, int ticket_slot)
 {
-  return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_partials, prof);
+  return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_partials, prof, ticket_slot);
 }
 eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
 {

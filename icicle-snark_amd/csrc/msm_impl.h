@@ -644,7 +644,7 @@ inline void allow_big_lds(K kernel, size_t bytes)
 
 // stages 4, 4b, 5 for one base set
 template <class C>
-eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof)
+eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof, int ticket_slot = 0)
 {
   typedef typename C::X X;
   const MsmGeom& g = pl->g;
@@ -662,22 +662,28 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
   WsScoped<X> raw;
-  WsScoped<uint32_t> tickets;
+  WsScoped<uint32_t> own_tickets;
+  uint32_t* tickets = nullptr;
   if (rs.bpw > 1) {
-    // per-workgroup results + one ticket counter per window: the workgroup that finishes a window last folds it
+    // per-workgroup results + one ticket counter per window: the workgroup that finishes a window last folds it.  The
+    // counters were zeroed with the sort's own (a memset here is one more launch on a latency chain)
     HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * 2, s), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(tickets.alloc((size_t)g.Wb, s), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(hipMemsetAsync(tickets.p, 0, (size_t)g.Wb * sizeof(uint32_t), s), ICICLE_UNKNOWN_ERROR);
+    if (g.Wb <= 64 && ticket_slot >= 0 && ticket_slot < MSM_TICKET_SLOTS && pl->tickets) tickets = pl->tickets + ticket_slot * 64;
+    else {
+      HIP_TRY(own_tickets.alloc((size_t)g.Wb, s), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(hipMemsetAsync(own_tickets.p, 0, (size_t)g.Wb * sizeof(uint32_t), s), ICICLE_UNKNOWN_ERROR);
+      tickets = own_tickets.p;
+    }
   }
   typedef typename Lazy<C>::type::X LX;
   const size_t lds_r = 2 * (size_t)rs.rblock * sizeof(LX);
   if (rs.scan) {
     // small table-mode set: [TT | L | LL] (LL only with more than one workgroup per slice; the host applies M)
     allow_big_lds(msm_bucket_reduce_scan_kernel<C>, lds_r);
-    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, raw.p, tickets.p);
+    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, raw.p, tickets);
   } else {
     allow_big_lds(msm_bucket_reduce_kernel<C>, lds_r);
-    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, g.tab, raw.p, tickets.p);
+    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, g.tab, raw.p, tickets);
   }
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;

@@ -27,6 +27,7 @@ struct MsmGeom {
 };
 
 // Result of the recode + counting-sort stage for one scalar vector (device arrays, workspace arena).
+constexpr int MSM_TICKET_SLOTS = 8;
 struct SortPlan {
   MsmGeom g;
   uint32_t L = 0, nbuckets = 0, large_thr = 0;
@@ -34,6 +35,7 @@ struct SortPlan {
   uint32_t* counts = nullptr;  // [nbuckets] entries per bucket (bucket = w·NB + |digit| − 1)
   uint32_t* offsets = nullptr; // [nbuckets] exclusive prefix sum
   uint32_t* n_large = nullptr; // [0] number of large buckets, [1] total entries, [2] number of large work items
+  uint32_t* tickets = nullptr; // [MSM_TICKET_SLOTS][64] zeroed by the sort: one counter per window for each bucket-stage run that uses this plan
   uint32_t* large_list = nullptr; // [nbuckets] ids of buckets with more than large_thr entries
   uint32_t* large_first = nullptr; // [nbuckets] first work item of each large bucket
   uint2* large_items = nullptr;   // [item_cap] (bucket, chunk) work items: a large bucket is cut into MSM_LARGE_CHUNK-entry chunks
@@ -86,8 +88,9 @@ eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form,
 void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_projective_t* out);
 void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_g2_projective_t* out);
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M);
-eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1);
-eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1);
+// `ticket_slot` < MSM_TICKET_SLOTS: every run of the bucket stages on one plan needs its own (the runs may overlap in time)
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0);
+eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0);
 // host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective
 void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out);
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out);

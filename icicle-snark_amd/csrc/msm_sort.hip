@@ -532,9 +532,10 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   const uint32_t om = oblk * ORDER_BINS, oscan = (om + SCAN_B - 1) / SCAN_B;
   // work items of large buckets: ≤ entries/CHUNK full chunks + one partial chunk per large bucket (≤ entries/thr of those)
   pl->item_cap = (uint32_t)(nentries / MSM_LARGE_CHUNK + nentries / thr + 2);
-  // layout: counts | offsets | cursor | large_list | order | large_first | n_large[4] | bsum[nblocks] | part_count[nparts] | part_start[nparts+1] |
+  // layout: counts | offsets | cursor | large_list | order | large_first | n_large[4] | tickets[TK] | bsum[nblocks] | part_count[nparts] | part_start[nparts+1] |
   //         part_cursor[nparts] | blockhist[om] | obsum[oscan] | large_items[2·item_cap]
-  const size_t head = (size_t)nb * 6 + 4 + nblocks + 3 * (size_t)nparts + 1 + om + oscan;
+  constexpr uint32_t TK = MSM_TICKET_SLOTS * 64;
+  const size_t head = (size_t)nb * 6 + 4 + TK + nblocks + 3 * (size_t)nparts + 1 + om + oscan;
   HIP_TRY(ws_alloc((void**)&pl->ws, (head + 2 * (size_t)pl->item_cap + 2) * 4, s), ICICLE_ALLOCATION_FAILED);
   pl->counts = pl->ws;
   pl->offsets = pl->counts + nb;
@@ -543,7 +544,8 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->order = pl->large_list + nb;
   pl->large_first = pl->order + nb;
   pl->n_large = pl->large_first + nb;
-  uint32_t* bsum = pl->n_large + 4;
+  pl->tickets = pl->n_large + 4;
+  uint32_t* bsum = pl->tickets + TK;
   uint32_t* part_count = bsum + nblocks;
   uint32_t* part_start = part_count + nparts;
   uint32_t* part_cursor = part_start + nparts + 1;
@@ -561,7 +563,7 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   unsigned zb = (3 * nb + 255) / 256;
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, 3 * nb); // counts | offsets | cursor
-  hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + nblocks + nparts); // n_large | bsum | part_count
+  hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + TK + nblocks + nparts); // n_large | tickets | bsum | part_count
   const unsigned lgrid = (L + 255) / 256;
   if (two_level) {
     // counts and offsets come out of the partitions: no per-digit global atomics

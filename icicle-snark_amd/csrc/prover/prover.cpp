@@ -793,7 +793,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
   if (!early) P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
   fill(prof[2], plan_w, 1);
-  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len())); // commitment_b — src/proof_helper.rs:206
+  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len(), 3)); // commitment_b — src/proof_helper.rs:206
   (void)hipEventRecord(prof[2]->ev[3], g2);
   prof[2]->valid = true;
   P_HIP(hipEventRecord(z->ev_g2done, g2));
@@ -820,7 +820,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
     P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
     if (k && !early) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
     (void)hipEventRecord(p->ev[0], st3[k]);
-    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len()));
+    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len(), k)); // ticket slots 0-2 of the witness plan (B2: 3)
     (void)hipEventRecord(p->ev[3], st3[k]);
     p->valid = true;
   }
