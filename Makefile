@@ -7,7 +7,8 @@ PKG     := icicle-snark_amd
 SRC     := $(PKG)/csrc
 LIBDIR  := $(PKG)/lib
 OBJDIR  := build/obj
-CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -Iinclude -I$(SRC) -Wno-unused-result
+EXTRA ?=
+CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -Iinclude -I$(SRC) -Wno-unused-result $(EXTRA)
 
 SRCS := $(SRC)/runtime.cpp $(SRC)/host_ffi.cpp $(SRC)/vec_ops.hip $(SRC)/ntt.hip $(SRC)/msm_sort.hip $(SRC)/msm_g1.hip $(SRC)/msm_g2.hip $(SRC)/msm_g2_acc.hip $(SRC)/microbench.hip $(wildcard $(SRC)/prover/*.cpp) $(wildcard $(SRC)/prover/*.hip)
 OBJS := $(patsubst $(SRC)/%,$(OBJDIR)/%.o,$(SRCS))
