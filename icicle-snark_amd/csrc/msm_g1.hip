@@ -1,4 +1,7 @@
 // msm_g1.hip — G1 instantiation of the MSM pipeline (see msm_impl.h).
+#ifdef G1_ACC_MIN_WAVES // experiment hook: waves per SIMD of the G1 accumulation only (make EXTRA=-DG1_ACC_MIN_WAVES=4)
+#define ACC_MIN_WAVES G1_ACC_MIN_WAVES
+#endif
 #include "msm_impl.h"
 
 namespace isnark {
