@@ -451,6 +451,22 @@ int ilog2_ceil(uint64_t x)
 
 } // namespace
 
+// Table mode: low bucket bits carried in the 32-bit entries of the two-level sort (partitions = buckets >> low).  8192
+// partitions (64 KiB of LDS cursors in the partition pass) as a rule; 16384 (128 KiB, one workgroup per CU) when only
+// that lets the entry — point index | window | low bucket bits | sign — fit: 3.2 M constraints keep c = 20 / 13 digits
+// instead of c = 19 / 14.  −1: does not fit.
+static int tab_low_bits(int c, int ib, int W)
+{
+  static const int pb_max = getenv("ICICLE_SNARK_SORT_PARTITION_BITS") ? atoi(getenv("ICICLE_SNARK_SORT_PARTITION_BITS")) : 14;
+  for (int pb = 13; pb <= (pb_max < 13 ? 13 : pb_max > 14 ? 14 : pb_max); pb++) {
+    int low = (c - 1) - pb;
+    if (low < 0) low = 0;
+    if (low > 7) continue;
+    if (ib + ilog2_ceil((uint64_t)W) + low <= 31) return low;
+  }
+  return -1;
+}
+
 MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
 {
   // window size: as the reference, ≈ log2(L) − 4 (cuda_msm.cuh:45-48), capped so that bucket magnitudes fit
@@ -467,10 +483,7 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
     int ct = 0;
     if (c_cfg <= 0) {
       for (int t = c + 4 > 20 ? 20 : c + 4; t > c; t--) {
-        int low = (t - 1) - 13;
-        if (low < 0) low = 0;
-        if (low > 7) low = 7;
-        if (ib + ilog2_ceil((uint64_t)(254 / t + 1)) + low <= 31) {
+        if (tab_low_bits(t, ib, 254 / t + 1) >= 0) {
           ct = t;
           break;
         }
@@ -521,13 +534,12 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   // bucket index = partition | low bits (≤ 128 buckets per partition; ≤ 8192 partitions: two u32 per partition in LDS)
   int low_bits = (g.c - 1) > 8 ? (g.c - 1) - 8 : 0;
   if (g.tab) {
-    low_bits = (g.c - 1) - 13;
-    if (low_bits < 0) low_bits = 0;
-    if (low_bits > 7) low_bits = 7;
+    low_bits = tab_low_bits(g.c, g.IB, g.W);
+    if (low_bits < 0) low_bits = 7; // forced c that does not fit: the two_level test below fails and the global-histogram path runs
   }
   const uint32_t NP = g.NBb >> low_bits, nparts = nb >> low_bits;
   const int idx_bits = g.tab ? g.IB + ilog2_ceil((uint64_t)g.W) : ilog2_ceil(L ? L : 1);
-  const bool two_level = idx_bits + low_bits <= 31 && low_bits <= 7 && (size_t)nparts * 8 <= 64 * 1024;
+  const bool two_level = idx_bits + low_bits <= 31 && low_bits <= 7 && (size_t)nparts * 8 <= 128 * 1024;
   const uint32_t oblk = (nb + ORDER_BINS - 1) / ORDER_BINS;           // workgroups of the size-order pass
   const uint32_t om = oblk * ORDER_BINS, oscan = (om + SCAN_B - 1) / SCAN_B;
   // work items of large buckets: ≤ entries/CHUNK full chunks + one partial chunk per large bucket (≤ entries/thr of those)
@@ -571,6 +583,7 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     if (L) hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(pgrid), dim3(PA_THREADS), (size_t)nparts * 4, s, d_scalars, L, g, mont_sc, low_bits, nparts, part_count);
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(SCAN_T), 0, s, part_count, nparts, part_start, part_cursor);
     if (L) {
+      if ((size_t)nparts * 8 > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)nparts * 8));
       hipLaunchKernelGGL(msm_partition_kernel, dim3(pgrid), dim3(PA_THREADS), (size_t)nparts * 8, s, d_scalars, L, g, mont_sc, low_bits, NP, nparts, part_cursor, tmp);
       hipLaunchKernelGGL(msm_fine_count_kernel, dim3(nparts, PB_SPLIT), dim3(256), 0, s, tmp, part_start, low_bits, pl->counts);
     }
