@@ -7,7 +7,7 @@
 //
 // Pipeline (everything is enqueued on the caller's stream, no host synchronisation):
 //  1. recode + histogram   one thread per scalar: s ↦ signed c-bit digits (d ∈ [−2^(c−1), 2^(c−1)) via
-//                          the "+H" trick, scalars with bit 253 set are negated first, so the top
+//                          the "+H" trick, scalars above (r − 1)/2 are negated first, so the top
 //                          window never carries out), per-bucket counts by global atomics.
 //                          Signed digits halve the bucket count versus the reference's unsigned
 //                          digits (cuda_msm.cuh:166-203).
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void batch_to_affine_kernel(const typename C::P
 // table mode, cold path: rows[w·n + i] = 2^(c·w)·P_i (w < W) as Montgomery-256 projective points; the caller turns
 // them into affine (batch inversion) and into the internal encoding.  One thread per base, W·c doublings.
 template <class C>
-__global__ __launch_bounds__(256) void msm_table_rows_kernel(const typename C::A* __restrict__ pts, uint32_t n, int from_form, int c, int W, typename C::P* __restrict__ rows)
+__global__ __launch_bounds__(256) void msm_table_rows_kernel(const typename C::A* __restrict__ pts, uint32_t n, int from_form, int c, int W, int wide, typename C::P* __restrict__ rows)
 {
   typedef typename Lazy<C>::type CL;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void msm_table_rows_kernel(const typename C::A
   for (int w = 0; w < W; w++) {
     rows[(size_t)w * n + i] = C::x_to_projective(CL::x_store(x)); // identity → (0, 1, 0)
     if (w + 1 < W)
-      for (int k = 0; k < c; k++) x = CL::x_dbl(x);
+      for (int k = 0; k < (w < wide ? c : c - 1); k++) x = CL::x_dbl(x); // row w + 1 sits at the bit where window w ends
   }
 }
 template <class C, class F>
@@ -456,7 +456,7 @@ eIcicleError build_table_run(const void* d_points, uint32_t n, int from_form, co
       (void)hipFree(table);
       return ICICLE_ALLOCATION_FAILED;
     }
-    hipLaunchKernelGGL((msm_table_rows_kernel<C>), dim3((n + 255) / 256), dim3(256), 0, s, (const A*)d_points, n, from_form, g.c, g.W, rows);
+    hipLaunchKernelGGL((msm_table_rows_kernel<C>), dim3((n + 255) / 256), dim3(256), 0, s, (const A*)d_points, n, from_form, g.c, g.W, g.wide, rows);
     const int chunk = 32;
     const uint64_t nthreads = (m + chunk - 1) / chunk;
     hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, rows, m, chunk, table, scratch);

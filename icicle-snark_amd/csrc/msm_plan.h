@@ -20,6 +20,11 @@ struct MsmGeom {
   // is left.  The number of mixed additions is still one per non-zero digit, but with a single bucket set the digit
   // can be 4 bits wider for the same number of buckets: 13 instead of 16 digits per 254-bit scalar (−19 % additions)
   // at the price of W× the base memory — 8 GB of the 288 GB at 1.6 M constraints.
+  // Table mode narrows the TOP windows by one bit so that the W windows cover exactly 254 bits (c = 20: seven 20-bit and six
+  // 19-bit windows instead of twelve full ones and a 14-bit top digit, whose 2^21 entries all fell into 12 K buckets — four times
+  // the average load, the waves that defined the accumulation's length): windows w < wide are c bits wide at bit c·w, the others
+  // c − 1 bits at c·wide + (c − 1)(w − wide).  Classic layout: wide = W (Horner needs equal steps).
+  int wide;
   int tab;       // 0 classic (bucket = w·NB + |d| − 1, entry = point index), 1 table mode (bucket = |d| − 1, entry = i | w << IB)
   int IB;        // table mode: bits of the point index inside an entry
   int Wb;        // bucket array viewed as Wb pseudo-windows of NBb buckets (classic: W × NB) for the reduction kernel

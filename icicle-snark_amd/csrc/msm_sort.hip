@@ -1,10 +1,11 @@
 // msm_sort.hip — stage 1-3 of the MSM pipeline (see msm_impl.h): signed-digit recoding of the scalars and
 // a counting sort of (point index | sign) by (window, bucket).
 //
-//  recode      s ↦ digits d_w ∈ [−2^(c−1), 2^(c−1)) with Σ d_w 2^(cw) = s: scalars with bit 253 set are
+//  recode      s ↦ digits d_w ∈ [−2^(c−1), 2^(c−1)) with Σ d_w 2^(cw) = s: scalars above (r − 1)/2 are
 //              negated first (s ← r − s, sign flipped), then t = s + H with H = Σ_w 2^(cw+c−1) makes
 //              d_w = ((t >> cw) & (2^c − 1)) − 2^(c−1) independent per window (W = ⌊254/c⌋ + 1 windows, the
-//              top one cannot overflow).  Signed digits halve the bucket count of the reference's unsigned
+//              top one cannot overflow; table mode narrows the top windows by one bit so that they tile the 254 bits
+//              exactly, MsmGeom.wide).  Signed digits halve the bucket count of the reference's unsigned
 //              digits (cuda_msm.cuh:166-203).
 //  histogram   one global atomic per non-zero digit into counts[w·NB + |d| − 1]            (2 MiB of counters at c = 16: L2-resident)
 //  scan        exclusive prefix sum, three small kernels (block sums / top / finish) + list of large buckets
@@ -53,7 +54,18 @@ __device__ __forceinline__ void recode(const fe* scalars, uint32_t i, const MsmG
 {
   fe s = ld_fe(scalars + i);
   if (mont) s = Fr::from_mont(s);
-  neg = (s.l[7] >> 29) & 1; // bit 253
+  // s > (r − 1)/2 is replaced by r − s: the value recoded is then ≤ (r − 1)/2 < 0.756·2^253, which leaves the top window —
+  // exactly the scalar's last bits in table mode — room for its half-range offset and a carry
+  constexpr uint32_t HALF[8] = {0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+  neg = 0;
+  bool decided = false;
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    if (!decided && s.l[k] != HALF[k]) {
+      neg = s.l[k] > HALF[k] ? 1u : 0u;
+      decided = true;
+    }
+  }
   if (neg) s = Fr::neg(s);
   uint64_t c = 0;
 #pragma unroll
@@ -67,12 +79,13 @@ __device__ __forceinline__ void recode(const fe* scalars, uint32_t i, const MsmG
 // signed digit of window w: 0 for a zero digit, else |d| with the sign in bit 31
 __device__ __forceinline__ uint32_t digit(const uint32_t t[9], int w, const MsmGeom& g)
 {
-  const int bit = w * g.c;
+  const int cw = w < g.wide ? g.c : g.c - 1;
+  const int bit = w < g.wide ? w * g.c : g.wide * g.c + (w - g.wide) * (g.c - 1);
   const int limb = bit >> 5, off = bit & 31;
   uint64_t v = t[limb];
   if (limb < 8) v |= (uint64_t)t[limb + 1] << 32;
-  const uint32_t raw = (uint32_t)(v >> off) & ((1u << g.c) - 1);
-  const int32_t d = (int32_t)raw - (int32_t)g.NB;
+  const uint32_t raw = (uint32_t)(v >> off) & ((1u << cw) - 1);
+  const int32_t d = (int32_t)raw - (int32_t)(1u << (cw - 1));
   if (d == 0) return 0;
   return d < 0 ? ((uint32_t)(-d) | 0x80000000u) : (uint32_t)d;
 }
@@ -507,9 +520,14 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
     g.NBb = g.NB;
     g.Wb = g.W;
   }
+  g.wide = g.W;
+  if (g.tab) {
+    const int spare = g.W * c - 254; // ≥ 0: bits the W windows cover beyond the 254 of a scalar
+    if (c >= 5) g.wide = g.W - (spare < g.W ? spare : g.W); // a 3-bit top window would have no room for offset + carry
+  }
   uint32_t H[10] = {0};
   for (int w = 0; w < g.W; w++) {
-    const int bit = w * c + c - 1;
+    const int bit = (w < g.wide ? w * c : g.wide * c + (w - g.wide) * (c - 1)) + (w < g.wide ? c : c - 1) - 1;
     H[bit >> 5] |= 1u << (bit & 31);
   }
   memcpy(g.H, H, sizeof g.H);

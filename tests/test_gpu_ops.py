@@ -226,6 +226,22 @@ def test_msm_degenerate(gpu, O):
     assert not K.ec("g1", "to_affine", K.msm("g1", sc, b2)).any()
 
 
+@pytest.mark.parametrize("c", [0, 5, 8, 16])
+def test_msm_edge_scalars(gpu, O, c):
+    """recoding limits: scalars around the negation threshold (r − 1)/2, around 2^253, r − 1, all-ones low parts"""
+    K = gpu
+    R = O.R_MOD
+    half = (R - 1) // 2
+    vals = [half, half + 1, half - 1, (1 << 253) - 1, 1 << 253, (1 << 253) + 1, R - 1, R - 2, 1, 0, (1 << 252) - 1,
+            (half >> 230 << 230) - 1, (1 << 240) - 1, ((1 << 253) - 1) ^ (1 << 19)]
+    vals = vals + [(R - v) % R for v in vals]
+    rng = np.random.default_rng(4)
+    bases = _bases(O, "g1", rng, len(vals))
+    sc = O.ints_to_arr(vals)
+    got = K.ec("g1", "to_affine", K.msm("g1", sc, bases, c=c))
+    assert np.array_equal(got, O.ec_to_affine("g1", O.msm("g1", sc, bases)))
+
+
 @pytest.mark.parametrize("grp", ["g1", "g2"])
 def test_generator_mul(gpu, O, grp):
     K = gpu

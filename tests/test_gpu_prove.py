@@ -210,3 +210,26 @@ def test_repeated_and_opposite_points_in_one_bucket(gpu, cm, O, S):
     proof, public = O.groth16_prove(zkey2, wtns, 3, 9)
     assert json.loads(pj) == proof and json.loads(qj) == public
     cm.evict("degenerate")
+
+
+def test_edge_scalars_in_the_witness(gpu, cm, O, S):
+    """signed-digit recoding at its limits on the prover's table path (the windows tile the 254 bits exactly there):
+    witness values around (r − 1)/2 — the negation threshold —, around 2^253, r − 1, and values whose low bits are all
+    ones (carries through every window).  Not a satisfying witness; the proof is compared with the oracle's."""
+    K = gpu
+    r1, w = S.squaring_chain(400)
+    zkey, _ = S.setup(r1, _fbm(K), points_to_mont=lambda a: O.fq_convert_montgomery(a, True))
+    R = O.R_MOD
+    half = (R - 1) // 2
+    edge = [half, half + 1, half - 1, half + 2, (1 << 253) - 1, 1 << 253, (1 << 253) + 1, R - 1, R - 2, 1, 2,
+            half - (half % (1 << 200)) - 1, (half >> 230 << 230) - 1, (1 << 252) - 1, (1 << 240) - 1, ((1 << 253) - 1) ^ (1 << 19)]
+    w = list(w)
+    for k, v in enumerate(edge):
+        w[5 + k] = v % R
+        w[100 + k] = (R - v) % R
+    wtns = S.write_wtns(w)
+    cm.load("edge", zkey)
+    pj, qj, _ = cm.prove_mem("edge", wtns, 7, 11)
+    proof, public = O.groth16_prove(zkey, wtns, 7, 11)
+    assert json.loads(pj) == proof and json.loads(qj) == public
+    cm.evict("edge")
