@@ -17,9 +17,9 @@ void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint3
   memcpy(out, &p, sizeof p);
 }
 eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G2>(d_points, n, from_form, s); }
-void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out)
+void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, int wide, bn254_g2_projective_t* out)
 {
-  G2::P p = msm_host_tail<G2>((const G2::X*)h_partials, W, bpw, c);
+  G2::P p = msm_host_tail<G2>((const G2::X*)h_partials, W, bpw, c, wide);
   memcpy(out, &p, sizeof p);
 }
 } // namespace isnark

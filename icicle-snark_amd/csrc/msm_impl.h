@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C
 
 // window sums → Horner → projective standard form.  One workgroup of 64 threads.
 template <class C>
-__global__ __launch_bounds__(64) void msm_tail_kernel(const typename C::X* __restrict__ partials, int W, int bpw, int c, typename C::P* __restrict__ result)
+__global__ __launch_bounds__(64) void msm_tail_kernel(const typename C::X* __restrict__ partials, int W, int bpw, int c, int wide, typename C::P* __restrict__ result)
 {
   typedef typename C::X X;
   __shared__ X wsum[64];
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void msm_tail_kernel(const typename C::X* __res
   if (threadIdx.x == 0) {
     X acc = wsum[W - 1];
     for (int w = W - 2; w >= 0; w--) {
-      for (int j = 0; j < c; j++) acc = C::x_dbl(acc);
+      for (int j = 0; j < (w < wide ? c : c - 1); j++) acc = C::x_dbl(acc); // window w + 1 starts where window w ends
       acc = C::x_add(acc, wsum[w]);
     }
     typename C::P p = C::p_from_mont(C::x_to_projective(acc));
@@ -716,12 +716,12 @@ typename C::P msm_host_tail_tab(const typename C::X* part, uint32_t Wb, uint32_t
 
 // host tail: Σ partials per window, Horner, standard-form projective (identity → (0,1,0))
 template <class C>
-typename C::P msm_host_tail(const typename C::X* part, uint32_t W, uint32_t bpw, int c)
+typename C::P msm_host_tail(const typename C::X* part, uint32_t W, uint32_t bpw, int c, int wide)
 {
   typedef typename C::X X;
   X acc = C::x_zero();
   for (int w = (int)W - 1; w >= 0; w--) {
-    for (int j = 0; j < c; j++) acc = C::x_dbl(acc);
+    for (int j = 0; j < (w < wide ? c : c - 1); j++) acc = C::x_dbl(acc); // window w + 1 starts where window w ends
     X ws = C::x_zero();
     for (uint32_t k = 0; k < bpw; k++) ws = C::x_add(ws, part[(size_t)w * bpw + k]);
     acc = C::x_add(acc, ws);
@@ -737,7 +737,7 @@ struct alignas(64) TailSlot {
   unsigned char partials[64 * 256]; // W ≤ 64 windows (c ≥ 4) of ≤ 256-byte XYZZ
   unsigned char result[192];
   void* host_dst; // result requested in host memory: written by the host function itself
-  int W, c;
+  int W, c, wide;
 };
 constexpr int TAIL_SLOTS = 128; // ring: a slot is reused after 128 further MSM calls of this process
 inline TailSlot* tail_slot_next()
@@ -759,7 +759,7 @@ template <class C>
 void host_tail_callback(void* ud)
 {
   TailSlot* t = (TailSlot*)ud;
-  typename C::P p = msm_host_tail<C>((const typename C::X*)t->partials, (uint32_t)t->W, 1, t->c);
+  typename C::P p = msm_host_tail<C>((const typename C::X*)t->partials, (uint32_t)t->W, 1, t->c, t->wide);
   memcpy(t->result, &p, sizeof p);
   if (t->host_dst) memcpy(t->host_dst, &p, sizeof p);
 }
@@ -814,6 +814,7 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     if (slot) {
       slot->W = pl.g.W;
       slot->c = pl.g.c;
+      slot->wide = pl.g.wide;
       slot->host_dst = cfg->are_results_on_device ? nullptr : (void*)(results + bi);
       HIP_TRY(hipMemcpyAsync(slot->partials, partials.p, (size_t)pl.g.W * sizeof(X), hipMemcpyDeviceToHost, s), ICICLE_COPY_FAILED);
       HIP_TRY(hipLaunchHostFunc(s, host_tail_callback<C>, slot), ICICLE_UNKNOWN_ERROR);
@@ -826,7 +827,7 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
         HIP_TRY(dres.alloc(1, s), ICICLE_ALLOCATION_FAILED);
         dst = dres.p;
       }
-      hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, 1, pl.g.c, dst);
+      hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, 1, pl.g.c, pl.g.wide, dst);
       ICICLE_TRY(check_launch("msm_tail"));
       if (!cfg->are_results_on_device) {
         HIP_TRY(hipMemcpyAsync(results + bi, dres.p, sizeof(P), hipMemcpyDeviceToHost, s), ICICLE_COPY_FAILED);

@@ -23,7 +23,7 @@ struct MsmGeom {
   // Table mode narrows the TOP windows by one bit so that the W windows cover exactly 254 bits (c = 20: seven 20-bit and six
   // 19-bit windows instead of twelve full ones and a 14-bit top digit, whose 2^21 entries all fell into 12 K buckets — four times
   // the average load, the waves that defined the accumulation's length): windows w < wide are c bits wide at bit c·w, the others
-  // c − 1 bits at c·wide + (c − 1)(w − wide).  Classic layout: wide = W (Horner needs equal steps).
+  // c − 1 bits at c·wide + (c − 1)(w − wide).  Classic layout: only when the top digit would be 1–3 bits short (msm_geometry); its Horner tails double c or c − 1 times.
   int wide;
   int tab;       // 0 classic (bucket = w·NB + |d| − 1, entry = point index), 1 table mode (bucket = |d| − 1, entry = i | w << IB)
   int IB;        // table mode: bits of the point index inside an entry
@@ -97,8 +97,8 @@ size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0);
 eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0);
 // host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective
-void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_projective_t* out);
-void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, bn254_g2_projective_t* out);
+void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, int wide, bn254_projective_t* out);
+void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, int wide, bn254_g2_projective_t* out);
 
 // G2 bucket accumulation, compiled with inlined Fq2 arithmetic (msm_g2_acc.hip)
 void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, uint32_t stride, hipStream_t s, void* buckets);

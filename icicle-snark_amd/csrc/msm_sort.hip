@@ -521,9 +521,14 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
     g.Wb = g.W;
   }
   g.wide = g.W;
-  if (g.tab) {
+  {
+    // Table mode: always (one shared bucket set: nothing is lost).  Classic layout (one bucket set per window): a narrower
+    // window leaves half of its buckets empty, so only when the top digit would be 1–3 bits short — then its entries sit in
+    // 1/2 … 1/8 of a window's buckets, too few per bucket for the large-bucket path and several times the average
+    // (c = 16: a 14-bit top digit); a top digit 4 or more bits short is handled by the large-bucket kernels.
+    static const bool classic_narrow = !getenv("ICICLE_SNARK_CLASSIC_NARROW") || atoi(getenv("ICICLE_SNARK_CLASSIC_NARROW")) != 0;
     const int spare = g.W * c - 254; // ≥ 0: bits the W windows cover beyond the 254 of a scalar
-    if (c >= 5) g.wide = g.W - (spare < g.W ? spare : g.W); // a 3-bit top window would have no room for offset + carry
+    if (c >= 5 && (g.tab || (classic_narrow && spare <= 3))) g.wide = g.W - (spare < g.W ? spare : g.W); // (a 3-bit top window would have no room for offset + carry)
   }
   uint32_t H[10] = {0};
   for (int w = 0; w < g.W; w++) {

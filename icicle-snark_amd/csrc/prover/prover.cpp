@@ -871,7 +871,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
       (void)hipEventSynchronize(evd[k]);
       const MsmGeom& gg = k == 4 ? gh : gw;
       if (gg.tab) msm_g1_host_tail_tab(HP + k * PARTIALS_STRIDE, W, bpw, gg.NBb, (bn254_projective_t*)(out_points + off));
-      else msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, 1, c, (bn254_projective_t*)(out_points + off));
+      else msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, 1, c, gg.wide, (bn254_projective_t*)(out_points + off));
       if (et && k < 2) {
         while (!et->bl_ready.load(std::memory_order_acquire)) std::this_thread::yield();
         bn254_projective_t p;
@@ -889,7 +889,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[2]);
       if (gw.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Ww, bw2, gw.NBb, (bn254_g2_projective_t*)(out_points + 192));
-      else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, 1, cw, (bn254_g2_projective_t*)(out_points + 192));
+      else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, 1, cw, gw.wide, (bn254_g2_projective_t*)(out_points + 192));
     });
     g1tail(4, Wh, bh, ch, 480);
     t0.join(); t1.join(); t2.join(); t3.join();

@@ -9,6 +9,10 @@ n = 1 << logn
 rng = np.random.default_rng(0)
 sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
 sc[:, 3] &= np.uint64((1 << 61) - 1)
+if len(sys.argv) > 3 and sys.argv[3] == "modr":   # uniform mod r (what a prover sees) instead of uniform below 2^253
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    top = rng.integers(0, R >> 192, size=n, dtype=np.uint64)
+    sc[:, 3] = top
 pts = K.generator_mul(grp, sc[::-1].copy())
 d_s, d_b = K.DeviceVec.from_host(sc), K.DeviceVec.from_host(pts)
 for rep in range(3):
