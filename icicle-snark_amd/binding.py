@@ -377,7 +377,7 @@ def ntt(inp, inverse: bool, out=None, batch_size=1, size=None, stream=None, is_a
 
 # --------------------------------------------------------------------------------------------- MSM
 def msm(group: str, scalars, bases, out=None, stream=None, is_async=False, c=0, size=None,
-        scalars_mont=False, points_mont=False, ext=None, batch_size=1, shared_points=True, precompute_factor=1):
+        scalars_mont=False, points_mont=False, ext=None, batch_size=1, shared_points=True, precompute_factor=1, bitsize=0):
     """msm() — icicle-core/src/msm/mod.rs:106-154. Returns the projective result (3,4)/(6,4) u64 when `out` is None."""
     if size is None:
         size = _n_of(scalars) // batch_size
@@ -385,7 +385,7 @@ def msm(group: str, scalars, bases, out=None, stream=None, is_async=False, c=0, 
     if host_out:
         out = np.zeros(((3, 4) if group == "g1" else (6, 4)) if batch_size == 1 else ((batch_size, 3, 4) if group == "g1" else (batch_size, 6, 4)), dtype=np.uint64)
     cfg = MSMConfig.default()
-    cfg.c = c
+    cfg.c, cfg.bitsize = c, bitsize
     cfg.batch_size, cfg.are_points_shared_in_batch, cfg.precompute_factor = batch_size, shared_points, precompute_factor
     cfg.are_scalars_on_device, cfg.are_points_on_device, cfg.are_results_on_device = _on_dev(scalars), _on_dev(bases), _on_dev(out)
     cfg.are_scalars_montgomery_form, cfg.are_points_montgomery_form = scalars_mont, points_mont
@@ -397,13 +397,13 @@ def msm(group: str, scalars, bases, out=None, stream=None, is_async=False, c=0, 
     return out
 
 
-def msm_precompute_bases(group: str, bases: np.ndarray, precompute_factor: int, c=0, points_mont=False) -> np.ndarray:
+def msm_precompute_bases(group: str, bases: np.ndarray, precompute_factor: int, c=0, points_mont=False, bitsize=0) -> np.ndarray:
     """msm_precompute_bases — icicle-core/src/msm/mod.rs:156-190 (host arrays in and out)"""
     per = 64 if group == "g1" else 128
     n = bases.nbytes // per
     out = np.empty((n * precompute_factor,) + bases.shape[1:], dtype=np.uint64)
     cfg = MSMConfig.default()
-    cfg.c, cfg.precompute_factor, cfg.are_points_montgomery_form = c, precompute_factor, points_mont
+    cfg.c, cfg.precompute_factor, cfg.are_points_montgomery_form, cfg.bitsize = c, precompute_factor, points_mont, bitsize
     name = "bn254_msm_precompute_bases" if group == "g1" else "bn254_g2_msm_precompute_bases"
     check(getattr(lib(), name)(ptr_of(np.ascontiguousarray(bases)), C.c_int(n), C.byref(cfg), ptr_of(out)), name)
     return out

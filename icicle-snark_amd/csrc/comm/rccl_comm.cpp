@@ -33,6 +33,7 @@ int fail(const char* what, int code)
 } // namespace
 
 API const char* icicle_snark_rccl_last_error(void) { return g_err; }
+API int icicle_snark_rccl_destroy(void* comm);
 
 // rank 0 creates the id (128 bytes) and shares it with the other ranks out of band
 API int icicle_snark_rccl_unique_id(uint8_t out[NCCL_UNIQUE_ID_BYTES])
@@ -55,10 +56,16 @@ API int icicle_snark_rccl_init(const uint8_t id_bytes[NCCL_UNIQUE_ID_BYTES], int
   memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
   ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank", (int)r); }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate", -1);
-  if (hipMalloc((void**)&c->d_in, max_bytes_per_rank) != hipSuccess) return fail("hipMalloc", -1);
-  if (hipMalloc((void**)&c->d_out, max_bytes_per_rank * world) != hipSuccess) return fail("hipMalloc", -1);
-  if (hipHostMalloc((void**)&c->h_pin, max_bytes_per_rank * (world + 1)) != hipSuccess) return fail("hipHostMalloc", -1);
+  // any failure from here on releases what was created so far (communicator, stream, buffers)
+  const char* what = nullptr;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) what = "hipStreamCreate";
+  else if (hipMalloc((void**)&c->d_in, max_bytes_per_rank) != hipSuccess) what = "hipMalloc(d_in)";
+  else if (hipMalloc((void**)&c->d_out, max_bytes_per_rank * world) != hipSuccess) what = "hipMalloc(d_out)";
+  else if (hipHostMalloc((void**)&c->h_pin, max_bytes_per_rank * (world + 1)) != hipSuccess) what = "hipHostMalloc";
+  if (what) {
+    (void)icicle_snark_rccl_destroy(c);
+    return fail(what, -1);
+  }
   *out = c;
   return 0;
 }
@@ -100,12 +107,12 @@ API int icicle_snark_rccl_destroy(void* comm)
   Comm* c = (Comm*)comm;
   if (!c) return 0;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
-  ncclCommDestroy(c->comm);
-  (void)hipFree(c->d_in);
-  (void)hipFree(c->d_out);
-  (void)hipHostFree(c->h_pin);
-  (void)hipStreamDestroy(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->d_in) (void)hipFree(c->d_in);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }

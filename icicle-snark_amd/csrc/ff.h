@@ -118,6 +118,12 @@ struct Fp {
     }
     return (uint32_t)b;
   }
+  // a < MOD (a canonical residue)
+  static FF_HD bool is_canonical(const fe& a)
+  {
+    fe t;
+    return sub_mod_raw(t, a) != 0;
+  }
   // conditional final subtraction: a in [0, 2p) -> [0, p)
   static FF_HD fe reduce_once(const fe& a)
   {

@@ -739,21 +739,59 @@ struct alignas(64) TailSlot {
   void* host_dst; // result requested in host memory: written by the host function itself
   int W, c, wide;
 };
-constexpr int TAIL_SLOTS = 128; // ring: a slot is reused after 128 further MSM calls of this process
-inline TailSlot* tail_slot_next()
+// Ring of pinned slots.  A slot is in use from tail_slot_acquire() until the event its user records behind the last
+// stream operation that touches it (tail_slot_commit) has completed: a caller that keeps more than TAIL_SLOTS
+// asynchronous MSMs in flight gets nullptr and falls back to the device tail instead of overwriting a slot whose copy
+// or host function is still pending.
+constexpr int TAIL_SLOTS = 128;
+struct TailRing {
+  std::mutex mu;
+  TailSlot* slots = nullptr;
+  hipEvent_t ev[TAIL_SLOTS] = {};
+  unsigned char state[TAIL_SLOTS] = {}; // 0 never used / known free, 1 acquired (no event yet), 2 event recorded
+  unsigned next = 0;
+  bool failed = false;
+};
+inline TailRing& tail_ring()
 {
-  static TailSlot* ring = nullptr;
-  static std::atomic<unsigned> next{0};
-  static std::mutex mu;
-  if (!ring) {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!ring) {
-      TailSlot* p = nullptr;
-      if (hipHostMalloc((void**)&p, sizeof(TailSlot) * TAIL_SLOTS, hipHostMallocPortable) != hipSuccess) return nullptr;
-      ring = p;
+  static TailRing r;
+  return r;
+}
+inline TailSlot* tail_slot_acquire()
+{
+  TailRing& r = tail_ring();
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (r.failed) return nullptr;
+  if (!r.slots) {
+    TailSlot* p = nullptr;
+    if (hipHostMalloc((void**)&p, sizeof(TailSlot) * TAIL_SLOTS, hipHostMallocPortable) != hipSuccess) {
+      r.failed = true;
+      return nullptr;
     }
+    for (int i = 0; i < TAIL_SLOTS; i++)
+      if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) {
+        r.failed = true;
+        return nullptr;
+      }
+    r.slots = p;
   }
-  return ring + (next.fetch_add(1) % TAIL_SLOTS);
+  for (int k = 0; k < TAIL_SLOTS; k++) {
+    const unsigned i = (r.next + k) % TAIL_SLOTS;
+    if (r.state[i] == 1) continue;
+    if (r.state[i] == 2 && hipEventQuery(r.ev[i]) != hipSuccess) continue; // still in flight
+    r.state[i] = 1;
+    r.next = i + 1;
+    return r.slots + i;
+  }
+  return nullptr;
+}
+// all stream work that uses the slot has been enqueued on s
+inline void tail_slot_commit(TailSlot* t, hipStream_t s)
+{
+  TailRing& r = tail_ring();
+  std::lock_guard<std::mutex> lk(r.mu);
+  const size_t i = (size_t)(t - r.slots);
+  r.state[i] = hipEventRecord(r.ev[i], s) == hipSuccess ? 2 : 0;
 }
 template <class C>
 void host_tail_callback(void* ud)
@@ -778,7 +816,7 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   typedef typename C::P P;
   static_assert(sizeof(A) == sizeof(AT) && sizeof(P) == sizeof(PT), "ABI layout");
   if (!cfg || !results || (msm_size > 0 && (!scalars || !bases))) return ICICLE_INVALID_POINTER;
-  if (msm_size < 0 || cfg->batch_size < 0 || cfg->precompute_factor < 0) return ICICLE_INVALID_ARGUMENT;
+  if (msm_size < 0 || cfg->batch_size < 0 || cfg->precompute_factor < 0 || cfg->bitsize < 0 || cfg->bitsize > 254) return ICICLE_INVALID_ARGUMENT;
   ICICLE_TRY(require_device());
   hipStream_t s = (hipStream_t)cfg->stream;
   const uint32_t L = (uint32_t)msm_size;
@@ -798,7 +836,7 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     prof = msm_profile_next();
     SortPlan pl;
     (void)hipEventRecord(prof->ev[0], s);
-    ICICLE_TRY(msm_sort_run(ss.ptr<fe>() + (size_t)bi * L, L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl));
+    ICICLE_TRY(msm_sort_run(ss.ptr<fe>() + (size_t)bi * L, L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl, 0, cfg->bitsize, (int)stride));
     prof->L = L;
     prof->nbuckets = pl.nbuckets;
     prof->c = pl.g.c;
@@ -806,19 +844,22 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     prof->is_g2 = sizeof(A) > 64;
     const ReduceShape rs = reduce_shape<X>(pl.g);
     WsScoped<X> partials;
-    HIP_TRY(partials.alloc((size_t)pl.g.W, s), ICICLE_ALLOCATION_FAILED);
+    const int Wt = pl.g.Wb; // windows left for the tail (= W, or ⌈W / f⌉ with precomputed bases)
+    HIP_TRY(partials.alloc((size_t)Wt, s), ICICLE_ALLOCATION_FAILED);
     (void)rs;
     const A* pts = sb.ptr<A>() + (shared ? 0 : (size_t)bi * L * stride);
-    ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, stride, s, partials.p, prof));
-    TailSlot* slot = pl.g.W <= 64 ? tail_slot_next() : nullptr;
+    ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, 1, s, partials.p, prof)); // the sort entries index the (precomputed) base array directly
+    TailSlot* slot = Wt <= 64 ? tail_slot_acquire() : nullptr;
     if (slot) {
-      slot->W = pl.g.W;
+      slot->W = Wt;
       slot->c = pl.g.c;
-      slot->wide = pl.g.wide;
+      slot->wide = pl.g.wide < Wt ? pl.g.wide : Wt;
       slot->host_dst = cfg->are_results_on_device ? nullptr : (void*)(results + bi);
-      HIP_TRY(hipMemcpyAsync(slot->partials, partials.p, (size_t)pl.g.W * sizeof(X), hipMemcpyDeviceToHost, s), ICICLE_COPY_FAILED);
-      HIP_TRY(hipLaunchHostFunc(s, host_tail_callback<C>, slot), ICICLE_UNKNOWN_ERROR);
-      if (cfg->are_results_on_device) HIP_TRY(hipMemcpyAsync(results + bi, slot->result, sizeof(P), hipMemcpyHostToDevice, s), ICICLE_COPY_FAILED);
+      hipError_t he = hipMemcpyAsync(slot->partials, partials.p, (size_t)Wt * sizeof(X), hipMemcpyDeviceToHost, s);
+      if (he == hipSuccess) he = hipLaunchHostFunc(s, host_tail_callback<C>, slot);
+      if (he == hipSuccess && cfg->are_results_on_device) he = hipMemcpyAsync(results + bi, slot->result, sizeof(P), hipMemcpyHostToDevice, s);
+      tail_slot_commit(slot, s); // on every path: the slot is free again once what was enqueued has run
+      HIP_TRY(he, ICICLE_COPY_FAILED);
     } else {
       // no pinned slot: single-lane Horner on the device (2.5 ms G1 / 9 ms G2)
       WsScoped<P> dres;
@@ -827,7 +868,7 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
         HIP_TRY(dres.alloc(1, s), ICICLE_ALLOCATION_FAILED);
         dst = dres.p;
       }
-      hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, pl.g.W, 1, pl.g.c, pl.g.wide, dst);
+      hipLaunchKernelGGL((msm_tail_kernel<C>), dim3(1), dim3(64), 0, s, partials.p, Wt, 1, pl.g.c, pl.g.wide < Wt ? pl.g.wide : Wt, dst);
       ICICLE_TRY(check_launch("msm_tail"));
       if (!cfg->are_results_on_device) {
         HIP_TRY(hipMemcpyAsync(results + bi, dres.p, sizeof(P), hipMemcpyDeviceToHost, s), ICICLE_COPY_FAILED);
@@ -887,8 +928,8 @@ eIcicleError precompute_impl(const AT* bases, int nof_bases, const MSMConfig* cf
   ICICLE_TRY(sb.in(bases, (size_t)n * sizeof(A), cfg->are_points_on_device, s));
   ICICLE_TRY(so.out(out, (size_t)n * f * sizeof(A), cfg->are_results_on_device, s));
   if (n) {
-    const MsmGeom g = msm_geometry(n, cfg->c);
-    const int shift = g.c * ((g.W + f - 1) / f);
+    const MsmGeom g = msm_geometry(n, cfg->c, 0, cfg->bitsize, f);
+    const int shift = g.c * g.nbms;
     const uint64_t m = (uint64_t)n * f;
     WsScoped<P> proj;
     WsScoped<typename F::T> scratch;

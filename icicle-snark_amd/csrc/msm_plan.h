@@ -27,8 +27,13 @@ struct MsmGeom {
   int wide;
   int tab;       // 0 classic (bucket = w·NB + |d| − 1, entry = point index), 1 table mode (bucket = |d| − 1, entry = i | w << IB)
   int IB;        // table mode: bits of the point index inside an entry
-  int Wb;        // bucket array viewed as Wb pseudo-windows of NBb buckets (classic: W × NB) for the reduction kernel
+  int Wb;        // bucket array viewed as Wb pseudo-windows of NBb buckets (classic: nbms × NB) for the reduction kernel
   uint32_t NBb;
+  // Classic layout with precomputed bases (MSMConfig.precompute_factor = pf > 1, icicle/include/icicle/msm.h:23-27): the
+  // caller's base array holds pf points per base, [pf·i + j] = 2^(j·c·nbms)·P_i (msm_precompute_bases), so window w adds
+  // point j = w / nbms into the bucket set of window w mod nbms: nbms = ⌈W / pf⌉ bucket sets to reduce and a Horner tail
+  // of nbms windows instead of W.  pf = 1: nbms = W.
+  int pf, nbms;
 };
 
 // Result of the recode + counting-sort stage for one scalar vector (device arrays, workspace arena).
@@ -56,11 +61,13 @@ struct SortPlan {
 
 // geometry for a length-L MSM (c_cfg > 0 forces the window size); tab != 0 asks for the table mode (falls back to
 // the classic layout when the entry encoding would not fit)
-MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab = 0);
+// `bits` (MSMConfig.bitsize, msm.h:32-34): every scalar is < 2^bits — W = ⌊bits / c⌋ + 1 windows instead of ⌊254 / c⌋ + 1
+// (0 = the scalar field's 254); `pf`: precompute factor of the base array (classic layout only).
+MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab = 0, int bits = 0, int pf = 1);
 // recode → histogram → scan → scatter on stream s.  Workspace comes from the arena of stream s and is
 // returned by msm_sort_release (which only marks it reusable by later work on that stream; idempotent, also
 // run by ~SortPlan).
-eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl, int tab = 0);
+eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl, int tab = 0, int bits = 0, int pf = 1);
 void msm_sort_release(SortPlan* pl);
 
 // ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,

@@ -91,8 +91,18 @@ __device__ __forceinline__ uint32_t digit(const uint32_t t[9], int w, const MsmG
 }
 
 // bucket of digit magnitude bk+1 of window w, and the entry that names the point
-__device__ __forceinline__ uint32_t bucket_id(const MsmGeom& g, int w, uint32_t bk) { return g.tab ? bk : (uint32_t)w * g.NB + bk; }
-__device__ __forceinline__ uint32_t entry_idx(const MsmGeom& g, int w, uint32_t i) { return g.tab ? (i | ((uint32_t)w << g.IB)) : i; }
+// (classic layout with precomputed bases: window w uses multiple j = w / nbms of the base and the bucket set w mod nbms)
+__device__ __forceinline__ uint32_t bucket_id(const MsmGeom& g, int w, uint32_t bk)
+{
+  if (g.tab) return bk;
+  const int wm = g.pf > 1 ? w % g.nbms : w;
+  return (uint32_t)wm * g.NB + bk;
+}
+__device__ __forceinline__ uint32_t entry_idx(const MsmGeom& g, int w, uint32_t i)
+{
+  if (g.tab) return i | ((uint32_t)w << g.IB);
+  return g.pf > 1 ? i * (uint32_t)g.pf + (uint32_t)(w / g.nbms) : i;
+}
 
 // zero `n` u32 words (a kernel instead of hipMemsetAsync keeps every dependency on the compute queue)
 __global__ __launch_bounds__(256) void msm_zero_kernel(uint32_t* __restrict__ p, uint32_t n)
@@ -480,8 +490,11 @@ static int tab_low_bits(int c, int ib, int W)
   return -1;
 }
 
-MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
+MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab, int bits, int pf)
 {
+  if (bits <= 0 || bits > 254) bits = 254;
+  if (pf < 1) pf = 1;
+  if (bits != 254 || pf > 1) tab = 0; // the table mode belongs to the prover's cached keys: full-width scalars, own tables
   // window size: as the reference, ≈ log2(L) − 4 (cuda_msm.cuh:45-48), capped so that bucket magnitudes fit
   // 15 bits + sign
   MsmGeom g;
@@ -511,14 +524,16 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
   }
   g.tab = tab ? 1 : 0;
   g.c = c;
-  g.W = 254 / c + 1;
+  g.W = bits / c + 1; // the top window holds the remaining bits + the carry of the signed recoding
   g.NB = 1u << (c - 1);
+  g.pf = g.tab ? 1 : pf;
+  g.nbms = (g.W + g.pf - 1) / g.pf;
   if (g.tab) {
     g.NBb = g.NB > 32768u ? 32768u : g.NB;
     g.Wb = (int)(g.NB / g.NBb);
   } else {
     g.NBb = g.NB;
-    g.Wb = g.W;
+    g.Wb = g.nbms;
   }
   g.wide = g.W;
   {
@@ -528,7 +543,9 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
     // (c = 16: a 14-bit top digit); a top digit 4 or more bits short is handled by the large-bucket kernels.
     static const bool classic_narrow = !getenv("ICICLE_SNARK_CLASSIC_NARROW") || atoi(getenv("ICICLE_SNARK_CLASSIC_NARROW")) != 0;
     const int spare = g.W * c - 254; // ≥ 0: bits the W windows cover beyond the 254 of a scalar
-    if (c >= 5 && (g.tab || (classic_narrow && spare <= 3))) g.wide = g.W - (spare < g.W ? spare : g.W); // (a 3-bit top window would have no room for offset + carry)
+    // (only for full-width scalars — the argument rests on the recoded value being ≤ (r − 1)/2 — and equal windows are what
+    //  the shift c·nbms of precomputed bases assumes)
+    if (bits == 254 && g.pf == 1 && c >= 5 && (g.tab || (classic_narrow && spare <= 3))) g.wide = g.W - (spare < g.W ? spare : g.W); // (a 3-bit top window would have no room for offset + carry)
   }
   uint32_t H[10] = {0};
   for (int w = 0; w < g.W; w++) {
@@ -539,16 +556,16 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab)
   return g;
 }
 
-eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl, int tab)
+eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl, int tab, int bits, int pf)
 {
-  pl->g = msm_geometry(L, c_cfg, tab);
+  pl->g = msm_geometry(L, c_cfg, tab, bits, pf);
   const MsmGeom& g = pl->g;
   pl->L = L;
   pl->stream = s;
   const uint32_t nb = g.NBb * (uint32_t)g.Wb;
   pl->nbuckets = nb;
   // large-bucket threshold (the reference: large_bucket_factor(10) × average, cuda_msm.cuh:205-220)
-  const uint64_t avg = (g.tab ? (uint64_t)L * g.W : (uint64_t)L) / g.NB + 1;
+  const uint64_t avg = (g.tab ? (uint64_t)L * g.W : (uint64_t)L * g.pf) / g.NB + 1;
   uint32_t thr = (uint32_t)(avg * (uint64_t)(lbf > 0 ? lbf : 10));
   if (thr < 512) thr = 512;
   pl->large_thr = thr;
@@ -561,7 +578,11 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     if (low_bits < 0) low_bits = 7; // forced c that does not fit: the two_level test below fails and the global-histogram path runs
   }
   const uint32_t NP = g.NBb >> low_bits, nparts = nb >> low_bits;
-  const int idx_bits = g.tab ? g.IB + ilog2_ceil((uint64_t)g.W) : ilog2_ceil(L ? L : 1);
+  const int idx_bits = g.tab ? g.IB + ilog2_ceil((uint64_t)g.W) : ilog2_ceil((L ? (uint64_t)L : 1) * g.pf);
+  if (idx_bits > 31) {
+    set_last_error("msm: %u scalars x precompute_factor %d exceed the 31-bit point index of a sort entry", L, g.pf);
+    return ICICLE_INVALID_ARGUMENT;
+  }
   const bool two_level = idx_bits + low_bits <= 31 && low_bits <= 7 && (size_t)nparts * 8 <= 128 * 1024;
   const uint32_t oblk = (nb + ORDER_BINS - 1) / ORDER_BINS;           // workgroups of the size-order pass
   const uint32_t om = oblk * ORDER_BINS, oscan = (om + SCAN_B - 1) / SCAN_B;

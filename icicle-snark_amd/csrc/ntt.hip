@@ -21,6 +21,7 @@
 //    multiply yields the standard-form product directly.
 //  * per element each pass reads 32 B and writes 32 B: 64·P bytes of HBM traffic per element
 //    (P = number of passes), the twiddle table (N·32 B) is L2/Infinity-Cache resident.
+#include <atomic>
 #include <mutex>
 #include <string.h>
 #include <vector>
@@ -48,8 +49,18 @@ struct Domain {
   fe root_std;
   int device = -1;
 };
+// one domain per device (the reference's CUDA backend keeps `domains_for_devices`, ntt.cuh:441-450); every entry point
+// below works on the domain of the calling thread's active device
+constexpr int MAX_DEVICES = 32;
 std::mutex g_dom_mu;
-Domain g_dom;
+Domain g_doms[MAX_DEVICES];
+Domain& cur_dom() // caller holds g_dom_mu
+{
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+  return g_doms[d];
+}
+#define g_dom cur_dom()
 
 fe host_omega(int logn) // Fr::omega — modular_arithmetic.h:61-73 ; standard form in/out
 {
@@ -414,7 +425,8 @@ ISNARK_API eIcicleError bn254_ntt_release_domain(void)
     (void)hipDeviceSynchronize();
     (void)hipFree(g_dom.tw);
   }
-  g_dom = Domain();
+  Domain& d = g_dom;
+  d = Domain();
   return ICICLE_SUCCESS;
 }
 
@@ -578,10 +590,11 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
       tiles = tpg * mid;
     }
     const size_t lds = ((size_t)2 << (p.log_r + p.log_c)) * 16 + (size_t)(R >> 1) * 32 + 32;
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
+    static std::atomic<bool> lds_attr_set[MAX_DEVICES]; // function attributes are per device
+    const int devi = dom.device >= 0 && dom.device < MAX_DEVICES ? dom.device : 0;
+    if (!lds_attr_set[devi].load(std::memory_order_acquire)) {
       HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);
-      lds_attr_set = true;
+      lds_attr_set[devi].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(NT), lds, s, src, dst, dom.tw, p, ninv);
     ICICLE_TRY(check_launch("ntt_pass"));

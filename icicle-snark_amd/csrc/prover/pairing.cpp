@@ -306,6 +306,8 @@ struct JParser {
   const char* p;
   const char* end;
   bool ok = true;
+  int depth = 0; // nesting of the value being parsed; a proof / key nests 3 deep, hostile input must not exhaust the stack
+  static constexpr int MAX_DEPTH = 32;
   void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
   std::string str()
   {
@@ -322,6 +324,8 @@ struct JParser {
   JVal val()
   {
     JVal v;
+    if (depth >= MAX_DEPTH) { ok = false; return v; }
+    struct Nest { int& d; Nest(int& x) : d(x) { d++; } ~Nest() { d--; } } nest(depth);
     ws();
     if (p >= end) { ok = false; return v; }
     if (*p == '"') { v.t = JVal::STR; v.s = str(); }
@@ -388,21 +392,49 @@ bool dec_to_fe(const std::string& s, fe* out) // decimal string → 256-bit stan
   memcpy(out->l, w, 32);
   return true;
 }
+// The reference deserialises whatever it is given (src/conversions.rs:58-96).  A verifier that takes proofs from an
+// untrusted prover has to validate: coordinates must be canonical residues (< q), points must lie on the curve — for G2
+// also in the order-r subgroup (the twist has a cofactor) — and public signals must be < r (x and x + r would verify
+// alike: the aliasing snarkjs guards against).  (0, 0) stays the identity encoding it is everywhere else in this ABI.
+bool g1_valid(const G1::A& a) // Montgomery form
+{
+  if (G1::aff_is_zero(a)) return true;
+  fe three = Fq::zero();
+  three.l[0] = 3;
+  const fe rhs = Fq::add(Fq::mul(Fq::sqr(a.x), a.x), Fq::to_mont(three));
+  return Fq::eq(Fq::sqr(a.y), rhs);
+}
+bool g2_valid(const G2::A& a) // Montgomery form: on the twist y² = x³ + 3/ξ and killed by r
+{
+  if (G2::aff_is_zero(a)) return true;
+  const f2 rhs = F2::add(F2::mul(F2::sqr(a.x), a.x), K().b_twist);
+  if (!F2::eq(F2::sqr(a.y), rhs)) return false;
+  const G2::A std_a = {Fq2Ops::from_mont(a.x), Fq2Ops::from_mont(a.y)};
+  bn254_g2_projective_t P, Q;
+  bn254_g2_from_affine((const bn254_g2_affine_t*)&std_a, &P);
+  const fe r = Fr::modulus();
+  bn254_g2_mul_scalar(&P, (const bn254_scalar_t*)&r, &Q); // plain windowed double-and-add over the 254 bits of r
+  const fe2* z = reinterpret_cast<const fe2*>(&Q) + 2;
+  return Fq2Ops::is_zero(*z);
+}
 bool read_g1(const JVal* v, G1::A* out) // deserialize_g1_affine — src/conversions.rs:58-70
 {
   if (!v || v->t != JVal::ARR || v->a.size() < 2) return false;
   fe x, y;
   if (!dec_to_fe(v->a[0].s, &x) || !dec_to_fe(v->a[1].s, &y)) return false;
+  if (!Fq::is_canonical(x) || !Fq::is_canonical(y)) return false;
   *out = {Fq::to_mont(x), Fq::to_mont(y)};
-  return true;
+  return g1_valid(*out);
 }
 bool read_g2(const JVal* v, G2::A* out) // deserialize_g2_affine — src/conversions.rs:72-96
 {
   if (!v || v->t != JVal::ARR || v->a.size() < 2 || v->a[0].a.size() < 2 || v->a[1].a.size() < 2) return false;
   fe c[4];
   if (!dec_to_fe(v->a[0].a[0].s, &c[0]) || !dec_to_fe(v->a[0].a[1].s, &c[1]) || !dec_to_fe(v->a[1].a[0].s, &c[2]) || !dec_to_fe(v->a[1].a[1].s, &c[3])) return false;
+  for (const fe& ci : c)
+    if (!Fq::is_canonical(ci)) return false;
   *out = {{Fq::to_mont(c[0]), Fq::to_mont(c[1])}, {Fq::to_mont(c[2]), Fq::to_mont(c[3])}};
-  return true;
+  return g2_valid(*out);
 }
 bool read_file(const char* path, std::string* out)
 {
@@ -518,7 +550,9 @@ __attribute__((visibility("default"))) int groth16_verify_json(const char* proof
   if (!pp.ok || !pq.ok || !pv.ok || proof.t != JVal::OBJ || pub.t != JVal::ARR || vk.t != JVal::OBJ) return vfail(-2, "malformed JSON");
   G1::A pi_a, pi_c, alpha1;
   G2::A pi_b, beta2, gamma2, delta2;
-  if (!read_g1(proof.get("pi_a"), &pi_a) || !read_g2(proof.get("pi_b"), &pi_b) || !read_g1(proof.get("pi_c"), &pi_c)) return vfail(-2, "proof: bad point");
+  (void)K(); // constants (twist coefficient) before the point checks
+  if (!read_g1(proof.get("pi_a"), &pi_a) || !read_g2(proof.get("pi_b"), &pi_b) || !read_g1(proof.get("pi_c"), &pi_c))
+    return vfail(-2, "proof: bad point (not canonical, not on the curve, or outside the r-torsion)");
   if (!read_g1(vk.get("vk_alpha_1"), &alpha1) || !read_g2(vk.get("vk_beta_2"), &beta2) || !read_g2(vk.get("vk_gamma_2"), &gamma2) || !read_g2(vk.get("vk_delta_2"), &delta2))
     return vfail(-2, "verification key: bad point");
   const JVal* ic = vk.get("IC");
@@ -538,6 +572,7 @@ __attribute__((visibility("default"))) int groth16_verify_json(const char* proof
     G1::A ai;
     fe sc;
     if (!read_g1(&ic->a[i + 1], &ai) || !dec_to_fe(pub.a[i].s, &sc)) return vfail(-2, "IC / public: bad value");
+    if (!Fr::is_canonical(sc)) return vfail(-2, "public signal is not below the scalar field modulus");
     G1::A s = {Fq::from_mont(ai.x), Fq::from_mont(ai.y)};
     bn254_projective_t pi;
     bn254_from_affine((const bn254_affine_t*)&s, &pi);

@@ -27,7 +27,9 @@
 #include <string.h>
 #include <string>
 #include <thread>
+#include <errno.h>
 #include <sys/mman.h>
+#include <sys/random.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
@@ -86,13 +88,13 @@ int read_sections(const uint8_t* data, size_t len, const char* type, uint32_t ma
   out.assign(nsec + 1 > 16 ? nsec + 1 : 16, Section());
   size_t pos = 12;
   for (uint32_t i = 0; i < nsec; i++) {
-    if (pos + 12 > len) return fail(ERR_FORMAT, "truncated section table");
+    if (len - pos < 12) return fail(ERR_FORMAT, "truncated section table");
     uint32_t ht;
     uint64_t hl;
     memcpy(&ht, data + pos, 4);
     memcpy(&hl, data + pos + 4, 8);
     pos += 12;
-    if (pos + hl > len) return fail(ERR_FORMAT, "section %u exceeds the file", ht);
+    if (hl > len - pos) return fail(ERR_FORMAT, "section %u exceeds the file", ht); // pos <= len here; `pos + hl` could wrap for a hostile 64-bit length
     if (ht < out.size()) {
       out[ht].p = data + pos;
       out[ht].size = hl;
@@ -345,12 +347,6 @@ int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint
 int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out)
 {
   if (count < 1 || rank < 0 || rank >= count) return fail(ERR_ARG, "bad shard %d/%d", rank, count);
-  IcicleDevice dev;
-  memset(&dev, 0, sizeof dev);
-  strcpy(dev.type, "HIP");
-  dev.id = device_id;
-  P_ICICLE(icicle_set_device(&dev));
-
   const bool trace = getenv("ICICLE_SNARK_TRACE_COLD") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -405,8 +401,20 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   // coefficients (section 4): {m:u32 c:u32 s:u32 value[32]} — src/cache.rs:126-166 (only byte 0 of m is read, :159)
   const size_t rec = 12 + 32;
   if (s4->size < 4 || (s4->size - 4) % rec) return fail(ERR_FORMAT, "zkey: coefficient section size");
+  if ((s4->size - 4) / rec > 0xffffffffull) return fail(ERR_FORMAT, "zkey: too many coefficients");
   const uint32_t n_coef = (uint32_t)((s4->size - 4) / rec);
-  z->n_coef = n_coef;
+  {
+    const uint64_t nv64 = z->n_vars, np1 = (uint64_t)z->n_public + 1;
+    if (s5->size != nv64 * 64 || s6->size != nv64 * 64 || s7->size != nv64 * 128 || s8->size != (nv64 - np1) * 64 || s9->size != (uint64_t)n * 64)
+      return fail(ERR_FORMAT, "zkey: point section size mismatch");
+  }
+  z->n_coef = n_coef; // from the section length, like src/cache.rs:129 (the declared count in the first 4 bytes is not read)
+  // the container and the header are validated before the device is touched (a malformed key is a format error on any host)
+  IcicleDevice dev;
+  memset(&dev, 0, sizeof dev);
+  strcpy(dev.type, "HIP");
+  dev.id = device_id;
+  P_ICICLE(icicle_set_device(&dev));
   // device CSR built by kernels from the raw records (prover/csr.hip); the records travel with the points below
   uint32_t* d_records = nullptr;
   const size_t rec_bytes = (size_t)n_coef * rec;
@@ -546,8 +554,9 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
 } // namespace
 
 struct Groth16CacheManager {
-  std::mutex mu;
-  std::map<std::string, std::unique_ptr<ZKeyCache>> cache;
+  std::mutex mu;     // serialises cache builds and proves (one device pipeline per manager)
+  std::mutex map_mu; // guards `cache`; entries are shared_ptr so that an evict cannot free a key a prove still uses
+  std::map<std::string, std::shared_ptr<ZKeyCache>> cache;
   uint32_t domain_n = 0; // domain_size the NTT domain was last initialised for (get_cache, src/cache.rs:242-256)
 };
 
@@ -576,10 +585,11 @@ double ms_since(std::chrono::steady_clock::time_point t0)
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-ZKeyCache* find(Groth16CacheManager* cm, const char* key)
+std::shared_ptr<ZKeyCache> find(Groth16CacheManager* cm, const char* key)
 {
+  std::lock_guard<std::mutex> lk(cm->map_mu);
   auto it = cm->cache.find(key ? key : "");
-  return it == cm->cache.end() ? nullptr : it->second.get();
+  return it == cm->cache.end() ? nullptr : it->second;
 }
 
 // ------------------------------------------------------------------------------------------------ JSON
@@ -617,21 +627,30 @@ __attribute__((visibility("default"))) void groth16_cache_manager_free(Groth16Ca
 
 __attribute__((visibility("default"))) int groth16_cache_contains(const Groth16CacheManager* cm, const char* key)
 {
-  return cm && cm->cache.count(key ? key : "") ? 1 : 0;
+  return cm && find(const_cast<Groth16CacheManager*>(cm), key) ? 1 : 0;
 }
 __attribute__((visibility("default"))) void groth16_cache_evict(Groth16CacheManager* cm, const char* key)
 {
-  if (cm) cm->cache.erase(key ? key : "");
+  if (!cm) return;
+  std::shared_ptr<ZKeyCache> victim; // destroyed outside the map lock; a prove in flight keeps its own reference
+  {
+    std::lock_guard<std::mutex> lk(cm->map_mu);
+    auto it = cm->cache.find(key ? key : "");
+    if (it == cm->cache.end()) return;
+    victim = std::move(it->second);
+    cm->cache.erase(it);
+  }
 }
 
 __attribute__((visibility("default"))) int groth16_cache_load(Groth16CacheManager* cm, const char* key, const void* zkey, size_t zkey_len, int device_id, int shard_rank, int shard_count)
 {
   if (!cm || !key || !zkey) return fail(ERR_ARG, "null argument");
   std::lock_guard<std::mutex> lk(cm->mu);
-  if (cm->cache.count(key)) return 0;
+  if (find(cm, key)) return 0;
   std::unique_ptr<ZKeyCache> z;
   if (int rc = build_cache((const uint8_t*)zkey, zkey_len, device_id, shard_rank, shard_count, z)) return rc;
-  cm->cache[key] = std::move(z);
+  std::lock_guard<std::mutex> lm(cm->map_mu);
+  cm->cache[key] = std::shared_ptr<ZKeyCache>(z.release());
   return 0;
 }
 
@@ -647,9 +666,9 @@ __attribute__((visibility("default"))) int groth16_cache_load_file(Groth16CacheM
 __attribute__((visibility("default"))) int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16CircuitInfo* info)
 {
   if (!cm || !info) return fail(ERR_ARG, "null argument");
-  auto it = cm->cache.find(key ? key : "");
-  if (it == cm->cache.end()) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
-  const ZKeyCache* z = it->second.get();
+  const std::shared_ptr<ZKeyCache> zp = find(const_cast<Groth16CacheManager*>(cm), key);
+  if (!zp) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  const ZKeyCache* z = zp.get();
   info->n_vars = z->n_vars;
   info->n_public = z->n_public;
   info->domain_size = z->domain_size;
@@ -695,7 +714,8 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
 {
   if (!cm || !out_points) return fail(ERR_ARG, "null argument");
   std::lock_guard<std::mutex> lk(cm->mu);
-  ZKeyCache* z = find(cm, key);
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  ZKeyCache* z = zp.get();
   if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
   if (!wtns && !z->witness_resident) return fail(ERR_ARG, "no witness given and none resident on the device");
   const auto t0 = std::chrono::steady_clock::now();
@@ -737,6 +757,18 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));
   const uint32_t wlo = z->A.lo, wlen = z->A.len(), skip = npub + 1;
   SortPlan plan_w, plan_h;
+  // declared after the plans, so it runs before their destructors: on an error return the kernels already enqueued may
+  // still read the plans' workspace, which ~SortPlan hands back to the arena — drain the six streams first
+  struct DrainOnError {
+    ZKeyCache* z;
+    bool armed = true;
+    ~DrainOnError()
+    {
+      if (!armed) return;
+      for (hipStream_t st : {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5})
+        if (st) (void)hipStreamSynchronize(st);
+    }
+  } drain{z};
   MsmProfile* prof[5]; // A, B1, B2, C, H
   for (auto& p : prof) p = msm_profile_next();
   (void)hipEventRecord(prof[2]->ev[0], g2);
@@ -900,6 +932,8 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   P_HIP(hipStreamSynchronize(g3));
   P_HIP(hipStreamSynchronize(z->s_g4));
   P_HIP(hipStreamSynchronize(z->s_g5));
+  P_HIP(hipStreamSynchronize(z->s_qap));
+  drain.armed = false;
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
   if (tm) {
@@ -938,10 +972,42 @@ __attribute__((visibility("default"))) int groth16_sum_commitments(const uint8_t
 } // extern "C"
 
 namespace {
-void compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_in, Blinding* b)
+// Uniform scalar in [0, r) from the kernel's CSPRNG (getrandom(2), /dev/urandom as fallback): 254 random bits, rejected
+// while ≥ r (acceptance 0.756).  The reference draws r, s from an unseeded mt19937 (ScalarCfg::generate_random →
+// utils/rand_gen.h:5) — zero-knowledge must not rest on a 32-bit-seeded, predictable generator, so the production path
+// does not restate that; bn254_generate_scalars (test data, like the reference's) keeps the Mersenne twister.
+bool secure_scalar(bn254_scalar_t* out)
+{
+  for (int tries = 0; tries < 256; tries++) {
+    fe v;
+    size_t got = 0;
+    while (got < 32) {
+      const ssize_t k = getrandom((uint8_t*)v.l + got, 32 - got, 0);
+      if (k < 0) {
+        if (errno == EINTR) continue;
+        break;
+      }
+      got += (size_t)k;
+    }
+    if (got < 32) {
+      FILE* f = fopen("/dev/urandom", "rb");
+      if (!f) return false;
+      const size_t k = fread(v.l, 1, 32, f);
+      fclose(f);
+      if (k != 32) return false;
+    }
+    v.l[7] &= 0x3fffffffu;
+    if (Fr::is_canonical(v)) {
+      memcpy(out, v.l, 32);
+      return true;
+    }
+  }
+  return false;
+}
+int compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_in, Blinding* b)
 {
   bn254_scalar_t rs[2];
-  if (!r_in || !s_in) bn254_generate_scalars(rs, 2); // ScalarCfg::generate_random(2) — src/proof_helper.rs:276
+  if ((!r_in && !secure_scalar(&rs[0])) || (!s_in && !secure_scalar(&rs[1]))) return fail(ERR_IO, "no entropy source for the blinding scalars"); // src/proof_helper.rs:276
   if (r_in) memcpy(&rs[0], r_in, 32);
   if (s_in) memcpy(&rs[1], s_in, 32);
   b->r = rs[0];
@@ -952,6 +1018,7 @@ void compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_
   bn254_mul_scalar(delta1, &b->s, &b->d1s);
   bn254_mul_scalar(&b->d1r, &b->s, &b->d1rs);
   bn254_g2_mul_scalar(delta2, &b->s, &b->d2s);
+  return 0;
 }
 int assemble_impl(ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap, const EarlyTerms* et = nullptr);
 } // namespace
@@ -962,10 +1029,11 @@ __attribute__((visibility("default"))) int groth16_assemble_proof(Groth16CacheMa
                                                                   const uint8_t* r_in, const uint8_t* s_in, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap)
 {
   if (!cm || !wtns || !points) return fail(ERR_ARG, "null argument");
-  ZKeyCache* z = find(cm, key);
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  ZKeyCache* z = zp.get();
   if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
   Blinding bl;
-  compute_blinding(z, r_in, s_in, &bl);
+  if (int rc = compute_blinding(z, r_in, s_in, &bl)) return rc;
   return assemble_impl(z, wtns, wtns_len, points, bl, proof_json, proof_cap, public_json, public_cap);
 }
 
@@ -1065,19 +1133,26 @@ __attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheMa
   uint8_t pts[GROTH16_COMMITMENTS_BYTES];
   const auto t0 = std::chrono::steady_clock::now();
   if (!cm || !wtns) return fail(ERR_ARG, "null argument");
-  ZKeyCache* z = find(cm, key);
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  ZKeyCache* z = zp.get();
   if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  // A sharded cache holds only this rank's point range: its commitments are PARTIAL sums and a proof assembled from them
+  // alone would be well-formed but invalid.  The only correct sequence for shards is groth16_commitments → all-gather →
+  // groth16_sum_commitments → groth16_assemble_proof (parallel.py).
+  if (z->shard_count != 1) return fail(ERR_ARG, "cache entry '%s' is shard %d of %d: use groth16_commitments + groth16_sum_commitments + groth16_assemble_proof", key ? key : "", z->shard_rank, z->shard_count);
   // r, s and the commitment-independent blinding terms on a host thread while the GPU computes the commitments
   Blinding bl;
   EarlyTerms et;
   et.bl = &bl;
+  int bl_rc = 0;
   std::thread th([&] {
-    compute_blinding(z, r, s, &bl);
+    bl_rc = compute_blinding(z, r, s, &bl);
     et.bl_ready.store(true, std::memory_order_release);
   });
-  int rc = commitments_impl(cm, key, wtns_resident ? nullptr : wtns, wtns_len, pts, tm, z->shard_count == 1 ? &et : nullptr);
+  int rc = commitments_impl(cm, key, wtns_resident ? nullptr : wtns, wtns_len, pts, tm, &et);
   th.join();
   if (rc) return rc;
+  if (bl_rc) return fail(bl_rc, "no entropy source for the blinding scalars"); // (the message was set on the helper thread)
   rc = assemble_impl(z, wtns, wtns_len, pts, bl, proof_json, proof_cap, public_json, public_cap, &et);
   if (tm) tm->total_ms = ms_since(t0);
   return rc;
@@ -1102,7 +1177,8 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
   if (int rc = wf.open_ro(witness_path)) return rc;
   std::vector<char> pj(4096), qj(256);
   {
-    ZKeyCache* z = find(cm, key.c_str());
+    const std::shared_ptr<ZKeyCache> z = find(cm, key.c_str());
+    if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key.c_str());
     qj.resize(64 + (size_t)z->n_public * 84);
   }
   if (int rc = groth16_prove_mem(cm, key.c_str(), wf.data, wf.len, nullptr, nullptr, pj.data(), pj.size(), qj.data(), qj.size(), nullptr)) return rc;

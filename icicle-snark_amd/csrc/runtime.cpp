@@ -114,14 +114,22 @@ struct WsBlock {
   bool in_use;
 };
 static std::mutex g_ws_mu;
-static std::map<hipStream_t, std::vector<WsBlock>> g_ws;
+// keyed by (device, stream): the null stream exists on every device
+typedef std::pair<int, hipStream_t> WsKey;
+static std::map<WsKey, std::vector<WsBlock>> g_ws;
+static WsKey ws_key(hipStream_t s)
+{
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return WsKey(d, s);
+}
 
 hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s)
 {
   if (bytes == 0) bytes = 256;
   bytes = (bytes + 255) & ~(size_t)255;
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  auto& v = g_ws[s];
+  auto& v = g_ws[ws_key(s)];
   int best = -1;
   for (size_t i = 0; i < v.size(); i++)
     if (!v[i].in_use && v[i].size >= bytes && (best < 0 || v[i].size < v[best].size)) best = (int)i;
@@ -149,22 +157,27 @@ hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s)
 hipError_t ws_free(void* p, hipStream_t s)
 {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  auto& v = g_ws[s];
-  for (auto& b : v)
-    if (b.ptr == p) {
-      b.in_use = false;
-      return hipSuccess;
-    }
+  // the freeing thread's active device need not be the block's (a non-null stream belongs to exactly one device)
+  for (auto& kv : g_ws) {
+    if (kv.first.second != s) continue;
+    for (auto& b : kv.second)
+      if (b.ptr == p) {
+        b.in_use = false;
+        return hipSuccess;
+      }
+  }
   return hipErrorInvalidValue;
 }
 
 void ws_release_stream(hipStream_t s)
 {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  auto it = g_ws.find(s);
-  if (it == g_ws.end()) return;
-  for (auto& b : it->second) (void)hipFree(b.ptr);
-  g_ws.erase(it);
+  for (auto it = g_ws.begin(); it != g_ws.end();) {
+    if (it->first.second == s && (s != nullptr || it->first == ws_key(s))) {
+      for (auto& b : it->second) (void)hipFree(b.ptr);
+      it = g_ws.erase(it);
+    } else ++it;
+  }
 }
 
 } // namespace isnark

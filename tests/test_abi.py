@@ -110,3 +110,47 @@ def test_generate_scalars_in_range(K, O):
     K.lib().bn254_generate_scalars(out.ctypes.data_as(C.c_void_p), 64)
     vals = O.arr_to_ints(out)
     assert all(v < O.R_MOD for v in vals) and len(set(vals)) == 64
+
+
+def _sections(kind, secs, version=1):
+    out = kind + (version).to_bytes(4, "little") + len(secs).to_bytes(4, "little")
+    for t, ln, data in secs:
+        out += t.to_bytes(4, "little") + ln.to_bytes(8, "little") + data
+    return out
+
+
+def test_malformed_containers_are_format_errors_without_a_device(K):
+    """The snarkjs container and the zkey header are validated before the device is touched: a hostile section length
+    (pos + len wrapping past 2^64), a truncated table or a foreign magic must come back as a format error — never as
+    an out-of-bounds read (the reference, in Rust, panics safely: src/file_wrapper.rs:45-103)."""
+    cm = K.CacheManager()
+    try:
+        wrap = _sections(b"zkey", [(1, 4, (1).to_bytes(4, "little")), (2, (1 << 64) - 8, b"\0" * 64)])
+        with pytest.raises(K.ProverError, match="exceeds the file"):
+            cm.load("wrapped", wrap)
+        with pytest.raises(K.ProverError, match="exceeds the file"):
+            cm.load("huge", _sections(b"zkey", [(1, 1 << 40, b"")]))
+        with pytest.raises(K.ProverError, match="truncated section table"):
+            cm.load("trunc", b"zkey" + (1).to_bytes(4, "little") + (3).to_bytes(4, "little") + b"\1\0\0\0")
+        with pytest.raises(K.ProverError, match="Invalid File format"):
+            cm.load("magic", _sections(b"wtns", []))
+        with pytest.raises(K.ProverError, match="Version not supported"):
+            cm.load("version", _sections(b"zkey", [], version=9))
+        with pytest.raises(K.ProverError, match="Missing section"):
+            cm.load("nosec", _sections(b"zkey", [(1, 4, (1).to_bytes(4, "little"))]))
+        with pytest.raises(K.ProverError, match="Protocol not supported"):
+            cm.load("proto", _sections(b"zkey", [(1, 4, (2).to_bytes(4, "little"))]))
+    finally:
+        cm.close()
+
+
+def test_golden_zkey_with_corrupt_point_section_is_rejected_before_the_device(K):
+    import base64
+    from conftest import load_golden
+    z = bytearray(base64.b64decode(load_golden("groth16.json")["zkey"]))
+    cm = K.CacheManager()
+    try:
+        with pytest.raises(K.ProverError, match="exceeds the file|size mismatch|too short"):
+            cm.load("cut", bytes(z[:len(z) - 100]))
+    finally:
+        cm.close()

@@ -149,3 +149,49 @@ def test_msm_batch_and_precompute(gpu, O, grp):
     bm = O.fq_convert_montgomery(bases.reshape(-1, 4), True).reshape(bases.shape)
     prem = K.msm_precompute_bases(grp, bm, f, points_mont=True)
     assert np.array_equal(O.fq_convert_montgomery(prem.reshape(-1, 4), False).reshape(pre.shape), pre)
+
+
+@pytest.mark.parametrize("grp", ["g1", "g2"])
+def test_msm_bitsize_and_precompute_factor_semantics(gpu, O, grp):
+    """MSMConfig.bitsize (msm.h:32-34: scalars below 2^bitsize → fewer windows) and precompute_factor > 1 read through
+    every precomputed multiple (window w uses multiple w / nbms, bucket set w mod nbms — icicle/src/msm.cpp:45-72,
+    cuda_msm.cuh:186-203): same group element as the plain MSM, for several (c, f, bitsize)."""
+    K = gpu
+    rng = np.random.default_rng(31 if grp == "g1" else 32)
+    n = 3000
+    G = O.ec_to_affine(grp, O.ec_generator(grp))
+    bases = O.fixed_base_mul(grp, G, rand_fr(rng, n))
+    bases[7] = 0
+    sc = rand_fr(rng, n)
+    sc[0] = 0
+    sc[1, :] = np.frombuffer((O.R_MOD - 1).to_bytes(32, "little"), dtype=np.uint64)
+    want = O.ec_to_affine(grp, O.msm(grp, sc, bases))
+    for c, f in ((0, 2), (0, 4), (10, 3), (13, 7), (5, 64)):
+        pre = K.msm_precompute_bases(grp, bases, f, c=c)
+        got = K.ec(grp, "to_affine", K.msm(grp, sc, pre, size=n, precompute_factor=f, c=c))
+        assert np.array_equal(got, want), (c, f)
+    # short scalars: 64-bit and 100-bit, with the maximum value present
+    for bits in (1, 64, 100, 253):
+        s2 = sc.copy()
+        if bits <= 64:
+            s2[:, 1:] = 0
+            s2[:, 0] &= np.uint64((1 << bits) - 1)
+            s2[2, 0] = np.uint64((1 << bits) - 1)
+        elif bits == 100:
+            s2[:, 2:] = 0
+            s2[:, 1] &= np.uint64((1 << 36) - 1)
+            s2[2, 0], s2[2, 1] = np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64((1 << 36) - 1)
+        else:
+            s2[:, 3] &= np.uint64((1 << 61) - 1)
+            s2[1] = 0
+        w2 = O.ec_to_affine(grp, O.msm(grp, s2, bases))
+        for c in (0, 9):
+            got = K.ec(grp, "to_affine", K.msm(grp, s2, bases, bitsize=bits, c=c))
+            assert np.array_equal(got, w2), (bits, c)
+        if bits in (64, 100):
+            f = 3
+            pre = K.msm_precompute_bases(grp, bases, f, bitsize=bits)
+            got = K.ec(grp, "to_affine", K.msm(grp, s2, pre, size=n, precompute_factor=f, bitsize=bits))
+            assert np.array_equal(got, w2), (bits, "precompute")
+    with pytest.raises(K.IcicleError):
+        K.msm(grp, sc, bases, bitsize=300)

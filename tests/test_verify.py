@@ -108,6 +108,85 @@ def test_verify_reports_malformed_input(K, S):
         K.groth16_verify_json(pj, "[]", vkj)
 
 
+def test_verify_rejects_non_canonical_and_off_curve_input(K, S):
+    """What a verifier facing an untrusted prover must refuse (the reference deserialises anything, src/conversions.rs:58-96):
+    aliased public signals (x + r), coordinates >= q, points off the curve, G2 points outside the r-torsion, and JSON
+    nested deeply enough to exhaust a recursive parser."""
+    g, vkj = _golden_vk_json(S)
+    c = g["cases"][0]
+    pj, qj = json.dumps(c["proof"]), json.dumps(c["public"])
+    r = S.R_MOD
+    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    assert K.groth16_verify_json(pj, qj, vkj) is True
+    # public-input aliasing: x + r is the same field element, and must not verify
+    with pytest.raises(K.ProverError, match="scalar field modulus"):
+        K.groth16_verify_json(pj, json.dumps([str(int(c["public"][0]) + r)] + c["public"][1:]), vkj)
+    # coordinate >= q (x + q is the same residue)
+    bad = json.loads(pj)
+    bad["pi_a"][0] = str(int(bad["pi_a"][0]) + q)
+    with pytest.raises(K.ProverError, match="bad point"):
+        K.groth16_verify_json(json.dumps(bad), qj, vkj)
+    # G1 point off the curve
+    bad = json.loads(pj)
+    bad["pi_c"][1] = str((int(bad["pi_c"][1]) + 1) % q)
+    with pytest.raises(K.ProverError, match="bad point"):
+        K.groth16_verify_json(json.dumps(bad), qj, vkj)
+    # G2 point off the twist
+    bad = json.loads(pj)
+    bad["pi_b"][0][0] = str((int(bad["pi_b"][0][0]) + 1) % q)
+    with pytest.raises(K.ProverError, match="bad point"):
+        K.groth16_verify_json(json.dumps(bad), qj, vkj)
+    # G2 point ON the twist but outside the order-r subgroup (the twist's cofactor is 2q - r > 1): take x = 1, 2, … until
+    # x³ + 3/ξ is a square in Fq2; a random twist point lies in the subgroup with probability 1/cofactor ≈ 2^-254
+    def f2mul(a, b):
+        return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+
+    def f2inv(a):
+        d = pow(a[0] * a[0] + a[1] * a[1], -1, q)
+        return (a[0] * d % q, -a[1] * d % q)
+
+    def f2sqrt(a):
+        # q ≡ 3 (mod 4): complex method; returns None when a is not a square
+        if a[1] == 0:
+            s = pow(a[0], (q + 1) // 4, q)
+            if s * s % q == a[0]:
+                return (s, 0)
+            s = pow(-a[0] % q, (q + 1) // 4, q)
+            return (0, s) if s * s % q == -a[0] % q else None
+        n = (a[0] * a[0] + a[1] * a[1]) % q
+        sn = pow(n, (q + 1) // 4, q)
+        if sn * sn % q != n:
+            return None
+        for sgn in (1, -1):
+            t = (a[0] + sgn * sn) * pow(2, -1, q) % q
+            x0 = pow(t, (q + 1) // 4, q)
+            if x0 * x0 % q == t and x0:
+                x1 = a[1] * pow(2 * x0, -1, q) % q
+                if f2mul((x0, x1), (x0, x1)) == (a[0] % q, a[1] % q):
+                    return (x0, x1)
+        return None
+    bt = f2mul((3, 0), f2inv((9, 1)))
+    pt = None
+    for x0 in range(1, 50):
+        x = (x0, 0)
+        rhs = f2mul(f2mul(x, x), x)
+        rhs = ((rhs[0] + bt[0]) % q, (rhs[1] + bt[1]) % q)
+        y = f2sqrt(rhs)
+        if y:
+            pt = (x, y)
+            break
+    assert pt is not None
+    bad = json.loads(pj)
+    bad["pi_b"] = [[str(pt[0][0]), str(pt[0][1])], [str(pt[1][0]), str(pt[1][1])], ["1", "0"]]
+    with pytest.raises(K.ProverError, match="bad point"):
+        K.groth16_verify_json(json.dumps(bad), qj, vkj)
+    # nesting bomb: must be reported, not crash the process
+    with pytest.raises(K.ProverError, match="malformed"):
+        K.groth16_verify_json("[" * 100000 + "]" * 100000, qj, vkj)
+    with pytest.raises(K.ProverError, match="malformed"):
+        K.groth16_verify_json(pj, "[" * 100000, vkj)
+
+
 def test_verify_agrees_with_reference_on_random_circuit(K, S, O, R):
     """a second statement (random R1CS with 3 public inputs) proved by the oracle: the library and the reference's
     pairing check must agree on accept and on reject."""
