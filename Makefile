@@ -18,7 +18,7 @@ LIB := $(LIBDIR)/libicicle_snark_hip.so
 
 RCCL_LIB := $(LIBDIR)/libicicle_snark_rccl.so
 
-all: $(LIB) links prove $(RCCL_LIB)
+all: $(LIB) links prove dropin $(RCCL_LIB)
 
 $(OBJDIR)/%.o: $(SRC)/% $(HDRS)
 	@mkdir -p $(dir $@)
@@ -42,11 +42,16 @@ prove: $(LIB)
 	@if [ -f $(SRC)/prover/cli_main.cc ]; then \
 	  $(HIPCC) -O2 -std=c++17 -Iinclude -o $(LIBDIR)/prove $(SRC)/prover/cli_main.cc -L$(LIBDIR) -licicle_snark_hip -Wl,-rpath,'$$ORIGIN'; fi
 
+# the reference's Rust host restated call for call over the C ABI (only icicle_* / bn254_* exports): drop-in sequence
+# test and timing (tests/test_dropin_sequence.py, bench.py)
+dropin: $(LIB)
+	$(HIPCC) -O2 -std=c++17 -Iinclude -o $(LIBDIR)/dropin_host $(SRC)/tools/dropin_host.cc -L$(LIBDIR) -licicle_snark_hip -lpthread -Wl,-rpath,'$$ORIGIN'
+
 oracle:
 	$(MAKE) -C oracle
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -rf build $(LIBDIR)/*.so $(LIBDIR)/prove
+	rm -rf build $(LIBDIR)/*.so $(LIBDIR)/prove $(LIBDIR)/dropin_host
 
-.PHONY: all links prove oracle clean
+.PHONY: all links prove dropin oracle clean

@@ -416,8 +416,8 @@ def last_msm_timings():
 
 
 def msm_profile(back: int = 0):
-    """(ms[4], dict geom) of the `back`-th most recent MSM; see include/icicle_snark_hip.h."""
-    ms = (C.c_float * 4)()
+    """(ms[5], dict geom) of the `back`-th most recent MSM; see include/icicle_snark_hip.h."""
+    ms = (C.c_float * 5)()
     geom = (C.c_uint32 * 5)()
     check(lib().icicle_snark_msm_profile(back, ms, geom), "msm_profile")
     return list(ms), dict(L=geom[0], nbuckets=geom[1], c=geom[2], W=geom[3], is_g2=bool(geom[4]))
@@ -592,6 +592,15 @@ class CacheManager:
                                              C.c_size_t(len(pj)), qj, C.c_size_t(len(qj)), C.byref(tm)), "prove_resident")
         return pj.value.decode(), qj.value.decode(), tm
 
+    def prove_files(self, witness: str, zkey: str, proof: str, public: str, device: str = "HIP"):
+        """groth16_prove — src/lib.rs:33-61: files in, files out (the reference's timed region)"""
+        return self.prove(witness, zkey, proof, public, device)
+
+    def last_timings(self, key: str) -> Timings:
+        tm = Timings()
+        _pcheck(lib().groth16_last_timings(self._h, key.encode(), C.byref(tm)), "last_timings")
+        return tm
+
     def prove(self, witness: str, zkey: str, proof: str, public: str, device: str = "HIP"):
         """groth16_prove — src/lib.rs:33-61"""
         _pcheck(lib().groth16_prove(witness.encode(), zkey.encode(), proof.encode(), public.encode(), device.encode(), self._h), "groth16_prove")
@@ -600,7 +609,7 @@ class CacheManager:
 PROVER_SYMBOLS = """
 groth16_cache_manager_new groth16_cache_manager_free groth16_prove groth16_cache_load groth16_cache_load_file
 groth16_cache_contains groth16_cache_evict groth16_commitments groth16_sum_commitments groth16_assemble_proof
-groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error
+groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error groth16_last_timings
 groth16_verify groth16_verify_json groth16_verify_last_error
 """.split()
 

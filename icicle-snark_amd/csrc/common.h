@@ -31,6 +31,8 @@ void set_last_error(const char* fmt, ...);
 
 // True once icicle_set_device() selected the HIP device on this thread (or a default exists).
 eIcicleError require_device();
+// `p` lies inside a block handed out by icicle_malloc{,_async} (the map behind icicle_is_active_device_memory)
+bool is_tracked_device_ptr(const void* p);
 
 // Stages a host-resident operand on the device for the lifetime of the object (the reference's
 // wrappers do the same per VecOpsConfig / NTTConfig / MSMConfig flags, e.g.
@@ -45,9 +47,15 @@ class Staged
 public:
   Staged() {}
   ~Staged() { release(); }
+  // Residency is declared by the caller's flags — with one leniency the reference's own host needs: the Rust wrapper of
+  // ScalarField::from_mont passes a DEVICE buffer as the output while leaving is_result_on_device at its default, false
+  // (wrappers/rust/icicle-core/src/field.rs:379-398 → src/proof_helper.rs:79, src/cache.rs:228; the CUDA backend then
+  // "copies back" into that device pointer, cuda_mont.cuh:33-50).  A pointer that lies inside a block this runtime
+  // allocated is therefore treated as device memory whatever the flag says.
   eIcicleError in(const void* p, size_t bytes, bool on_device, hipStream_t s)
   {
     stream_ = s;
+    if (!on_device && bytes && is_tracked_device_ptr(p)) on_device = true;
     if (on_device || bytes == 0) {
       dev_ = const_cast<void*>(p);
       return ICICLE_SUCCESS;
@@ -61,6 +69,7 @@ public:
   {
     stream_ = s;
     host_out_ = nullptr;
+    if (!on_device && bytes && is_tracked_device_ptr(p)) on_device = true;
     if (on_device || bytes == 0) {
       dev_ = p;
       return ICICLE_SUCCESS;

@@ -837,6 +837,8 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     SortPlan pl;
     (void)hipEventRecord(prof->ev[0], s);
     ICICLE_TRY(msm_sort_run(ss.ptr<fe>() + (size_t)bi * L, L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl, 0, cfg->bitsize, (int)stride));
+    (void)hipEventRecord(prof->ev[4], s);
+    prof->has_sort_end = true;
     prof->L = L;
     prof->nbuckets = pl.nbuckets;
     prof->c = pl.g.c;

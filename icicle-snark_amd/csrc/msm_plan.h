@@ -73,7 +73,8 @@ void msm_sort_release(SortPlan* pl);
 // ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,
 // never synchronised here) + geometry, read back by icicle_snark_msm_profile() after the caller synced.
 struct MsmProfile {
-  hipEvent_t ev[4]; // start (sort), before accumulate, after accumulate, end
+  hipEvent_t ev[5]; // start (sort), before accumulate, after accumulate, end, end of the sort (same stream as ev[0])
+  bool has_sort_end;
   uint32_t L, nbuckets;
   int c, W, is_g2;
   bool valid;

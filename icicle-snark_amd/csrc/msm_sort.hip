@@ -33,6 +33,7 @@ MsmProfile* msm_profile_next()
   if (!p->ev[0])
     for (auto& e : p->ev) (void)hipEventCreate(&e);
   p->valid = false;
+  p->has_sort_end = false;
   g_msm_seq++;
   return p;
 }
@@ -661,9 +662,9 @@ SortPlan::~SortPlan() { msm_sort_release(this); }
 
 // Profile of the `back`-th most recent MSM (0 = latest) issued by this process.  The caller must have
 // synchronised the MSM's stream.  out_ms = {recode+sort, bucket accumulation kernel, large buckets +
-// reduction (+ device tail), total}; geom = {L, nbuckets, c, W, is_g2}.  When several base sets share one
-// sort, only the first of them carries the sort time.
-ISNARK_API eIcicleError icicle_snark_msm_profile(int back, float out_ms[4], uint32_t geom[5])
+// reduction (+ device tail), total, digit sort alone (0 when this MSM did not issue one: several base sets share one
+// sort — the prover records it with the G2 MSM for the witness and with the H MSM)}; geom = {L, nbuckets, c, W, is_g2}.
+ISNARK_API eIcicleError icicle_snark_msm_profile(int back, float out_ms[5], uint32_t geom[5])
 {
   using namespace isnark;
   if (!out_ms || !geom || back < 0 || back >= MSM_PROFILE_RING || (uint64_t)back >= g_msm_seq) return ICICLE_INVALID_ARGUMENT;
@@ -673,6 +674,8 @@ ISNARK_API eIcicleError icicle_snark_msm_profile(int back, float out_ms[4], uint
   (void)hipEventElapsedTime(&out_ms[1], p.ev[1], p.ev[2]);
   (void)hipEventElapsedTime(&out_ms[2], p.ev[2], p.ev[3]);
   (void)hipEventElapsedTime(&out_ms[3], p.ev[0], p.ev[3]);
+  out_ms[4] = 0;
+  if (p.has_sort_end) (void)hipEventElapsedTime(&out_ms[4], p.ev[0], p.ev[4]);
   geom[0] = p.L; geom[1] = p.nbuckets; geom[2] = (uint32_t)p.c; geom[3] = (uint32_t)p.W; geom[4] = (uint32_t)p.is_g2;
   return ICICLE_SUCCESS;
 }

@@ -192,6 +192,7 @@ struct ZKeyCache {
              ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
+  Groth16Timings last_tm = {0, 0, 0, 0}; // phase timings of the most recent prove (groth16_last_timings)
 
   ~ZKeyCache()
   {
@@ -663,6 +664,16 @@ __attribute__((visibility("default"))) int groth16_cache_load_file(Groth16CacheM
   return groth16_cache_load(cm, key, f.data, f.len, device_id, shard_rank, shard_count);
 }
 
+__attribute__((visibility("default"))) int groth16_last_timings(Groth16CacheManager* cm, const char* key, Groth16Timings* tm)
+{
+  if (!cm || !tm) return fail(ERR_ARG, "null argument");
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  if (!zp) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  std::lock_guard<std::mutex> lk(cm->mu);
+  *tm = zp->last_tm;
+  return 0;
+}
+
 __attribute__((visibility("default"))) int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16CircuitInfo* info)
 {
   if (!cm || !info) return fail(ERR_ARG, "null argument");
@@ -774,6 +785,8 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   (void)hipEventRecord(prof[2]->ev[0], g2);
   P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 10, 0, g2, &plan_w, z->geom_w.tab));
   if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
+  (void)hipEventRecord(prof[2]->ev[4], g2); // end of the witness digit sort (roofline.scatter)
+  prof[2]->has_sort_end = true;
   P_HIP(hipEventRecord(z->ev_sort, g2));
   mark("wsort");
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
@@ -836,6 +849,8 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   (void)hipEventRecord(prof[4]->ev[0], g3);
   P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 10, 0, g3, &plan_h, z->geom_h.tab));
   if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
+  (void)hipEventRecord(prof[4]->ev[4], g3);
+  prof[4]->has_sort_end = true;
   P_HIP(hipEventRecord(z->ev_sort_h, g3));
   mark("hsort");
 
@@ -936,15 +951,16 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   drain.armed = false;
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
-  if (tm) {
+  {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
     (void)hipEventElapsedTime(&b, z->ev[1], z->ev[2]);
     (void)hipEventElapsedTime(&c, z->ev[2], z->ev[3]);
-    tm->h2d_ms = h2d_host_ms + a;
-    tm->qap_ms = b;
-    tm->msm_ms = c;
-    tm->total_ms = ms_since(t0);
+    z->last_tm.h2d_ms = h2d_host_ms + a;
+    z->last_tm.qap_ms = b;
+    z->last_tm.msm_ms = c;
+    z->last_tm.total_ms = ms_since(t0);
+    if (tm) *tm = z->last_tm;
   }
   return 0;
 }
@@ -1189,8 +1205,11 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
     fputs(k ? qj.data() : pj.data(), f);
     fclose(f);
   }
-  printf("proof took: %.3fms\n", ms_since(t0)); // src/lib.rs:58
-  fflush(stdout);
+  static const bool quiet = getenv("ICICLE_SNARK_QUIET") && atoi(getenv("ICICLE_SNARK_QUIET")) != 0;
+  if (!quiet) {
+    printf("proof took: %.3fms\n", ms_since(t0)); // src/lib.rs:58
+    fflush(stdout);
+  }
   return 0;
 }
 

@@ -107,6 +107,8 @@ static int identify(const void* p)
   return -1;
 }
 
+bool is_tracked_device_ptr(const void* p) { return identify(p) >= 0; }
+
 // ---- workspace arena (see common.h) -------------------------------------------------------------
 struct WsBlock {
   void* ptr;

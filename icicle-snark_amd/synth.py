@@ -344,3 +344,206 @@ def setup_squaring_chain(N: int, vec, fixed_base_mul, points_to_mont=None, seed:
     R2 = MONT_R * MONT_R % R_MOD
     vals = bcast(R2, 2 * N + 2)
     return _finish(m, npub, n, a_tau, b_tau, c_s, ic_s, h_s, mcs, vals, toxic, fixed_base_mul, points_to_mont)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Scale-sized stand-ins for BASELINE.json configs 4 (anon_aadhaar) and 5 (Aptos keyless).  The real circuits need circom,
+# circomlib and input files that are not in the reference checkout (benchmark/anon_aadhaar has no input.json,
+# benchmark/keyless/README.md is a pointer), so a random sparse R1CS of published scale stands in:
+# ≥ 70 % of the wires are bits, ~10 % are below 2^64, the rest full width; ≈ 3 non-zeros per row of A and ≈ 1.5 per row
+# of B.  Everything produced from it is labelled "synthetic stand-in".
+STANDIN_SIZES = {
+    # name: (constraints, public signals, free inputs) — domain 2^20 / 2^21
+    "aadhaar_standin": (1_000_000, 4, 4096),
+    "keyless_standin": (1_400_000, 1, 8192),
+}
+
+
+@dataclass
+class SparseR1CS:
+    """R1CS as flat numpy arrays (row, wire, small signed coefficient) per matrix — the list-of-tuples R1CS above costs
+    ~100 bytes per entry, too much at 10^6 constraints."""
+    n_vars: int
+    n_public: int
+    n_constraints: int
+    A: tuple  # (rows int64[k], wires int64[k], coeffs int64[k])
+    B: tuple
+    C: tuple
+
+    def to_lists(self) -> R1CS:
+        r = R1CS(self.n_vars, self.n_public, self.n_constraints)
+        for name in "ABC":
+            rows, wires, vals = getattr(self, name)
+            getattr(r, name).extend((int(j), int(i), int(v) % R_MOD) for j, i, v in zip(rows.tolist(), wires.tolist(), vals.tolist()))
+        return r
+
+
+def standin_circuit(n_constraints: int, n_public: int, n_inputs: int, seed: int = 7):
+    """Random satisfiable R1CS with the wire and row statistics of an RSA/SHA-style circuit.  Every constraint defines one
+    fresh wire (`out`, through C).  Five constraint kinds (AND alone would drive the density of ones towards zero — the
+    XOR / MUX share keeps it near 3/8):
+      10 %  AND    x · y = out                       x, y earlier BIT wires              A 1, B 1   out ∈ {0,1}
+      25 %  XOR    2x · y = x + y − out              x, y earlier bit wires              A 1, B 1   out ∈ {0,1}
+      35 %  MUX    (x − y) · s = out − y             x, y, s earlier bit wires           A 2, B 1   out ∈ {0,1}
+      10 %  PACK   (Σ_{k<8} 2^k·b_k) · 1 = out       b_k earlier bit wires               A 8, B 1   out < 2^9: a small value
+      20 %  MULADD (Σ_5 a_k x_k) · (Σ_3 b_k y_k) = out   any earlier wires, a, b < 2^16   A 5, B 3   out full width
+    Average non-zeros per row: A 2.85, B 1.4.  Returns (SparseR1CS, witness list of Python ints)."""
+    rng = np.random.default_rng(seed)
+    pr = _Prng(seed)
+    first = 1 + n_public + n_inputs
+    n_vars = first + n_constraints
+    w = [0] * n_vars
+    w[0] = 1
+    is_bit = np.zeros(n_vars, dtype=bool)
+    # free inputs: 3/4 bits, the others full width (public signals are full-width field elements)
+    for i in range(1, first):
+        if i > n_public and (i & 3):
+            w[i] = int(rng.integers(0, 2))
+            is_bit[i] = True
+        else:
+            w[i] = pr.fr()
+    kind = rng.choice(5, size=n_constraints, p=[0.10, 0.35, 0.10, 0.20, 0.25])   # AND, MUX, PACK, MULADD, XOR
+    is_bit[first:] = (kind < 2) | (kind == 4)
+    # bit_rank[i] = number of bit wires among wires [0, i): a random earlier bit wire is bits[floor(u · bit_rank[out])]
+    bits = np.flatnonzero(is_bit)
+    bit_rank = np.cumsum(is_bit) - is_bit
+    assert bit_rank[first] >= 8, "need at least 8 bit inputs"
+    u = rng.random((n_constraints, 8))
+    any_u = rng.random((n_constraints, 8))
+    coef = rng.integers(1, 1 << 16, size=(n_constraints, 8))
+    outs = first + np.arange(n_constraints)
+    nb = bit_rank[outs]                                       # bit wires available to each constraint
+    bit_pick = bits[(u * nb[:, None]).astype(np.int64)]       # 8 candidate bit wires per constraint
+    any_pick = (any_u * outs[:, None]).astype(np.int64)       # 8 candidate arbitrary earlier wires (incl. the constant 1)
+    Ar, Aw, Av, Br, Bw, Bv, Cr, Cw, Cv = ([] for _ in range(9))
+    j_all = np.arange(n_constraints)
+    for k in range(5):
+        sel = j_all[kind == k]
+        if k == 0:      # AND
+            Ar.append(sel); Aw.append(bit_pick[sel, 0]); Av.append(np.ones(len(sel), np.int64))
+            Br.append(sel); Bw.append(bit_pick[sel, 1]); Bv.append(np.ones(len(sel), np.int64))
+            Cr.append(sel); Cw.append(outs[sel]); Cv.append(np.ones(len(sel), np.int64))
+        elif k == 1:    # MUX
+            Ar += [sel, sel]; Aw += [bit_pick[sel, 0], bit_pick[sel, 1]]; Av += [np.ones(len(sel), np.int64), -np.ones(len(sel), np.int64)]
+            Br.append(sel); Bw.append(bit_pick[sel, 2]); Bv.append(np.ones(len(sel), np.int64))
+            Cr += [sel, sel]; Cw += [outs[sel], bit_pick[sel, 1]]; Cv += [np.ones(len(sel), np.int64), -np.ones(len(sel), np.int64)]
+        elif k == 2:    # PACK
+            for t in range(8):
+                Ar.append(sel); Aw.append(bit_pick[sel, t]); Av.append(np.full(len(sel), 1 << t, np.int64))
+            Br.append(sel); Bw.append(np.zeros(len(sel), np.int64)); Bv.append(np.ones(len(sel), np.int64))
+            Cr.append(sel); Cw.append(outs[sel]); Cv.append(np.ones(len(sel), np.int64))
+        elif k == 4:    # XOR
+            ones = np.ones(len(sel), np.int64)
+            Ar.append(sel); Aw.append(bit_pick[sel, 0]); Av.append(2 * ones)
+            Br.append(sel); Bw.append(bit_pick[sel, 1]); Bv.append(ones)
+            Cr += [sel, sel, sel]; Cw += [bit_pick[sel, 0], bit_pick[sel, 1], outs[sel]]; Cv += [ones, ones, -ones]
+        else:           # MULADD
+            for t in range(5):
+                Ar.append(sel); Aw.append(any_pick[sel, t]); Av.append(coef[sel, t])
+            for t in range(3):
+                Br.append(sel); Bw.append(any_pick[sel, 5 + t]); Bv.append(coef[sel, 5 + t])
+            Cr.append(sel); Cw.append(outs[sel]); Cv.append(np.ones(len(sel), np.int64))
+    cat = lambda xs: np.concatenate(xs).astype(np.int64)
+    A = (cat(Ar), cat(Aw), cat(Av)); B = (cat(Br), cat(Bw), cat(Bv)); C = (cat(Cr), cat(Cw), cat(Cv))
+    # witness: constraints in order (each reads earlier wires only)
+    kl = kind.tolist()
+    bp = bit_pick.tolist()
+    ap = any_pick.tolist()
+    cf = coef.tolist()
+    for j in range(n_constraints):
+        out = first + j
+        k = kl[j]
+        b = bp[j]
+        if k == 0:
+            w[out] = w[b[0]] & w[b[1]]
+        elif k == 1:
+            w[out] = w[b[0]] if w[b[2]] else w[b[1]]
+        elif k == 2:
+            v = 0
+            for t in range(8):
+                v += w[b[t]] << t
+            w[out] = v
+        elif k == 4:
+            w[out] = w[b[0]] ^ w[b[1]]
+        else:
+            a, c = ap[j], cf[j]
+            sa = c[0] * w[a[0]] + c[1] * w[a[1]] + c[2] * w[a[2]] + c[3] * w[a[3]] + c[4] * w[a[4]]
+            sb = c[5] * w[a[5]] + c[6] * w[a[6]] + c[7] * w[a[7]]
+            w[out] = (sa % R_MOD) * (sb % R_MOD) % R_MOD
+    return SparseR1CS(n_vars, n_public, n_constraints, A, B, C), w
+
+
+def check_r1cs(r: SparseR1CS, w, sample: int = 0) -> bool:
+    """(A·w) ∘ (B·w) = C·w on all (sample = 0) or on `sample` random constraints — used by the tests of the generator."""
+    rows = range(r.n_constraints)
+    if sample:
+        rows = np.random.default_rng(1).integers(0, r.n_constraints, size=sample).tolist()
+    want = set(rows)
+    acc = {name: {} for name in "ABC"}
+    for name in "ABC":
+        jr, iw, vv = getattr(r, name)
+        d = acc[name]
+        if sample:
+            m = np.isin(jr, np.fromiter(want, dtype=np.int64))
+            jr, iw, vv = jr[m], iw[m], vv[m]
+        for j, i, v in zip(jr.tolist(), iw.tolist(), vv.tolist()):
+            d[j] = (d.get(j, 0) + v * w[i]) % R_MOD
+    return all(acc["A"].get(j, 0) * acc["B"].get(j, 0) % R_MOD == acc["C"].get(j, 0) for j in want)
+
+
+def setup_sparse(r: SparseR1CS, vec, fixed_base_mul, points_to_mont=None, seed: int = SEED):
+    """setup() for a SparseR1CS at 10^6 constraints: byte-identical to setup(r.to_lists(), …) (tested at small size).  The
+    two Lagrange bases come from `vec.intt` (as in setup_squaring_chain), the O(n) scalings from `vec.mul/add`; the sparse
+    accumulations a_i(τ) = Σ_j v_ji·L_j(τ) run over Python integers (a few seconds per million non-zeros)."""
+    toxic = _toxic(seed)
+    tau, alpha, beta, gamma, delta = toxic
+    m, npub, nc = r.n_vars, r.n_public, r.n_constraints
+    n = 1
+    while n < nc + npub + 1:
+        n <<= 1
+    logn = n.bit_length() - 1
+    one = ints_to_arr([1])
+
+    def bcast(x, k):
+        return np.broadcast_to(ints_to_arr([x]), (k, 4)).copy()
+
+    def powers(y):
+        p = one.copy()
+        step, k = y % R_MOD, 1
+        while k < n:
+            p = np.concatenate([p, vec.mul(p, bcast(step, k))])
+            step = step * step % R_MOD
+            k <<= 1
+        return p
+
+    L = arr_to_ints(vec.intt(powers(tau)))
+    g = omega(logn + 1)
+    Lc = vec.intt(powers(tau * pow(g, -1, R_MOD) % R_MOD))
+    tau_polys = []
+    for name in "ABC":
+        acc = [0] * m
+        rows, wires, vals = getattr(r, name)
+        for j, i, v in zip(rows.tolist(), wires.tolist(), vals.tolist()):
+            acc[i] += v * L[j]
+        if name == "A":
+            for s in range(npub + 1):     # snarkjs' extra rows binding the public inputs (A only)
+                acc[s] += L[nc + s]
+        tau_polys.append(ints_to_arr([x % R_MOD for x in acc]))
+    a_tau, b_tau, c_tau = tau_polys
+    comb = vec.add(vec.add(vec.mul(a_tau, bcast(beta, m)), vec.mul(b_tau, bcast(alpha, m))), c_tau)
+    ic_s = vec.mul(comb[0:npub + 1].copy(), bcast(pow(gamma, -1, R_MOD), npub + 1))
+    c_s = vec.mul(comb[npub + 1:].copy(), bcast(pow(delta, -1, R_MOD), m - npub - 1))
+    zt = (pow(tau, n, R_MOD) - 1) * pow((-2 * delta) % R_MOD, -1, R_MOD) % R_MOD
+    h_s = vec.mul(Lc, bcast(zt, n))
+    # coefficient section: A entries, then B entries (order of setup()), then the public-input rows
+    pub = np.arange(npub + 1, dtype=np.int64)
+    mm = np.concatenate([np.zeros(len(r.A[0]), np.int64), np.ones(len(r.B[0]), np.int64), np.zeros(npub + 1, np.int64)])
+    cc = np.concatenate([r.A[0], r.B[0], nc + pub])
+    ss = np.concatenate([r.A[1], r.B[1], pub])
+    vv = np.concatenate([r.A[2], r.B[2], np.ones(npub + 1, np.int64)])
+    mcs = np.stack([mm, cc, ss], axis=1).astype(np.uint32)
+    R2 = MONT_R * MONT_R % R_MOD
+    uniq, inv = np.unique(vv, return_inverse=True)
+    table = ints_to_arr([int(v) % R_MOD * R2 % R_MOD for v in uniq.tolist()])
+    vals = table[inv]
+    return _finish(m, npub, n, a_tau, b_tau, c_s, ic_s, h_s, mcs, vals, toxic, fixed_base_mul, points_to_mont)

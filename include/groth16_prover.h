@@ -92,6 +92,11 @@ typedef struct {
 } Groth16CircuitInfo;
 int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16CircuitInfo* info);
 
+/* phase timings (HIP events) of the most recent prove of `key` through ANY entry point — groth16_prove returns none,
+ * like the reference's; bench.py reads them here.  ICICLE_SNARK_QUIET=1 suppresses groth16_prove's "proof took: …" line
+ * (src/lib.rs:58) for callers whose stdout is machine-read. */
+int groth16_last_timings(Groth16CacheManager* cm, const char* key, Groth16Timings* timings);
+
 const char* groth16_last_error(void);
 
 /* groth16_verify — src/lib.rs:63-82 with groth16_verify_helper (src/proof_helper.rs:319-372) and the snarkjs

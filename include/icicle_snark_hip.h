@@ -259,8 +259,9 @@ eIcicleError icicle_snark_g2_generator_mul(const bn254_scalar_t* s, uint64_t n, 
 eIcicleError icicle_snark_last_msm_timings(float out_ms[4]);
 /* HIP-event profile of the `back`-th most recent MSM of this process (0 = latest); the caller must have
  * synchronised that MSM's stream.  out_ms = {recode+sort, bucket-accumulation kernel, large buckets +
- * reduction + tail, total}; geom = {L, nbuckets, c, W, is_g2}. */
-eIcicleError icicle_snark_msm_profile(int back, float out_ms[4], uint32_t geom[5]);
+ * reduction + tail, total, the digit sort alone (0 if this MSM re-used another one's sort)};
+ * geom = {L, nbuckets, c, W, is_g2}. */
+eIcicleError icicle_snark_msm_profile(int back, float out_ms[5], uint32_t geom[5]);
 /* measured machine constants for bench.py: out[0] = device-to-device copy GB/s (read + write bytes),
  * out[1] = v_mad_u64_u32 lane-operations per second / 10^12 */
 eIcicleError icicle_snark_microbench(double out[2]);

@@ -424,6 +424,45 @@ def _aff_to_strs_g2(a):
     return [[str(x0), str(x1)], [str(y0), str(y1)], ["1", "0"]]
 
 
+def groth16_commitments_of(cache: dict, w: np.ndarray, timings: dict | None = None) -> dict:
+    """construct_r1cs + groth16_commitments — src/proof_helper.rs:31-241: the five MSM results (projective, this
+    restatement's representatives) for one witness.  They do not depend on (r, s): a test that proves one witness under
+    several blinding pairs computes them once and calls groth16_assemble per pair."""
+    import time
+    t0 = time.perf_counter()
+    d_vec = construct_r1cs(w, cache)
+    t1 = time.perf_counter()
+    n, npub = cache["domain_size"], cache["n_public"]
+    cm = dict(a=msm("g1", w, cache["A"]), b1=msm("g1", w, cache["B1"]), b=msm("g2", w, cache["B2"]),
+              c=msm("g1", w[npub + 1:], cache["C"]), h=msm("g1", d_vec[n:2 * n], cache["H"]))
+    if timings is not None:
+        timings.update(qap_s=t1 - t0, msm_s=time.perf_counter() - t1)
+    return cm
+
+
+def groth16_assemble(cache: dict, w: np.ndarray, cm: dict, r: int = 1, s: int = 1):
+    """blinding, to_affine, JSON values — src/proof_helper.rs:274-316"""
+    npub = cache["n_public"]
+    P = lambda g, k: ec_from_affine(g, cache[k])
+    pi_a = ec_add("g1", ec_add("g1", cm["a"], P("g1", "vk_alpha_1")), ec_mul_scalar("g1", P("g1", "vk_delta_1"), r))
+    pi_b = ec_add("g2", ec_add("g2", cm["b"], P("g2", "vk_beta_2")), ec_mul_scalar("g2", P("g2", "vk_delta_2"), s))
+    pi_b1 = ec_add("g1", ec_add("g1", cm["b1"], P("g1", "vk_beta_1")), ec_mul_scalar("g1", P("g1", "vk_delta_1"), s))
+    acc = ec_add("g1", cm["c"], cm["h"])
+    acc = ec_add("g1", acc, ec_mul_scalar("g1", pi_a, s))
+    acc = ec_add("g1", acc, ec_mul_scalar("g1", pi_b1, r))
+    rs = ec_mul_scalar("g1", ec_mul_scalar("g1", P("g1", "vk_delta_1"), r), s)
+    pi_c = ec_sub("g1", acc, rs)
+    proof = {
+        "pi_a": _aff_to_strs_g1(ec_to_affine("g1", pi_a)),
+        "pi_b": _aff_to_strs_g2(ec_to_affine("g2", pi_b)),
+        "pi_c": _aff_to_strs_g1(ec_to_affine("g1", pi_c)),
+        "protocol": "groth16",
+        "curve": "bn128",
+    }
+    public = [str(x) for x in arr_to_ints(w[1:npub + 1])]
+    return proof, public
+
+
 def groth16_prove(zkey_bytes: bytes, wtns_bytes: bytes, r: int = 1, s: int = 1, cache: dict | None = None, timings: dict | None = None):
     """groth16_prove_helper — src/proof_helper.rs:243-317.  (r, s) = (1, 1) reproduces the
     `no-randomness` feature (:287-295, algebraically identical to the general formula)."""
@@ -437,34 +476,8 @@ def groth16_prove(zkey_bytes: bytes, wtns_bytes: bytes, r: int = 1, s: int = 1, 
         raise ValueError("Invalid witness length")
     w = wt["witness"]
     t0 = time.perf_counter()
-    d_vec = construct_r1cs(w, cache)
-    t1 = time.perf_counter()
-    n, npub = cache["domain_size"], cache["n_public"]
-    # groth16_commitments — :172-241
-    pi_a = msm("g1", w, cache["A"])
-    pi_b1 = msm("g1", w, cache["B1"])
-    pi_b = msm("g2", w, cache["B2"])
-    pi_c = msm("g1", w[npub + 1:], cache["C"])
-    pi_h = msm("g1", d_vec[n:2 * n], cache["H"])
-    t2 = time.perf_counter()
-    P = lambda g, k: ec_from_affine(g, cache[k])
-    # :274-285
-    pi_a = ec_add("g1", ec_add("g1", pi_a, P("g1", "vk_alpha_1")), ec_mul_scalar("g1", P("g1", "vk_delta_1"), r))
-    pi_b = ec_add("g2", ec_add("g2", pi_b, P("g2", "vk_beta_2")), ec_mul_scalar("g2", P("g2", "vk_delta_2"), s))
-    pi_b1 = ec_add("g1", ec_add("g1", pi_b1, P("g1", "vk_beta_1")), ec_mul_scalar("g1", P("g1", "vk_delta_1"), s))
-    acc = ec_add("g1", pi_c, pi_h)
-    acc = ec_add("g1", acc, ec_mul_scalar("g1", pi_a, s))
-    acc = ec_add("g1", acc, ec_mul_scalar("g1", pi_b1, r))
-    rs = ec_mul_scalar("g1", ec_mul_scalar("g1", P("g1", "vk_delta_1"), r), s)
-    pi_c = ec_sub("g1", acc, rs)
-    proof = {
-        "pi_a": _aff_to_strs_g1(ec_to_affine("g1", pi_a)),
-        "pi_b": _aff_to_strs_g2(ec_to_affine("g2", pi_b)),
-        "pi_c": _aff_to_strs_g1(ec_to_affine("g1", pi_c)),
-        "protocol": "groth16",
-        "curve": "bn128",
-    }
-    public = [str(x) for x in arr_to_ints(w[1:npub + 1])]
+    cm = groth16_commitments_of(cache, w, timings)
+    out = groth16_assemble(cache, w, cm, r, s)
     if timings is not None:
-        timings.update(qap_s=t1 - t0, msm_s=t2 - t1, total_s=time.perf_counter() - t0)
-    return proof, public
+        timings["total_s"] = time.perf_counter() - t0
+    return out
