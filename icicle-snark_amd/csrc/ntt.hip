@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "ff.h"
+#include "ntt_fuse.h"
 
 using namespace bn254;
 using namespace isnark;
@@ -93,6 +94,10 @@ struct PassParams {
   int scale; // multiply by n^-1 (last pass of an inverse transform)
   uint64_t batch_stride;
   int load_rows_fastest; // global loads: consecutive threads walk rows (in_row == 1) instead of columns
+  // prover fusions (last pass only; full 2048-element tiles):
+  const fe* scale_tab;   // non-null: out[i] *= scale_tab[i·scale_stride] (i = natural output index) INSTEAD of the n⁻¹ constant —
+  uint32_t scale_stride; // the prover passes n⁻¹·g^i, which folds the coset keys of src/proof_helper.rs:121-141 into the inverse transform
+  int fuse_abc;          // batch of 3 rows [B | A | C'] handled by ONE workgroup per tile: writes A·B − C' (src/proof_helper.rs:154-167) to row 0 of `out`
 };
 
 __device__ __forceinline__ uint32_t tw_index(uint32_t e, uint32_t n_mask, int inverse)
@@ -167,10 +172,41 @@ __device__ __forceinline__ void dif_butterfly<1>(fe (&x)[2], int j, int log_m, i
 {
   NTT_BF(0, 1, j << (log_r - log_m))
 }
+// Last round of a sub-transform (log_m == Q: j = 0, g = 1): 7 of the 12 twiddles of a radix-8 group are ω^0 = 1 (3 of 4 for
+// radix 4) — those products are skipped; the data are in standard form, so "times Montgomery one" is the identity.
+#define NTT_BF1(a, b)                                                                                          \
+  {                                                                                                            \
+    const fe s_ = Fr::add(x[a], x[b]);                                                                         \
+    x[b] = Fr::sub(x[a], x[b]);                                                                                \
+    x[a] = s_;                                                                                                 \
+  }
+template <int Q>
+__device__ __forceinline__ void dif_butterfly_last(fe (&x)[1 << Q], int log_r, const uint4* twlo, const uint4* twhi);
+template <>
+__device__ __forceinline__ void dif_butterfly_last<3>(fe (&x)[8], int log_r, const uint4* twlo, const uint4* twhi)
+{
+  const int s0 = log_r - 3, s1 = s0 + 1;
+  NTT_BF1(0, 4) NTT_BF(1, 5, 1 << s0) NTT_BF(2, 6, 2 << s0) NTT_BF(3, 7, 3 << s0)
+  NTT_BF1(0, 2) NTT_BF(1, 3, 1 << s1) NTT_BF1(4, 6) NTT_BF(5, 7, 1 << s1)
+  NTT_BF1(0, 1) NTT_BF1(2, 3) NTT_BF1(4, 5) NTT_BF1(6, 7)
+}
+template <>
+__device__ __forceinline__ void dif_butterfly_last<2>(fe (&x)[4], int log_r, const uint4* twlo, const uint4* twhi)
+{
+  const int s0 = log_r - 2;
+  NTT_BF1(0, 2) NTT_BF(1, 3, 1 << s0)
+  NTT_BF1(0, 1) NTT_BF1(2, 3)
+}
+template <>
+__device__ __forceinline__ void dif_butterfly_last<1>(fe (&x)[2], int log_r, const uint4* twlo, const uint4* twhi)
+{
+  NTT_BF1(0, 1)
+}
+#undef NTT_BF1
 #undef NTT_BF
 
 // one round of radix-2^Q butterflies over the whole tile: 8 >> Q groups per thread
-template <int Q>
+template <int Q, bool LAST = false>
 __device__ __forceinline__ void dif_round(uint4* lo, uint4* hi, const uint4* twlo, const uint4* twhi, int log_m, int log_r, int log_c, int tid)
 {
   const int C = 1 << log_c;
@@ -186,7 +222,8 @@ __device__ __forceinline__ void dif_round(uint4* lo, uint4* hi, const uint4* twl
     fe x[1 << Q];
 #pragma unroll
     for (int k = 0; k < (1 << Q); k++) x[k] = lds_get(lo, hi, ((base_row + (k << log_g)) << log_c) + c);
-    dif_butterfly<Q>(x, j, log_m, log_r, twlo, twhi);
+    if (LAST) dif_butterfly_last<Q>(x, log_r, twlo, twhi); // log_m == Q
+    else dif_butterfly<Q>(x, j, log_m, log_r, twlo, twhi);
 #pragma unroll
     for (int k = 0; k < (1 << Q); k++) lds_put(lo, hi, ((base_row + (k << log_g)) << log_c) + c, x[k]);
   }
@@ -195,27 +232,19 @@ __device__ __forceinline__ void dif_round(uint4* lo, uint4* hi, const uint4* twl
 // One pass: grid = (tiles, batch); the tile always holds 2048 elements = 8 per thread (smaller transforms
 // are padded by idle threads).  LDS: two uint4 planes of R·C entries + R/2 stage twiddles.
 // The size-R sub-transforms run as ⌈log R / 3⌉ rounds of radix-8 (then one radix-4 / radix-2 round) with the
-// eight operands of a butterfly in registers — one LDS round trip and one barrier per THREE radix-2 stages.
-__global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ in, fe* __restrict__ out, const fe* __restrict__ tw, PassParams p, fe ninv_mont)
+// eight operands of a butterfly in registers — one LDS round trip and one barrier per THREE radix-2 stages; the last
+// round of a sub-transform skips its unit twiddles (7 of 12 products).
+// FUSE (prover, last pass of the forward transform, grid.y = 1, full tiles): the workgroup transforms its tile of the
+// three rows [B | A | C'] one after the other, keeps B's then A·B's eight outputs per thread in registers and writes
+// A·B − C' — the pointwise epilogue of construct_r1cs (src/proof_helper.rs:154-167) — to row 0 of `out`: one n-element
+// store instead of 3n, and no separate read-modify-write sweep.
+// one row's tile: load → rounds → store.  MODE 0: plain store (inter-pass twiddle / scale); MODE 1, 2, 3: rows B, A, C' of the
+// fused epilogue (see the kernel).  Instantiated once per mode so that nothing is live across the rows.
+template <int MODE>
+__device__ __forceinline__ void ntt_tile_row(const fe* __restrict__ src, fe* __restrict__ dst, const fe* __restrict__ tw, const PassParams& p, const fe& ninv_mont, uint4* lo, uint4* hi,
+                                             const uint4* twlo, const uint4* twhi, uint32_t b_lo, uint64_t out_off, int tid)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int R = 1 << p.log_r, C = 1 << p.log_c, RC = R * C;
-  uint4* lo = reinterpret_cast<uint4*>(smem);
-  uint4* hi = lo + RC;
-  uint4* twlo = hi + RC; // R/2 entries
-  uint4* twhi = twlo + (R >> 1);
-
-  const uint32_t b = blockIdx.x;
-  const uint32_t b_hi = b >> p.tiles_per_group_log, b_lo = b & ((1u << p.tiles_per_group_log) - 1);
-  const fe* src = in + (uint64_t)blockIdx.y * p.batch_stride + b_hi * p.in_hi + b_lo * p.in_lo;
-  fe* dst = out + (uint64_t)blockIdx.y * p.batch_stride + b_hi * p.out_hi + b_lo * p.out_lo;
-  const int tid = threadIdx.x;
-
-  // stage twiddles ω_R^e, e < R/2
-  for (int e = tid; e < (R >> 1); e += NT) {
-    fe w = g_get(tw + tw_index((uint32_t)e * p.stage_stride, p.n_mask, p.inverse));
-    lds_put(twlo, twhi, e, w);
-  }
   // load tile: LDS index = r·C + c.  All of a thread's loads are issued before the first LDS store.
   if (RC == NT * 8) {
     fe v[8];
@@ -248,18 +277,15 @@ __global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ 
   if (RC == NT * 8) {
     // natural order in → bit-reversed order out, three radix-2 stages per round
     int log_m = p.log_r;
-    while (log_m >= 3) {
+    while (log_m > 3) {
       dif_round<3>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
       __syncthreads();
       log_m -= 3;
     }
-    if (log_m == 2) {
-      dif_round<2>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
-      __syncthreads();
-    } else if (log_m == 1) {
-      dif_round<1>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
-      __syncthreads();
-    }
+    if (log_m == 3) dif_round<3, true>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
+    else if (log_m == 2) dif_round<2, true>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
+    else if (log_m == 1) dif_round<1, true>(lo, hi, twlo, twhi, log_m, p.log_r, p.log_c, tid);
+    __syncthreads();
   } else {
     // small transforms (tile smaller than 2048 elements): plain radix-2 stages
     const int nbf = RC >> 1;
@@ -283,9 +309,37 @@ __global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ 
     }
   }
 
-  // store: LDS row s holds k = bitrev(s); inter-pass twiddle and 1/n fused here
+  if (MODE != 0) {
+    // full tile, last pass (no inter-pass twiddle, no scaling).  The running value (B̂, then Â·B̂) lives in the output
+    // buffer itself: every thread re-reads exactly the addresses it wrote for the previous row (its own stores, program
+    // order; the 64 KiB a workgroup touches stay in L2), so nothing is held in registers across a row's transform —
+    // eight kept elements per thread (64 VGPRs) pushed the rounds into scratch.
+    // four elements at a time (like the plain store): four L2 reads in flight without pushing the kernel past its registers
+#pragma unroll 1
+    for (int u0 = 0; u0 < 8; u0 += 4) {
+      fe y[4];
+      fe* q[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = tid + (u0 + u) * NT;
+        const int c = e & (C - 1);
+        const uint32_t kk = __brev((uint32_t)(e >> p.log_c)) >> (32 - p.log_r);
+        q[u] = dst + (uint64_t)kk * p.out_row + (uint64_t)c * p.out_col;
+        if (MODE != 1) y[u] = g_get(q[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const fe x = lds_get(lo, hi, tid + (u0 + u) * NT);
+        if (MODE == 1) g_put(q[u], x);
+        else if (MODE == 2) g_put(q[u], Fr::mul(Fr::mul(x, y[u]), Fr::r2())); // standard-form product
+        else g_put(q[u], Fr::sub(y[u], x));
+      }
+    }
+    return;
+  }
+  // store: LDS row s holds k = bitrev(s); inter-pass twiddle and 1/n (or the caller's per-element scale) fused here
   for (int e0 = tid; e0 < RC; e0 += NT * 4) {
-    fe v[4], w[4];
+    fe w[4];
     uint32_t kk[4], ex[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -305,10 +359,42 @@ __global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ 
         const int c = e & (C - 1);
         fe x = lds_get(lo, hi, e);
         if (ex[u]) x = Fr::mul(x, w[u]);
-        if (p.scale) x = Fr::mul(x, ninv_mont);
+        if (p.scale_tab) x = Fr::mul(x, g_get(p.scale_tab + (out_off + (uint64_t)kk[u] * p.out_row + (uint64_t)c * p.out_col) * p.scale_stride));
+        else if (p.scale) x = Fr::mul(x, ninv_mont);
         g_put(dst + (uint64_t)kk[u] * p.out_row + (uint64_t)c * p.out_col, x);
       }
     }
+  }
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ in, fe* __restrict__ out, const fe* __restrict__ tw, PassParams p, fe ninv_mont)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int R = 1 << p.log_r, C = 1 << p.log_c, RC = R * C;
+  uint4* lo = reinterpret_cast<uint4*>(smem);
+  uint4* hi = lo + RC;
+  uint4* twlo = hi + RC; // R/2 entries
+  uint4* twhi = twlo + (R >> 1);
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t b_hi = b >> p.tiles_per_group_log, b_lo = b & ((1u << p.tiles_per_group_log) - 1);
+  const uint64_t in_off = b_hi * p.in_hi + b_lo * p.in_lo, out_off = b_hi * p.out_hi + b_lo * p.out_lo;
+  const int tid = threadIdx.x;
+
+  // stage twiddles ω_R^e, e < R/2
+  for (int e = tid; e < (R >> 1); e += NT) {
+    fe w = g_get(tw + tw_index((uint32_t)e * p.stage_stride, p.n_mask, p.inverse));
+    lds_put(twlo, twhi, e, w);
+  }
+  if (!FUSE) {
+    ntt_tile_row<0>(in + (uint64_t)blockIdx.y * p.batch_stride + in_off, out + (uint64_t)blockIdx.y * p.batch_stride + out_off, tw, p, ninv_mont, lo, hi, twlo, twhi, b_lo, out_off, tid);
+  } else {
+    ntt_tile_row<1>(in + in_off, out + out_off, tw, p, ninv_mont, lo, hi, twlo, twhi, b_lo, out_off, tid);
+    __syncthreads(); // the row's outputs have been read out of the tile
+    ntt_tile_row<2>(in + p.batch_stride + in_off, out + out_off, tw, p, ninv_mont, lo, hi, twlo, twhi, b_lo, out_off, tid);
+    __syncthreads();
+    ntt_tile_row<3>(in + 2 * p.batch_stride + in_off, out + out_off, tw, p, ninv_mont, lo, hi, twlo, twhi, b_lo, out_off, tid);
   }
 }
 
@@ -445,7 +531,8 @@ ISNARK_API eIcicleError bn254_get_root_of_unity_from_domain(uint64_t logn, bn254
   return ICICLE_SUCCESS;
 }
 
-ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir dir, const NTTConfig* cfg, bn254_scalar_t* output)
+namespace {
+eIcicleError ntt_impl(const bn254_scalar_t* input, int size, NTTDir dir, const NTTConfig* cfg, bn254_scalar_t* output, const isnark::NttFuse* fuse)
 {
   if (!cfg || !input || !output) return ICICLE_INVALID_POINTER;
   if (size <= 0 || (size & (size - 1))) {
@@ -593,10 +680,26 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
     static std::atomic<bool> lds_attr_set[MAX_DEVICES]; // function attributes are per device
     const int devi = dom.device >= 0 && dom.device < MAX_DEVICES ? dom.device : 0;
     if (!lds_attr_set[devi].load(std::memory_order_acquire)) {
-      HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);
+      HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);
+      HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);
       lds_attr_set[devi].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(NT), lds, s, src, dst, dom.tw, p, ninv);
+    const bool full_tile = ((size_t)1 << (p.log_r + p.log_c)) == (size_t)NT * 8;
+    if (last && fuse && fuse->scale_tab && inverse) {
+      p.scale_tab = fuse->scale_tab;
+      p.scale_stride = fuse->scale_stride;
+    }
+    if (last && fuse && fuse->fused_out) {
+      // A·B − C' epilogue: one workgroup per tile walks the three rows
+      if (!full_tile || batch != 3 || inverse || rev_out || cols) {
+        set_last_error("ntt: fused epilogue needs a forward batch-of-3 transform with full tiles");
+        return ICICLE_INVALID_ARGUMENT;
+      }
+      p.fuse_abc = 1;
+      hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((unsigned)tiles, 1), dim3(NT), lds, s, src, fuse->fused_out, dom.tw, p, ninv);
+    } else {
+      hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3((unsigned)tiles, (unsigned)batch), dim3(NT), lds, s, src, dst, dom.tw, p, ninv);
+    }
     ICICLE_TRY(check_launch("ntt_pass"));
     rem = tail;
   }
@@ -619,3 +722,48 @@ ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir 
   ICICLE_TRY(sout.finish());
   return end_call(s, cfg->is_async);
 }
+} // namespace
+
+ISNARK_API eIcicleError bn254_ntt(const bn254_scalar_t* input, int size, NTTDir dir, const NTTConfig* cfg, bn254_scalar_t* output)
+{
+  return ntt_impl(input, size, dir, cfg, output, nullptr);
+}
+
+namespace isnark {
+// the prover's transforms (device in/out, natural order, asynchronous on `s`), with the fusions of NttFuse
+eIcicleError ntt_fused(fe* d_inout, uint32_t n, int batch, bool inverse, hipStream_t s, const NttFuse& fuse)
+{
+  NTTConfig nc;
+  memset(&nc, 0, sizeof nc);
+  nc.stream = s;
+  nc.coset_gen.limbs[0] = 1;
+  nc.batch_size = batch;
+  nc.ordering = kNN;
+  nc.are_inputs_on_device = nc.are_outputs_on_device = true;
+  nc.is_async = true;
+  return ntt_impl((const bn254_scalar_t*)d_inout, (int)n, inverse ? kInverse : kForward, &nc, (bn254_scalar_t*)d_inout, &fuse);
+}
+// full 2048-element tiles in every pass (what the fused epilogue needs)
+bool ntt_fusable(uint32_t n) { return n >= (1u << 12); }
+// tab[i] = n⁻¹ · ω_{2n}^i  (Montgomery form), i < n: the per-element scale that folds 1/n and the coset keys g^i
+// (g = ω_2n, src/cache.rs:183-184,264-289) into the last pass of the inverse transform
+__global__ __launch_bounds__(256) void ntt_scaled_keys_kernel(const fe* __restrict__ tw, uint32_t tw_stride, uint32_t n, fe ninv_mont, fe* __restrict__ tab)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g_put(tab + i, Fr::mul(g_get(tw + (size_t)i * tw_stride), ninv_mont));
+}
+eIcicleError ntt_build_scaled_keys(uint32_t n, fe* d_tab, hipStream_t s)
+{
+  int lg = 0;
+  const fe* tw = ntt_domain_table(&lg);
+  if (!tw || (1ull << lg) < 2ull * n) {
+    set_last_error("ntt_build_scaled_keys: the domain must hold 2n = %llu roots", 2ull * n);
+    return ICICLE_INVALID_ARGUMENT;
+  }
+  fe nn = Fr::zero();
+  nn.l[0] = n;
+  const fe ninv = Fr::inv(Fr::to_mont(nn));
+  hipLaunchKernelGGL(ntt_scaled_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tw, (uint32_t)((1ull << lg) / (2ull * n)), n, ninv, d_tab);
+  return check_launch("ntt_scaled_keys");
+}
+} // namespace isnark

@@ -38,6 +38,7 @@
 #include "../common.h"
 #include "../ec.h"
 #include "../msm_plan.h"
+#include "../ntt_fuse.h"
 #include "qap.h"
 
 using namespace bn254;
@@ -185,6 +186,7 @@ struct ZKeyCache {
   fe* d_witness = nullptr; // n_vars
   fe* d_vec = nullptr;     // 3n
   fe* d_fold = nullptr;    // 3·n/G: folded rows of a strided H shard (qap_coset_fold3)
+  fe* d_skeys = nullptr;   // n: n⁻¹·g^i — 1/n and the coset keys folded into the inverse transform's last pass (ntt_fuse.h); built on first use
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
@@ -202,7 +204,7 @@ struct ZKeyCache {
     if (s_g3) (void)hipStreamSynchronize(s_g3);
     if (s_g4) (void)hipStreamSynchronize(s_g4);
     if (s_g5) (void)hipStreamSynchronize(s_g5);
-    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_partials})
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_partials})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
     if (s_qap) (void)icicle_destroy_stream(s_qap);
@@ -806,18 +808,39 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   nc.ordering = kNN;
   nc.are_inputs_on_device = nc.are_outputs_on_device = true;
   nc.is_async = true;
-  P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
   int dom_log = 0;
   const fe* tw = ntt_domain_table(&dom_log);
   const fe* d_hscalars = z->d_vec + n + z->H.lo; // slot 1 of the result, this rank's range
+  static const bool fuse_cfg = !(getenv("ICICLE_SNARK_NTT_FUSE") && atoi(getenv("ICICLE_SNARK_NTT_FUSE")) == 0);
   if (z->H.stride > 1) {
     // strided H shard: coset keys, the fold over the shard count and the twist in one pass, then a size-n/G transform
+    P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
     const uint32_t m = z->H.len();
     P_HIP(qap_coset_fold3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, z->H.stride, z->H.first, z->d_fold, gq));
-    P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_fold, (int)m, kForward, &nc, (bn254_scalar_t*)z->d_fold));
-    P_HIP(qap_final(z->d_fold, m, gq));
+    if (fuse_cfg && ntt_fusable(m)) {
+      NttFuse f;
+      f.fused_out = z->d_fold + m;
+      P_ICICLE(ntt_fused(z->d_fold, m, 3, false, gq, f));
+    } else {
+      P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_fold, (int)m, kForward, &nc, (bn254_scalar_t*)z->d_fold));
+      P_HIP(qap_final(z->d_fold, m, gq));
+    }
     d_hscalars = z->d_fold + m;
+  } else if (fuse_cfg && ntt_fusable(n)) {
+    // inverse transform with 1/n and the coset keys folded into its last pass (:116-141), forward transform with the
+    // A·B − C epilogue folded into its last pass (:145-167): no coset sweep, no final sweep, n instead of 3n stores
+    if (!z->d_skeys) {
+      P_HIP(hipMalloc((void**)&z->d_skeys, (size_t)n * 32));
+      z->device_bytes += (size_t)n * 32;
+      P_ICICLE(ntt_build_scaled_keys(n, z->d_skeys, gq));
+    }
+    NttFuse fi, ff;
+    fi.scale_tab = z->d_skeys;
+    P_ICICLE(ntt_fused(z->d_vec, n, 3, true, gq, fi));
+    ff.fused_out = z->d_vec + n;
+    P_ICICLE(ntt_fused(z->d_vec, n, 3, false, gq, ff));
   } else {
+    P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
     P_HIP(qap_coset_mul3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, gq));                                   // :121-141
     P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kForward, &nc, (bn254_scalar_t*)z->d_vec)); // :145
     P_HIP(qap_final(z->d_vec, n, gq));                                                                        // :154-167
