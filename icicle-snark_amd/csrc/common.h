@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/icicle_snark_hip.h"
 
@@ -33,6 +34,26 @@ void set_last_error(const char* fmt, ...);
 eIcicleError require_device();
 // `p` lies inside a block handed out by icicle_malloc{,_async} (the map behind icicle_is_active_device_memory)
 bool is_tracked_device_ptr(const void* p);
+// hand the blocks cached by icicle_free back to the driver (call before giving up on an allocation)
+void release_cached_device_memory();
+
+// ---- pageable-memory copies ------------------------------------------------------------------------------------------
+// A hipMemcpy from/to pageable host memory is a single-threaded staging copy (≈5–10 GB/s measured here).  staged_copy
+// runs up to STAGED_LANES workers, each moving 2 MB chunks through its own pair of pinned buffers and its own stream, so
+// page faults / memcpy of one chunk overlap the DMA of the others (54 GB/s host→device on the MI355X box).  It returns
+// when every byte has arrived.  `lanes`: streams to enqueue the DMAs on (idle streams of the caller); nullptr = the
+// engine's own persistent lane streams of the active device.  Callers order it against earlier stream work themselves.
+struct CopyJob {
+  void* dst;
+  const void* src;
+  size_t n;
+};
+constexpr int STAGED_LANES = 8;
+hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes = nullptr, int n_lanes = 0, bool own_temp_streams = false);
+// true when hipMemcpyAsync can DMA straight from/to `host_ptr` (pinned / registered memory)
+bool is_pinned_host(const void* host_ptr);
+// copies of at least this many bytes from/to pageable memory take the staged path
+constexpr size_t STAGED_MIN_BYTES = 4u << 20;
 
 // Stages a host-resident operand on the device for the lifetime of the object (the reference's
 // wrappers do the same per VecOpsConfig / NTTConfig / MSMConfig flags, e.g.
@@ -62,7 +83,12 @@ public:
     }
     HIP_TRY(hipMalloc(&dev_, bytes), ICICLE_ALLOCATION_FAILED);
     owned_ = true;
-    HIP_TRY(hipMemcpy(dev_, p, bytes, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
+    if (bytes >= STAGED_MIN_BYTES && !is_pinned_host(p)) {
+      int d = 0;
+      (void)hipGetDevice(&d);
+      const CopyJob j = {dev_, p, bytes};
+      HIP_TRY(staged_copy(d, &j, 1, true), ICICLE_COPY_FAILED);
+    } else HIP_TRY(hipMemcpy(dev_, p, bytes, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
     return ICICLE_SUCCESS;
   }
   eIcicleError out(void* p, size_t bytes, bool on_device, hipStream_t s)
@@ -85,7 +111,12 @@ public:
   {
     if (host_out_) {
       HIP_TRY(hipStreamSynchronize(stream_), ICICLE_SYNCHRONIZATION_FAILED);
-      HIP_TRY(hipMemcpy(host_out_, dev_, bytes_, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
+      if (bytes_ >= STAGED_MIN_BYTES && !is_pinned_host(host_out_)) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const CopyJob j = {host_out_, dev_, bytes_};
+        HIP_TRY(staged_copy(d, &j, 1, false), ICICLE_COPY_FAILED);
+      } else HIP_TRY(hipMemcpy(host_out_, dev_, bytes_, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
       host_out_ = nullptr;
     }
     return ICICLE_SUCCESS;

@@ -244,93 +244,15 @@ G2::P g2_from_mont_affine(const uint8_t* p)
 
 // ---- cold path: host → device ingest ------------------------------------------------------------
 // The zkey arrives as pageable memory (an mmap of the file, or the caller's buffer).  A pageable hipMemcpy is a
-// single-threaded staging copy; here UPLOAD_THREADS workers copy 2 MB chunks into their own pair of pinned buffers
-// and enqueue the DMA on their own streams, so page faults / memcpy of one chunk overlap the DMA of the others.
-struct UploadJob {
-  void* dst;
-  const uint8_t* src;
-  size_t n;
-};
-constexpr int UPLOAD_THREADS = 8;
-constexpr size_t UPLOAD_CHUNK = 2u << 20;
-
-struct UploadPool { // pinned staging and events, allocated once per process
-  std::mutex mu;
-  uint8_t* pinned = nullptr;
-  hipEvent_t events[UPLOAD_THREADS][2] = {};
-};
-UploadPool g_upload;
-
-// `lanes`: streams to enqueue the DMAs on (one worker thread per lane, ≤ UPLOAD_THREADS).  nullptr: the call creates
-// UPLOAD_THREADS short-lived streams itself (cold path; stream creation costs milliseconds, and idle streams would
-// occupy hardware-queue slots that the prover's own streams need — runtime.cpp, GPU_MAX_HW_QUEUES).  The per-prove
-// witness upload passes the prover's own streams, idle at that point.  Returns after every DMA has completed.
+// single-threaded staging copy; isnark::staged_copy (runtime.cpp) runs up to eight workers that copy 2 MB chunks into
+// their own pair of pinned buffers and enqueue the DMAs on their own streams, so page faults / memcpy of one chunk
+// overlap the DMA of the others.  `lanes`: streams to enqueue the DMAs on (the per-prove witness upload passes the
+// prover's own streams, idle at that point); nullptr: short-lived streams of the call (cold path).
+typedef CopyJob UploadJob;
 int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in = nullptr, int n_lanes = 0)
 {
-  std::lock_guard<std::mutex> lk(g_upload.mu);
-  UploadPool& P = g_upload;
-  if (!P.pinned) {
-    P_HIP(hipHostMalloc((void**)&P.pinned, UPLOAD_THREADS * 2 * UPLOAD_CHUNK, hipHostMallocPortable));
-    for (int t = 0; t < UPLOAD_THREADS; t++)
-      for (int k = 0; k < 2; k++) P_HIP(hipEventCreateWithFlags(&P.events[t][k], hipEventDisableTiming));
-  }
-  struct Lanes {
-    hipStream_t streams[UPLOAD_THREADS] = {};
-    bool own = false;
-    hipEvent_t (*events)[2] = nullptr;
-    ~Lanes()
-    {
-      if (own)
-        for (int t = 0; t < UPLOAD_THREADS; t++)
-          if (streams[t]) (void)hipStreamDestroy(streams[t]);
-    }
-  } lanes;
-  lanes.events = P.events;
-  const int max_lanes = lanes_in ? (n_lanes < UPLOAD_THREADS ? n_lanes : UPLOAD_THREADS) : UPLOAD_THREADS;
-  std::vector<UploadJob> chunks;
-  for (const UploadJob& j : jobs)
-    for (size_t off = 0; off < j.n; off += UPLOAD_CHUNK)
-      chunks.push_back({(uint8_t*)j.dst + off, j.src + off, j.n - off < UPLOAD_CHUNK ? j.n - off : UPLOAD_CHUNK});
-  std::atomic<size_t> next{0};
-  std::atomic<int> err{(int)hipSuccess};
-  auto worker = [&](int t) {
-    if (hipSetDevice(device_id) != hipSuccess) {
-      err = (int)hipErrorInvalidDevice;
-      return;
-    }
-    uint8_t* buf[2] = {P.pinned + (size_t)t * 2 * UPLOAD_CHUNK, P.pinned + ((size_t)t * 2 + 1) * UPLOAD_CHUNK};
-    bool used[2] = {false, false};
-    for (int k = 0;; k ^= 1) {
-      const size_t i = next.fetch_add(1);
-      if (i >= chunks.size() || err.load() != (int)hipSuccess) break;
-      hipError_t e = hipSuccess;
-      if (used[k]) e = hipEventSynchronize(lanes.events[t][k]); // the DMA that last read this buffer is done
-      if (e == hipSuccess) {
-        memcpy(buf[k], chunks[i].src, chunks[i].n);
-        e = hipMemcpyAsync(chunks[i].dst, buf[k], chunks[i].n, hipMemcpyHostToDevice, lanes.streams[t]);
-      }
-      if (e == hipSuccess) e = hipEventRecord(lanes.events[t][k], lanes.streams[t]);
-      used[k] = true;
-      if (e != hipSuccess) {
-        err = (int)e;
-        break;
-      }
-    }
-    hipError_t e = hipStreamSynchronize(lanes.streams[t]);
-    if (e != hipSuccess) err = (int)e;
-  };
-  std::vector<std::thread> th;
-  const int nt = chunks.size() < (size_t)max_lanes ? (int)chunks.size() : max_lanes;
-  if (lanes_in) {
-    for (int t = 0; t < nt; t++) lanes.streams[t] = lanes_in[t];
-  } else {
-    lanes.own = true;
-    for (int t = 0; t < nt; t++) P_HIP(hipStreamCreateWithFlags(&lanes.streams[t], hipStreamNonBlocking));
-  }
-  for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
-  if (nt > 0) worker(0);
-  for (auto& x : th) x.join();
-  if (err.load() != (int)hipSuccess) return fail((int)ICICLE_COPY_FAILED, "zkey upload: %s", hipGetErrorString((hipError_t)err.load()));
+  const hipError_t e = staged_copy(device_id, jobs.data(), jobs.size(), true, lanes_in, n_lanes, /*own_temp_streams=*/lanes_in == nullptr);
+  if (e != hipSuccess) return fail((int)ICICLE_COPY_FAILED, "host to device upload: %s", hipGetErrorString(e));
   return 0;
 }
 
@@ -492,6 +414,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
       // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
       // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
       size_t free_b = 0, total_b = 0;
+      release_cached_device_memory(); // blocks parked by icicle_free count as free
       P_HIP(hipMemGetInfo(&free_b, &total_b));
       const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W;
       const uint64_t need = ww * ((uint64_t)z->A.len() * 64 * 2 + (uint64_t)z->C.len() * 64 + (uint64_t)z->B2.len() * 128) + wh * (uint64_t)z->H.len() * 64 +

@@ -8,7 +8,9 @@
 // * every allocation made through this API is recorded so that icicle_is_active_device_memory()
 //   also answers for interior pointers (icicle/include/icicle/memory_tracker.h:11-55) — the Rust
 //   DeviceSlice checks this on every slice (wrappers/rust/icicle-runtime/src/memory.rs:120-125).
+#include <atomic>
 #include <map>
+#include <thread>
 #include <execinfo.h>
 #include <mutex>
 #include <signal.h>
@@ -109,6 +111,138 @@ static int identify(const void* p)
 
 bool is_tracked_device_ptr(const void* p) { return identify(p) >= 0; }
 
+// ---- pageable-memory copy engine (see common.h) ------------------------------------------------------------------
+constexpr size_t STAGED_CHUNK = 2u << 20;
+struct StagedPool { // pinned staging, events and lane streams: allocated once per process / device
+  std::mutex mu;
+  uint8_t* pinned = nullptr;
+  hipEvent_t events[STAGED_LANES][2] = {};
+  std::map<int, std::vector<hipStream_t>> lanes; // device → persistent lane streams
+};
+static StagedPool g_staged;
+
+bool is_pinned_host(const void* host_ptr)
+{
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, host_ptr) != hipSuccess) {
+    (void)hipGetLastError(); // an unregistered (pageable) pointer is reported as an error: clear it
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes_in, int n_lanes, bool own_temp_streams)
+{
+  std::lock_guard<std::mutex> lk(g_staged.mu);
+  StagedPool& P = g_staged;
+  hipError_t e0 = hipSetDevice(device_id);
+  if (e0 != hipSuccess) return e0;
+  if (!P.pinned) {
+    if ((e0 = hipHostMalloc((void**)&P.pinned, STAGED_LANES * 2 * STAGED_CHUNK, hipHostMallocPortable)) != hipSuccess) return e0;
+    for (int t = 0; t < STAGED_LANES; t++)
+      for (int k = 0; k < 2; k++)
+        if ((e0 = hipEventCreateWithFlags(&P.events[t][k], hipEventDisableTiming)) != hipSuccess) return e0;
+  }
+  std::vector<CopyJob> chunks;
+  for (size_t j = 0; j < njobs; j++)
+    for (size_t off = 0; off < jobs[j].n; off += STAGED_CHUNK)
+      chunks.push_back({(uint8_t*)jobs[j].dst + off, (const uint8_t*)jobs[j].src + off, jobs[j].n - off < STAGED_CHUNK ? jobs[j].n - off : STAGED_CHUNK});
+  if (chunks.empty()) return hipSuccess;
+  hipStream_t streams[STAGED_LANES] = {};
+  int max_lanes = STAGED_LANES;
+  std::vector<hipStream_t> temp;
+  if (lanes_in) {
+    max_lanes = n_lanes < STAGED_LANES ? n_lanes : STAGED_LANES;
+    for (int t = 0; t < max_lanes; t++) streams[t] = lanes_in[t];
+  } else if (own_temp_streams) {
+    // cold path: short-lived streams (idle streams would keep hardware-queue slots the prover's own streams need)
+    for (int t = 0; t < STAGED_LANES; t++) {
+      hipStream_t st;
+      if ((e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) {
+        for (hipStream_t x : temp) (void)hipStreamDestroy(x);
+        return e0;
+      }
+      temp.push_back(st);
+      streams[t] = st;
+    }
+  } else {
+    std::vector<hipStream_t>& v = P.lanes[device_id];
+    max_lanes = 4; // per-call copies of the C ABI: four lanes reach the PCIe rate without crowding the hardware queues
+    while ((int)v.size() < max_lanes) {
+      hipStream_t st;
+      if ((e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return e0;
+      v.push_back(st);
+    }
+    for (int t = 0; t < max_lanes; t++) streams[t] = v[t];
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<int> err{(int)hipSuccess};
+  auto worker = [&](int t) {
+    if (hipSetDevice(device_id) != hipSuccess) {
+      err = (int)hipErrorInvalidDevice;
+      return;
+    }
+    uint8_t* buf[2] = {P.pinned + (size_t)t * 2 * STAGED_CHUNK, P.pinned + ((size_t)t * 2 + 1) * STAGED_CHUNK};
+    if (to_device) {
+      bool used[2] = {false, false};
+      for (int k = 0;; k ^= 1) {
+        const size_t i = next.fetch_add(1);
+        if (i >= chunks.size() || err.load() != (int)hipSuccess) break;
+        hipError_t e = hipSuccess;
+        if (used[k]) e = hipEventSynchronize(P.events[t][k]); // the DMA that last read this buffer is done
+        if (e == hipSuccess) {
+          memcpy(buf[k], chunks[i].src, chunks[i].n);
+          e = hipMemcpyAsync(chunks[i].dst, buf[k], chunks[i].n, hipMemcpyHostToDevice, streams[t]);
+        }
+        if (e == hipSuccess) e = hipEventRecord(P.events[t][k], streams[t]);
+        used[k] = true;
+        if (e != hipSuccess) {
+          err = (int)e;
+          break;
+        }
+      }
+    } else {
+      // device → host: the DMA of chunk i into one buffer overlaps the memcpy of chunk i − 1 out of the other
+      size_t pending = (size_t)-1;
+      int pk = 0;
+      for (int k = 0;; k ^= 1) {
+        const size_t i = next.fetch_add(1);
+        const bool have = i < chunks.size() && err.load() == (int)hipSuccess;
+        hipError_t e = hipSuccess;
+        if (have) {
+          e = hipMemcpyAsync(buf[k], chunks[i].src, chunks[i].n, hipMemcpyDeviceToHost, streams[t]);
+          if (e == hipSuccess) e = hipEventRecord(P.events[t][k], streams[t]);
+        }
+        if (pending != (size_t)-1) {
+          hipError_t e2 = hipEventSynchronize(P.events[t][pk]);
+          if (e2 == hipSuccess) memcpy(chunks[pending].dst, buf[pk], chunks[pending].n);
+          else e = e2;
+          pending = (size_t)-1;
+        }
+        if (e != hipSuccess) {
+          err = (int)e;
+          break;
+        }
+        if (!have) break;
+        pending = i;
+        pk = k;
+      }
+    }
+    hipError_t e = hipStreamSynchronize(streams[t]);
+    if (e != hipSuccess) err = (int)e;
+  };
+  const int nt = chunks.size() < (size_t)max_lanes ? (int)chunks.size() : max_lanes;
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
+  if (nt > 0) worker(0);
+  for (auto& x : th) x.join();
+  for (hipStream_t x : temp) (void)hipStreamDestroy(x);
+  return (hipError_t)err.load();
+}
+
+void release_cached_device_memory(); // below: the allocation cache of icicle_malloc / icicle_free
+
 // ---- workspace arena (see common.h) -------------------------------------------------------------
 struct WsBlock {
   void* ptr;
@@ -144,10 +278,12 @@ hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s)
   void* q = nullptr;
   hipError_t e = hipMalloc(&q, bytes);
   if (e != hipSuccess) {
-    // drop cached free blocks of this stream and retry once
+    // drop cached free blocks of this stream (and the allocation cache of the C API) and retry once
+    (void)hipGetLastError();
     for (auto it = v.begin(); it != v.end();) {
       if (!it->in_use) { (void)hipFree(it->ptr); it = v.erase(it); } else ++it;
     }
+    release_cached_device_memory();
     e = hipMalloc(&q, bytes);
     if (e != hipSuccess) return e;
   }
@@ -255,11 +391,105 @@ ISNARK_API eIcicleError icicle_is_active_device_memory(const void* ptr)
   return d == active_device() ? ICICLE_SUCCESS : ICICLE_INVALID_POINTER;
 }
 
+// ---- device allocations ---------------------------------------------------------------------------------------------
+// The reference's host allocates and drops its big work buffers in EVERY prove (DeviceVec::device_malloc_async / Drop →
+// icicle_free: n_coef·32 B, 3n·32 B, n_vars·32 B — 350 MB at 1.6 M constraints, src/proof_helper.rs:41-42,189).  hipMalloc /
+// hipFree of such blocks cost milliseconds each and hipFree drains the device, so freed blocks of ≥ 1 MB are kept in a
+// size-keyed cache (per device, ≤ ALLOC_CACHE_MAX bytes) and handed out again.  icicle_free keeps hipFree's implicit
+// "everything submitted so far has finished" by synchronising the device before the block becomes reusable.
+constexpr size_t ALLOC_CACHE_MIN = 1u << 20;
+static size_t alloc_cache_max()
+{
+  static const size_t v = getenv("ICICLE_SNARK_ALLOC_CACHE_MB") ? (size_t)atoll(getenv("ICICLE_SNARK_ALLOC_CACHE_MB")) << 20 : (size_t)16 << 30;
+  return v;
+}
+struct AllocCache {
+  std::multimap<size_t, void*> blocks; // capacity → block
+  size_t bytes = 0;
+};
+static std::mutex g_ac_mu;
+static std::map<int, AllocCache> g_alloc_cache;            // device → cache
+static std::map<uintptr_t, size_t> g_capacity;             // live block → its real (hipMalloc) size
+
+static void alloc_cache_flush(int dev) // caller holds g_ac_mu
+{
+  AllocCache& c = g_alloc_cache[dev];
+  for (auto& kv : c.blocks) (void)hipFree(kv.second);
+  c.blocks.clear();
+  c.bytes = 0;
+}
+namespace isnark {
+void release_cached_device_memory()
+{
+  std::lock_guard<std::mutex> lk(g_ac_mu);
+  int d = 0;
+  (void)hipGetDevice(&d);
+  alloc_cache_flush(d);
+}
+} // namespace isnark
+static hipError_t cached_malloc(void** ptr, size_t size)
+{
+  const int dev = t_device;
+  if (size >= ALLOC_CACHE_MIN) {
+    std::lock_guard<std::mutex> lk(g_ac_mu);
+    AllocCache& c = g_alloc_cache[dev];
+    auto it = c.blocks.lower_bound(size);
+    if (it != c.blocks.end() && it->first <= size + size / 8) {
+      *ptr = it->second;
+      g_capacity[(uintptr_t)*ptr] = it->first;
+      c.bytes -= it->first;
+      c.blocks.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(ptr, size);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_ac_mu);
+    alloc_cache_flush(dev); // give the cached blocks back to the driver and retry once
+    e = hipMalloc(ptr, size);
+  }
+  if (e == hipSuccess && size >= ALLOC_CACHE_MIN) {
+    std::lock_guard<std::mutex> lk(g_ac_mu);
+    g_capacity[(uintptr_t)*ptr] = size;
+  }
+  return e;
+}
+// the block leaves the caller's hands: cache it (after draining the device) or return it to the driver
+static hipError_t cached_free(void* ptr, int owner)
+{
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_ac_mu);
+    auto it = g_capacity.find((uintptr_t)ptr);
+    if (it != g_capacity.end()) {
+      cap = it->second;
+      g_capacity.erase(it);
+    }
+  }
+  if (cap >= ALLOC_CACHE_MIN && cap <= alloc_cache_max() / 2) {
+    hipError_t e = hipDeviceSynchronize(); // what hipFree would have implied
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_ac_mu);
+    AllocCache& c = g_alloc_cache[owner];
+    while (!c.blocks.empty() && c.bytes + cap > alloc_cache_max()) { // evict the smallest blocks first
+      auto it = c.blocks.begin();
+      (void)hipFree(it->second);
+      c.bytes -= it->first;
+      c.blocks.erase(it);
+    }
+    c.blocks.emplace(cap, ptr);
+    c.bytes += cap;
+    return hipSuccess;
+  }
+  return hipFree(ptr);
+}
+
 ISNARK_API eIcicleError icicle_malloc(void** ptr, size_t size)
 {
   if (!ptr) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(require_device());
-  HIP_TRY(hipMalloc(ptr, size), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(cached_malloc(ptr, size), ICICLE_ALLOCATION_FAILED);
   track(*ptr, size);
   return ICICLE_SUCCESS;
 }
@@ -268,10 +498,10 @@ ISNARK_API eIcicleError icicle_malloc_async(void** ptr, size_t size, icicleStrea
 {
   if (!ptr) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(require_device());
-  // Plain hipMalloc: the returned block is usable at once on any stream, which satisfies the
-  // stream-ordered contract; the stream-ordered pool is avoided (see common.h, workspace arena).
+  // The returned block is usable at once on any stream, which satisfies the stream-ordered contract; the
+  // stream-ordered pool of the HIP runtime is avoided (see common.h, workspace arena).
   (void)stream;
-  HIP_TRY(hipMalloc(ptr, size), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(cached_malloc(ptr, size), ICICLE_ALLOCATION_FAILED);
   track(*ptr, size);
   return ICICLE_SUCCESS;
 }
@@ -285,7 +515,7 @@ ISNARK_API eIcicleError icicle_free(void* ptr)
   int cur = active_device();
   if (owner != cur) (void)hipSetDevice(owner);
   untrack(ptr);
-  hipError_t e = hipFree(ptr);
+  hipError_t e = cached_free(ptr, owner);
   if (owner != cur && cur >= 0) (void)hipSetDevice(cur);
   if (e != hipSuccess) {
     set_last_error("hipFree failed: %s", hipGetErrorString(e));
@@ -297,9 +527,10 @@ ISNARK_API eIcicleError icicle_free(void* ptr)
 ISNARK_API eIcicleError icicle_free_async(void* ptr, icicleStreamHandle stream)
 {
   if (!ptr) return ICICLE_SUCCESS;
+  const int owner = identify(ptr);
   if (!untrack(ptr)) return ICICLE_INVALID_POINTER;
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream), ICICLE_SYNCHRONIZATION_FAILED);
-  HIP_TRY(hipFree(ptr), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(cached_free(ptr, owner < 0 ? t_device : owner), ICICLE_DEALLOCATION_FAILED);
   return ICICLE_SUCCESS;
 }
 
@@ -308,6 +539,10 @@ ISNARK_API eIcicleError icicle_get_available_memory(size_t* total, size_t* free_
   if (!total || !free_) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(require_device());
   HIP_TRY(hipMemGetInfo(free_, total), ICICLE_UNKNOWN_ERROR);
+  {
+    std::lock_guard<std::mutex> lk(g_ac_mu); // cached blocks are available to the caller (the next allocation re-uses or releases them)
+    *free_ += g_alloc_cache[t_device].bytes;
+  }
   return ICICLE_SUCCESS;
 }
 
@@ -346,28 +581,50 @@ ISNARK_API eIcicleError icicle_copy_async(void* dst, const void* src, size_t siz
   HIP_TRY(hipMemcpyAsync(dst, src, size, direction(dst, src), (hipStream_t)stream), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
+// Large copies from/to PAGEABLE host memory (what the reference's Rust host passes: Vec<…> and mmap'ed files,
+// src/proof_helper.rs:73,96-101, src/cache.rs:199-207) go through the parallel pinned-staging engine: the stream is
+// drained first (the copy is ordered behind everything enqueued before it), the bytes are in place when the call
+// returns — a stricter behaviour than "asynchronous", which a pageable copy never is in CUDA/HIP either.
+static eIcicleError big_pageable_copy(void* dst, const void* src, size_t size, bool to_device, hipStream_t stream, bool* done)
+{
+  *done = false;
+  if (size < STAGED_MIN_BYTES || is_pinned_host(to_device ? src : dst)) return ICICLE_SUCCESS;
+  HIP_TRY(hipStreamSynchronize(stream), ICICLE_SYNCHRONIZATION_FAILED);
+  const CopyJob j = {dst, src, size};
+  HIP_TRY(staged_copy(active_device(), &j, 1, to_device), ICICLE_COPY_FAILED);
+  *done = true;
+  return ICICLE_SUCCESS;
+}
 ISNARK_API eIcicleError icicle_copy_to_host(void* dst, const void* src, size_t size)
 {
   ICICLE_TRY(require_device());
-  HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
+  bool done;
+  ICICLE_TRY(big_pageable_copy(dst, src, size, false, nullptr, &done));
+  if (!done) HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
 ISNARK_API eIcicleError icicle_copy_to_host_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
 {
   ICICLE_TRY(require_device());
-  HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  bool done;
+  ICICLE_TRY(big_pageable_copy(dst, src, size, false, (hipStream_t)stream, &done));
+  if (!done) HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t)stream), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
 ISNARK_API eIcicleError icicle_copy_to_device(void* dst, const void* src, size_t size)
 {
   ICICLE_TRY(require_device());
-  HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
+  bool done;
+  ICICLE_TRY(big_pageable_copy(dst, src, size, true, nullptr, &done));
+  if (!done) HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
 ISNARK_API eIcicleError icicle_copy_to_device_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
 {
   ICICLE_TRY(require_device());
-  HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  bool done;
+  ICICLE_TRY(big_pageable_copy(dst, src, size, true, (hipStream_t)stream, &done));
+  if (!done) HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t)stream), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
 
