@@ -253,6 +253,8 @@ static std::mutex g_ws_mu;
 // keyed by (device, stream): the null stream exists on every device
 typedef std::pair<int, hipStream_t> WsKey;
 static std::map<WsKey, std::vector<WsBlock>> g_ws;
+constexpr size_t WS_ORPHAN_MAX = (size_t)8 << 30;
+static std::map<int, std::vector<WsBlock>> g_ws_orphans; // device → idle blocks whose stream was destroyed (ws_release_stream)
 static WsKey ws_key(hipStream_t s)
 {
   int d = 0;
@@ -275,6 +277,19 @@ hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s)
     *p = v[best].ptr;
     return hipSuccess;
   }
+  {
+    // a block left behind by a destroyed stream of this device (idle: that stream was synchronised)
+    std::vector<WsBlock>& orphans = g_ws_orphans[ws_key(s).first];
+    int ob = -1;
+    for (size_t i = 0; i < orphans.size(); i++)
+      if (orphans[i].size >= bytes && orphans[i].size <= 4 * bytes + (1 << 20) && (ob < 0 || orphans[i].size < orphans[ob].size)) ob = (int)i;
+    if (ob >= 0) {
+      v.push_back({orphans[ob].ptr, orphans[ob].size, true});
+      *p = orphans[ob].ptr;
+      orphans.erase(orphans.begin() + ob);
+      return hipSuccess;
+    }
+  }
   void* q = nullptr;
   hipError_t e = hipMalloc(&q, bytes);
   if (e != hipSuccess) {
@@ -283,6 +298,8 @@ hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s)
     for (auto it = v.begin(); it != v.end();) {
       if (!it->in_use) { (void)hipFree(it->ptr); it = v.erase(it); } else ++it;
     }
+    for (auto& b : g_ws_orphans[ws_key(s).first]) (void)hipFree(b.ptr);
+    g_ws_orphans[ws_key(s).first].clear();
     release_cached_device_memory();
     e = hipMalloc(&q, bytes);
     if (e != hipSuccess) return e;
@@ -307,12 +324,24 @@ hipError_t ws_free(void* p, hipStream_t s)
   return hipErrorInvalidValue;
 }
 
+// The stream goes away (the caller has synchronised it): its idle blocks move to the device's orphan list, from which
+// ws_alloc serves the next stream — the reference's host creates and destroys its streams in every prove
+// (src/proof_helper.rs:32,186-187,235-236), and returning ~300 MB of MSM workspace to the driver each time cost
+// 20 ms of hipMalloc / hipFree per prove.
 void ws_release_stream(hipStream_t s)
 {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   for (auto it = g_ws.begin(); it != g_ws.end();) {
     if (it->first.second == s && (s != nullptr || it->first == ws_key(s))) {
-      for (auto& b : it->second) (void)hipFree(b.ptr);
+      std::vector<WsBlock>& orphans = g_ws_orphans[it->first.first];
+      size_t held = 0;
+      for (auto& b : orphans) held += b.size;
+      for (auto& b : it->second) {
+        if (!b.in_use && held + b.size <= WS_ORPHAN_MAX) {
+          orphans.push_back({b.ptr, b.size, false});
+          held += b.size;
+        } else (void)hipFree(b.ptr);
+      }
       it = g_ws.erase(it);
     } else ++it;
   }
@@ -628,10 +657,25 @@ ISNARK_API eIcicleError icicle_copy_to_device_async(void* dst, const void* src, 
   return ICICLE_SUCCESS;
 }
 
+// Streams are pooled: hipStreamCreate costs ≈4 ms on this stack and the reference's host creates and destroys three to
+// five streams in every prove (src/proof_helper.rs:32,186-187, src/conversions.rs:14).  A destroyed stream is drained and
+// parked (≤ STREAM_POOL_MAX per device, with the workspace blocks cached for it); the next create takes it back.
+constexpr size_t STREAM_POOL_MAX = 8;
+static std::mutex g_sp_mu;
+static std::map<int, std::vector<hipStream_t>> g_stream_pool;
 ISNARK_API eIcicleError icicle_create_stream(icicleStreamHandle* stream)
 {
   if (!stream) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(require_device());
+  {
+    std::lock_guard<std::mutex> lk(g_sp_mu);
+    std::vector<hipStream_t>& v = g_stream_pool[t_device];
+    if (!v.empty()) {
+      *stream = v.back();
+      v.pop_back();
+      return ICICLE_SUCCESS;
+    }
+  }
   hipStream_t s;
   HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
   *stream = s;
@@ -639,8 +683,21 @@ ISNARK_API eIcicleError icicle_create_stream(icicleStreamHandle* stream)
 }
 ISNARK_API eIcicleError icicle_destroy_stream(icicleStreamHandle stream)
 {
-  // the workspace blocks cached for this stream go back to the driver with it
+  if (!stream) return ICICLE_SUCCESS;
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
+  {
+    int d = 0;
+    hipDevice_t sd = 0;
+    if (hipStreamGetDevice((hipStream_t)stream, &sd) == hipSuccess) d = (int)sd; // the stream's own device, whatever is active now
+    else (void)hipGetDevice(&d);
+    std::lock_guard<std::mutex> lk(g_sp_mu);
+    std::vector<hipStream_t>& v = g_stream_pool[d];
+    if (v.size() < STREAM_POOL_MAX) {
+      v.push_back((hipStream_t)stream);
+      return ICICLE_SUCCESS;
+    }
+  }
+  // the workspace blocks cached for this stream move to the device's orphan list
   ws_release_stream((hipStream_t)stream);
   HIP_TRY(hipStreamDestroy((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
   return ICICLE_SUCCESS;

@@ -51,6 +51,16 @@ typedef bn254_g2_projective_t G2P;
     }                                                                                                \
   } while (0)
 
+static bool g_trace = false;
+static double g_t_last = 0;
+static double now_ms();
+static void lap(const char* what)
+{
+  if (!g_trace) return;
+  const double t = now_ms();
+  fprintf(stderr, "[dropin] %-40s %8.3f ms\n", what, t - g_t_last);
+  g_t_last = t;
+}
 static double now_ms()
 {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -397,9 +407,21 @@ static F* construct_r1cs(const F* witness, const ZKeyCache& z, double* t_host_ms
   const size_t n_coef = z.c_values.size(), nof_coef = z.domain_size;
   F* d_second_slice = (F*)device_malloc_async(n_coef * sizeof(F), stream);
   F* d_vec = (F*)device_malloc_async(nof_coef * 3 * sizeof(F), stream);
-  std::vector<F> out_buff_b_a(nof_coef * 2); // zero
-  memset(out_buff_b_a.data(), 0, out_buff_b_a.size() * sizeof(F));
-  std::vector<F> second_slice(n_coef), res(n_coef);
+  // vec![ScalarField::zero(); nof_coef * 2] is a zeroed allocation (calloc); Vec::with_capacity + set_len (:49-52, :66-69)
+  // leaves the memory uninitialised — std::vector<F>(n) would write 340 MB of zeros here
+  struct HostBuf {
+    F* p;
+    explicit HostBuf(F* q) : p(q) {}
+    ~HostBuf() { free(p); }
+    F* data() const { return p; }
+    F& operator[](size_t i) const { return p[i]; }
+  };
+  HostBuf out_buff_b_a((F*)calloc(nof_coef * 2, sizeof(F))), second_slice((F*)malloc(n_coef * sizeof(F))), res((F*)malloc(n_coef * sizeof(F)));
+  if (!out_buff_b_a.p || !second_slice.p || !res.p) {
+    fprintf(stderr, "out of host memory\n");
+    exit(2);
+  }
+  lap("r1cs: malloc + host vectors");
   const double t0 = now_ms();
   {
     // second_slice.par_iter_mut(): rayon → plain threads
@@ -413,10 +435,13 @@ static F* construct_r1cs(const F* witness, const ZKeyCache& z, double* t_host_ms
     for (auto& x : th) x.join();
   }
   double host_ms = now_ms() - t0;
+  lap("r1cs: host gather");
   CHK(icicle_copy_to_device_async(d_second_slice, second_slice.data(), n_coef * sizeof(F), stream));
+  lap("r1cs: H2D second_slice");
   scalar_from_mont(d_second_slice, n_coef, stream);
   vec_binop(true, z.first_slice, true, d_second_slice, true, res.data(), false, n_coef, cfg); // result on the HOST
   CHK(icicle_stream_synchronize(stream));
+  lap("r1cs: from_mont + mul -> host + sync");
   const double t1 = now_ms();
   {
     F zero;
@@ -428,13 +453,16 @@ static F* construct_r1cs(const F* witness, const ZKeyCache& z, double* t_host_ms
     }
   }
   host_ms += now_ms() - t1;
+  lap("r1cs: host scatter-add");
   CHK(icicle_copy_to_device_async(d_vec, out_buff_b_a.data() + nof_coef, nof_coef * sizeof(F), stream));
   CHK(icicle_copy_to_device_async(d_vec + nof_coef, out_buff_b_a.data(), nof_coef * sizeof(F), stream));
+  lap("r1cs: H2D b, a");
   vec_binop(true, d_vec, true, d_vec + nof_coef, true, d_vec + 2 * nof_coef, true, nof_coef, cfg);
   ntt_helper(d_vec, 3 * nof_coef, true, stream);
   for (int k = 0; k < 3; k++) vec_binop(true, d_vec + k * nof_coef, true, z.keys, true, d_vec + k * nof_coef, true, nof_coef, cfg);
   ntt_helper(d_vec, 3 * nof_coef, false, stream);
   CHK(icicle_stream_synchronize(stream));
+  lap("r1cs: mul, intt, 3 key muls, ntt + sync");
   CHK(icicle_destroy_stream(stream));
   // L·R − O with a fresh default config (synchronous, null stream) — :152-167
   VecOpsConfig c2 = vec_cfg_default();
@@ -442,7 +470,9 @@ static F* construct_r1cs(const F* witness, const ZKeyCache& z, double* t_host_ms
   vec_binop(false, d_vec, true, d_vec + 2 * nof_coef, true, d_vec + nof_coef, true, nof_coef, c2);
   vec_cfg_drop(c2);
   vec_cfg_drop(cfg);
+  lap("r1cs: final mul/sub (sync)");
   CHK(icicle_free(d_second_slice)); // DeviceVec::drop at the end of the function
+  lap("r1cs: free");
   if (t_host_ms) *t_host_ms = host_ms;
   return d_vec;
 }
@@ -487,9 +517,13 @@ struct Commitments {
 static Commitments groth16_commitments(F* d_vec, const F* scalars, const ZKeyCache& z)
 {
   const size_t nof_coef = z.domain_size;
+  lap("prove: between construct_r1cs and commitments");
   icicleStreamHandle g1 = stream_create(), g2 = stream_create();
+  lap("commitments: 2 streams created");
   F* d_scalars = (F*)device_malloc_async(z.n_vars * sizeof(F), g1);
+  lap("commitments: malloc scalars");
   CHK(icicle_copy_to_device_async(d_scalars, scalars, z.n_vars * sizeof(F), g1));
+  lap("commitments: H2D scalars");
   G1P* ca = msm_helper<G1A, G1P>(d_scalars, z.n_vars, z.points_a, z.len_a, g1, false);
   G1P* cb1 = msm_helper<G1A, G1P>(d_scalars, z.n_vars, z.points_b1, z.len_b1, g1, false);
   G1P* cc = msm_helper<G1A, G1P>(d_scalars + z.n_public + 1, z.n_vars - z.n_public - 1, z.points_c, z.len_c, g1, false);
@@ -501,8 +535,10 @@ static Commitments groth16_commitments(F* d_vec, const F* scalars, const ZKeyCac
   CHK(icicle_copy_to_host_async(&out.b, cb, sizeof(G2P), g2));
   CHK(icicle_copy_to_host_async(&out.c, cc, sizeof(G1P), g1));
   CHK(icicle_copy_to_host_async(&out.h, ch, sizeof(G1P), g1));
+  lap("commitments: 5 msm enqueued");
   CHK(icicle_stream_synchronize(g1));
   CHK(icicle_stream_synchronize(g2));
+  lap("commitments: sync");
   CHK(icicle_destroy_stream(g1));
   CHK(icicle_destroy_stream(g2));
   for (void* p : {(void*)ca, (void*)cb1, (void*)cc, (void*)ch, (void*)cb, (void*)d_scalars, (void*)d_vec}) CHK(icicle_free(p)); // drops
@@ -554,6 +590,7 @@ struct Timing {
 static void prove_once(const char* wtns_path, const ZKeyCache& z, const char* proof_path, const char* public_path, const F* rs_fixed, Timing* tm)
 {
   const double t0 = now_ms();
+  g_t_last = t0;
   BinFile w;
   if (!w.open(wtns_path, "wtns")) {
     fprintf(stderr, "cannot read wtns %s\n", wtns_path);
@@ -649,6 +686,7 @@ int main(int argc, char** argv)
       i += 2;
     } else if (!strcmp(argv[i], "--keys-dir") && i + 1 < argc) keys_dir = argv[++i];
   }
+  g_trace = getenv("DROPIN_TRACE") != nullptr;
   // try_load_and_set_backend_device — src/lib.rs:25-31
   CHK(icicle_load_backend_from_env_or_default());
   IcicleDevice dev;
