@@ -10,6 +10,12 @@ thread_local float g_last_msm_ms[4] = {0, 0, 0, 0};
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
 {
   const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g, pl->L) : reduce_shape<G1::X>(pl->g, pl->L);
+  if (rs.two) {
+    // two-level reduction: four sums [TRI_C, TRI_R, LINE_C, LINE_R]; M = MARK | LO selects the matching host tail
+    if (W) *W = 2;
+    if (M) *M = MSM_TWO_LEVEL_MARK | rs.LO;
+    return 4 * (g2 ? sizeof(G2::X) : sizeof(G1::X));
+  }
   if (W) *W = (uint32_t)pl->g.Wb;
   if (M) *M = rs.M; // scan reduction with several workgroups per slice: the tail adds M·LL (msm_*_host_tail_tab); else 0
   // the workgroups' partial sums are folded on the device: one element per window and kind [S | L (table mode) | LL (M > 0)]

@@ -510,7 +510,11 @@ struct ReduceShape {
   uint32_t tpw, rblock, bpw;
   bool scan;  // small table-mode bucket set: suffix-scan kernels, factor M = rblock << k_log left to the host tail
   uint32_t M; // 0 unless scan && bpw > 1
+  // large table-mode bucket set: row / column sums, then the scan kernel on the LO + HI sums (msm_reduce_rows_kernel …)
+  bool two;
+  uint32_t LO, HI, gy; // bucket b = h·LO + l;  gy = row groups of the column-sum kernel
 };
+constexpr uint32_t MSM_TWO_LEVEL_MARK = 0x80000000u; // msm_partials_bytes: M = MARK | LO tells the host tail which layout it gets
 template <class X>
 ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu)
 {
@@ -535,6 +539,18 @@ ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu)
   }
   r.scan = g.tab && L <= MSM_SCAN_REDUCE_MAX_L;
   r.M = r.scan && r.bpw > 1 ? r.rblock << r.k_log : 0;
+  static const bool two_cfg = !(getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL") && atoi(getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL")) == 0);
+  const uint32_t nb_all = g.NBb * (uint32_t)g.Wb;
+  int nbits = 0;
+  while ((1u << nbits) < nb_all) nbits++;
+  r.two = two_cfg && g.tab && !r.scan && nbits >= 14 && nbits <= 20 && (1u << nbits) == nb_all;
+  r.LO = r.HI = r.gy = 0;
+  if (r.two) {
+    r.LO = 1u << ((nbits + 1) / 2);
+    r.HI = nb_all / r.LO;
+    r.gy = r.HI / 32 ? r.HI / 32 : 1; // 4 row groups of ≤ 8 rows per workgroup
+    if (r.gy > 16) r.gy = 16;
+  }
   return r;
 }
 
@@ -635,6 +651,81 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_scan_kernel(const typen
   }
 }
 
+// ---- two-level bucket reduction (large table-mode sets) ------------------------------------------------------------------
+// Σ_b (b+1)·B_b over ONE bucket set of NB = LO·HI buckets, b = h·LO + l:
+//     Σ_b (b+1)·B_b = Σ_l (l+1)·C_l + LO·Σ_h h·R_h,    C_l = Σ_h B[h][l] (column sums),  R_h = Σ_l B[h][l] (row sums).
+// The 2·NB additions of the row and column sums are plain sums — no per-thread scalar multiplication, chains of ≈ 12
+// additions on 128 K – 256 K threads — and the two weighted sums that remain have LO and HI ≤ 1024 terms: the suffix-scan
+// kernel (msm_bucket_reduce_scan_kernel, one workgroup each) finishes them.  msm_bucket_reduce_kernel gives every thread 16
+// buckets, a running-sum pair AND a double-and-add by its first index (≈ 30 further point operations on the chain): 32 K
+// threads, 0.49 ms for a G1 set of 2^19 buckets and 1.8 ms for G2 — latency-bound kernels whose 392-register G2 waves also
+// kept the accumulation of the next MSM off the SIMDs they sat on.
+// rows: grid = HI workgroups; a workgroup sums the LO consecutive buckets of row h (threads own LO / blockDim consecutive ones)
+template <class C>
+__global__ __launch_bounds__(256) void msm_reduce_rows_kernel(const typename C::X* __restrict__ buckets, uint32_t LO, typename C::X* __restrict__ sums /* [LO + h] */)
+{
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sh = reinterpret_cast<X*>(smem);
+  const uint32_t per = LO / blockDim.x;
+  const typename C::X* B = buckets + (size_t)blockIdx.x * LO + (size_t)threadIdx.x * per;
+  X acc = CL::x_load_internal(B[0]);
+  for (uint32_t j = 1; j < per; j++) acc = CL::x_add(acc, CL::x_load_internal(B[j]));
+  acc = block_reduce_lazy<C>(acc, sh, (int)blockDim.x);
+  if (threadIdx.x == 0) sums[LO + blockIdx.x] = CL::x_store_internal(acc);
+}
+// columns: grid = (LO / 64, gy); a workgroup of 4 waves covers 64 columns × (HI / gy) rows — wave q the rows of its quarter,
+// lane l one column (a row's 64 buckets are one contiguous 8 / 16 KiB read) — and emits 64 partial column sums
+template <class C>
+__global__ __launch_bounds__(256) void msm_reduce_cols_kernel(const typename C::X* __restrict__ buckets, uint32_t LO, uint32_t HI, typename C::X* __restrict__ partial /* [gy][LO] */)
+{
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sh = reinterpret_cast<X*>(smem); // [4][64]
+  const uint32_t lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const uint32_t col = blockIdx.x * 64 + lane;
+  const uint32_t rows_wg = HI / gridDim.y, rows_q = rows_wg / 4 ? rows_wg / 4 : 1;
+  const uint32_t h0 = blockIdx.y * rows_wg + q * rows_q;
+  X acc = CL::x_zero();
+  if (q * rows_q < rows_wg) {
+    acc = CL::x_load_internal(buckets[(size_t)h0 * LO + col]);
+    for (uint32_t j = 1; j < rows_q; j++) acc = CL::x_add(acc, CL::x_load_internal(buckets[(size_t)(h0 + j) * LO + col]));
+  }
+  sh[q * 64 + lane] = acc;
+  __syncthreads();
+  if (q < 2) sh[q * 64 + lane] = acc = CL::x_add(acc, sh[(q + 2) * 64 + lane]);
+  __syncthreads();
+  if (q == 0) partial[(size_t)blockIdx.y * LO + col] = CL::x_store_internal(CL::x_add(acc, sh[64 + lane]));
+}
+// columns, last step: C_l = Σ_y partial[y][l]; workgroup = 16 columns × 16 slots (gy ≤ 16), tree over the slots
+template <class C>
+__global__ __launch_bounds__(256) void msm_reduce_cols_final_kernel(const typename C::X* __restrict__ partial, uint32_t LO, uint32_t gy, typename C::X* __restrict__ sums /* [l] */)
+{
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sh = reinterpret_cast<X*>(smem); // [16 slots][16 columns]
+  const uint32_t c = threadIdx.x & 15, y = threadIdx.x >> 4;
+  const uint32_t col = blockIdx.x * 16 + c;
+  X acc = y < gy ? CL::x_load_internal(partial[(size_t)y * LO + col]) : CL::x_zero();
+  sh[y * 16 + c] = acc;
+  __syncthreads();
+  for (uint32_t st = 8; st > 0; st >>= 1) {
+    if (y < st) sh[y * 16 + c] = acc = CL::x_add(acc, sh[(y + st) * 16 + c]);
+    __syncthreads();
+  }
+  if (y == 0) sums[col] = CL::x_store_internal(acc);
+}
+// zero the padding of the row-sum half when HI < LO (the scan kernel treats both halves as LO-bucket windows)
+template <class C>
+__global__ __launch_bounds__(256) void msm_reduce_pad_kernel(typename C::X* __restrict__ sums, uint32_t first, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sums[first + i] = C::x_zero();
+}
+
 // more than 64 KiB of dynamic LDS (two lazy XYZZ per thread) has to be allowed once per kernel
 template <class K>
 inline void allow_big_lds(K kernel, size_t bytes)
@@ -664,7 +755,7 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   WsScoped<X> raw;
   WsScoped<uint32_t> own_tickets;
   uint32_t* tickets = nullptr;
-  if (rs.bpw > 1) {
+  if (rs.bpw > 1 && !rs.two) {
     // per-workgroup results + one ticket counter per window: the workgroup that finishes a window last folds it.  The
     // counters were zeroed with the sort's own (a memset here is one more launch on a latency chain)
     HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * 2, s), ICICLE_ALLOCATION_FAILED);
@@ -677,6 +768,29 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   }
   typedef typename Lazy<C>::type::X LX;
   const size_t lds_r = 2 * (size_t)rs.rblock * sizeof(LX);
+  if (rs.two) {
+    // row sums | column sums → [C_0 … C_{LO−1} | R_0 … R_{HI−1}, 0 …] → the scan kernel on two LO-bucket windows:
+    // out = [Σ(l+1)·C_l, Σ(h+1)·R_h | Σ C_l, Σ R_h]; the host tail forms TRI_C + LO·(TRI_R − LINE_R)
+    WsScoped<X> sums, partial;
+    HIP_TRY(sums.alloc(2 * (size_t)rs.LO, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(partial.alloc((size_t)rs.gy * rs.LO, s), ICICLE_ALLOCATION_FAILED);
+    uint32_t rb = sizeof(X) > 128 ? 128 : 256; // LDS tree buffer ≤ 36 KiB
+    if (rb > rs.LO) rb = rs.LO;
+    hipLaunchKernelGGL((msm_reduce_rows_kernel<C>), dim3(rs.HI), dim3(rb), rb * sizeof(LX), s, buckets.p, rs.LO, sums.p);
+    allow_big_lds(msm_reduce_cols_kernel<C>, 256 * sizeof(LX));
+    allow_big_lds(msm_reduce_cols_final_kernel<C>, 256 * sizeof(LX));
+    hipLaunchKernelGGL((msm_reduce_cols_kernel<C>), dim3(rs.LO / 64, rs.gy), dim3(256), 256 * sizeof(LX), s, buckets.p, rs.LO, rs.HI, partial.p);
+    hipLaunchKernelGGL((msm_reduce_cols_final_kernel<C>), dim3(rs.LO / 16), dim3(256), 256 * sizeof(LX), s, partial.p, rs.LO, rs.gy, sums.p);
+    if (rs.HI < rs.LO) hipLaunchKernelGGL((msm_reduce_pad_kernel<C>), dim3((rs.LO - rs.HI + 255) / 256), dim3(256), 0, s, sums.p, rs.LO + rs.HI, rs.LO - rs.HI);
+    const uint32_t sblock = sizeof(X) > 128 ? 128 : 256;
+    int sk = 0;
+    while ((sblock << sk) < rs.LO) sk++;
+    const size_t lds_s = 2 * (size_t)sblock * sizeof(LX);
+    allow_big_lds(msm_bucket_reduce_scan_kernel<C>, lds_s);
+    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(1, 2), dim3(sblock), lds_s, s, sums.p, rs.LO, sk, d_partials, (X*)nullptr, (uint32_t*)nullptr);
+    ICICLE_TRY(check_launch("msm_bucket_reduce (two-level)"));
+    return ICICLE_SUCCESS;
+  }
   if (rs.scan) {
     // small table-mode set: [TT | L | LL] (LL only with more than one workgroup per slice; the host applies M)
     allow_big_lds(msm_bucket_reduce_scan_kernel<C>, lds_r);
@@ -696,6 +810,12 @@ template <class C>
 typename C::P msm_host_tail_tab(const typename C::X* part, uint32_t Wb, uint32_t M, uint32_t NBb)
 {
   typedef typename C::X X;
+  if (M & MSM_TWO_LEVEL_MARK) {
+    // two-level reduction: part = [Σ(l+1)·C_l, Σ(h+1)·R_h, Σ C_l, Σ R_h];  Σ_b (b+1)·B_b = part[0] + LO·(part[1] − part[3])
+    X U = C::x_add(part[1], C::x_neg(part[3]));
+    for (uint32_t m = M & ~MSM_TWO_LEVEL_MARK; m > 1; m >>= 1) U = C::x_dbl(U);
+    return C::p_from_mont(C::x_to_projective(C::x_add(part[0], U)));
+  }
   X S = C::x_zero(), run = C::x_zero(), U = C::x_zero(), LL = C::x_zero();
   for (int v = (int)Wb - 1; v >= 0; v--) {
     S = C::x_add(S, part[v]);
