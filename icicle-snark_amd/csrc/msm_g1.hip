@@ -9,7 +9,7 @@ thread_local float g_last_msm_ms[4] = {0, 0, 0, 0};
 
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
 {
-  const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g, pl->L) : reduce_shape<G1::X>(pl->g, pl->L);
+  const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g, pl->L, pl->reduce_pref) : reduce_shape<G1::X>(pl->g, pl->L, pl->reduce_pref);
   if (rs.two) {
     // two-level reduction: four sums [TRI_C, TRI_R, LINE_C, LINE_R]; M = MARK | LO selects the matching host tail
     if (W) *W = 2;

@@ -516,7 +516,7 @@ struct ReduceShape {
 };
 constexpr uint32_t MSM_TWO_LEVEL_MARK = 0x80000000u; // msm_partials_bytes: M = MARK | LO tells the host tail which layout it gets
 template <class X>
-ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu)
+ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu, int pref = 0)
 {
   ReduceShape r;
   int lnb = 0;
@@ -537,13 +537,17 @@ ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu)
     r.bpw = r.tpw / r.rblock;
     if (r.bpw <= r.rblock) break; // the workgroup that finishes a window last folds its bpw results with one thread each
   }
-  r.scan = g.tab && L <= MSM_SCAN_REDUCE_MAX_L;
+  static const uint32_t scan_max_l = getenv("ICICLE_SNARK_SCAN_REDUCE_MAX_L") ? (uint32_t)atoll(getenv("ICICLE_SNARK_SCAN_REDUCE_MAX_L")) : MSM_SCAN_REDUCE_MAX_L;
+  r.scan = g.tab && L <= scan_max_l;
   r.M = r.scan && r.bpw > 1 ? r.rblock << r.k_log : 0;
-  static const bool two_cfg = !(getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL") && atoi(getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL")) == 0);
+  // Opt-in (ICICLE_SNARK_REDUCE_TWO_LEVEL=1): interleaved A/B runs of benchmark/1600k on MI355X put it within ±0.15 ms of
+  // the single kernel (16.2–16.5 ms either way) — it does half the additions on 4–8× the threads, but its four dependent
+  // launches are as long as the single kernel's chain when the GPU is otherwise idle (0.8 vs 0.5 ms at the end of a prove).
+  static const bool two_cfg = getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL") && atoi(getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL")) != 0;
   const uint32_t nb_all = g.NBb * (uint32_t)g.Wb;
   int nbits = 0;
   while ((1u << nbits) < nb_all) nbits++;
-  r.two = two_cfg && g.tab && !r.scan && nbits >= 14 && nbits <= 20 && (1u << nbits) == nb_all;
+  r.two = two_cfg && pref != 1 && g.tab && !r.scan && nbits >= 14 && nbits <= 20 && (1u << nbits) == nb_all;
   r.LO = r.HI = r.gy = 0;
   if (r.two) {
     r.LO = 1u << ((nbits + 1) / 2);
@@ -739,7 +743,7 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
 {
   typedef typename C::X X;
   const MsmGeom& g = pl->g;
-  const ReduceShape rs = reduce_shape<X>(g, pl->L);
+  const ReduceShape rs = reduce_shape<X>(g, pl->L, pl->reduce_pref);
   WsScoped<X> buckets, item_partials;
   HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);

@@ -53,6 +53,9 @@ struct SortPlan {
   uint32_t* order = nullptr;   // [nbuckets] bucket ids by decreasing entry count (wave-uniform trip counts)
   uint32_t* sorted = nullptr;  // [L·W] (index within the scalar vector) | sign << 31, grouped by bucket
   hipStream_t stream = nullptr;
+  // bucket reduction of large table-mode sets: 0 = two-level row / column sums (least work: 4 short kernels), 1 = the single
+  // kernel (one launch, shortest chain when it runs alone) — the prover asks for 1 on the MSM whose reduction ends the prove
+  int reduce_pref = 0;
   SortPlan() = default;
   SortPlan(const SortPlan&) = delete;
   SortPlan& operator=(const SortPlan&) = delete;

@@ -827,8 +827,21 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   static const int h_behind_cfg = getenv("ICICLE_SNARK_H_BEHIND") ? atoi(getenv("ICICLE_SNARK_H_BEHIND")) : 1; // 0 = A, 1 = B1, 2 = C
   const int h_behind = h_behind_cfg < 0 || h_behind_cfg > 2 ? 1 : h_behind_cfg;
   const bool h_own = z->H.len() <= (1u << 19);
-  hipStream_t gh = h_own ? g3 : st3[h_behind];
-  if (!h_own) P_HIP(hipStreamWaitEvent(gh, z->ev_sort_h, 0));
+  // Large circuits: H is queued behind the whole chain of the MSM in front of it.  ICICLE_SNARK_H_AFTER=acc lets it wait
+  // only for that MSM's ACCUMULATION kernel (prof->ev[2]) on its own stream: the timeline shows ≈1 ms between the end of the
+  // four witness accumulations and the start of H's (the other MSM's empty large-bucket kernels and reduction sit in
+  // between), yet filling that gap makes the prove SLOWER — interleaved A/B on MI355X, 1.6 M constraints: 16.35–16.48 ms
+  // against 16.0–16.2 ms: H then overlaps the tails of three other accumulations, and five concurrent accumulations are
+  // less efficient than four followed by one.
+  static const bool h_after_chain = !(getenv("ICICLE_SNARK_H_AFTER") && !strcmp(getenv("ICICLE_SNARK_H_AFTER"), "acc"));
+  const bool h_chain = !h_own && h_after_chain;
+  hipStream_t gh = h_chain ? st3[h_behind] : g3;
+  if (h_chain) P_HIP(hipStreamWaitEvent(gh, z->ev_sort_h, 0));
+  else if (!h_own) P_HIP(hipStreamWaitEvent(gh, prof[order[h_behind]]->ev[2], 0));
+  // H's reduction is the last kernel of the prove: the single-kernel form (0.49 ms alone) even when the two-level
+  // reduction is switched on for the others
+  static const int h_reduce_pref = getenv("ICICLE_SNARK_H_REDUCE") ? atoi(getenv("ICICLE_SNARK_H_REDUCE")) : 1;
+  plan_h.reduce_pref = h_reduce_pref;
   fill(prof[4], plan_h, 0);
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
   (void)hipEventRecord(prof[4]->ev[3], gh);
@@ -841,7 +854,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Ww, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
   const size_t sizes[5] = {by1, by1, by2, by1, byh};
   hipStream_t st5[5] = {st3[0], st3[1], g2, st3[2], gh};
-  if (!h_own) {
+  if (h_chain) {
     // the copy of the MSM in front of H must not wait for H (same stream): its partials were complete at its ev[3], copy them on g3 instead
     P_HIP(hipStreamWaitEvent(g3, prof[order[h_behind]]->ev[3], 0));
     st5[order[h_behind]] = g3;

@@ -167,14 +167,17 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
       streams[t] = st;
     }
   } else {
+    // per-call copies of the C ABI: four workers fill their pinned buffers in parallel and enqueue the DMAs on ONE
+    // persistent stream of the engine — every extra idle stream takes one of the GPU_MAX_HW_QUEUES hardware queues away
+    // from the prover's own streams (with four lane streams alive, two of the prover's six shared a queue)
     std::vector<hipStream_t>& v = P.lanes[device_id];
-    max_lanes = 4; // per-call copies of the C ABI: four lanes reach the PCIe rate without crowding the hardware queues
-    while ((int)v.size() < max_lanes) {
+    max_lanes = 4;
+    if (v.empty()) {
       hipStream_t st;
       if ((e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return e0;
       v.push_back(st);
     }
-    for (int t = 0; t < max_lanes; t++) streams[t] = v[t];
+    for (int t = 0; t < max_lanes; t++) streams[t] = v[0];
   }
   std::atomic<size_t> next{0};
   std::atomic<int> err{(int)hipSuccess};

@@ -233,3 +233,31 @@ def test_edge_scalars_in_the_witness(gpu, cm, O, S):
     proof, public = O.groth16_prove(zkey, wtns, 7, 11)
     assert json.loads(pj) == proof and json.loads(qj) == public
     cm.evict("edge")
+
+
+def test_optional_schedules_and_reductions_give_the_same_proof(gpu, O, S, tmp_path):
+    """the opt-in variants kept for A/B measurements (two-level bucket reduction for every MSM, H released behind the
+    accumulation kernel of the MSM in front of it, unfused NTT) must produce the oracle's proof too — each runs in its own
+    process because the library reads the knobs once"""
+    import subprocess
+    import sys
+    K = gpu
+    N = 70_000                                     # domain 2^17: table mode, bucket sets large enough for the two-level path
+    import importlib
+    bench = importlib.import_module("bench")
+    zkey, wtns = bench.make_inputs(K, S, N)
+    (tmp_path / "c.zkey").write_bytes(zkey)
+    (tmp_path / "w.wtns").write_bytes(wtns)
+    proof, public = O.groth16_prove(zkey, wtns, 9, 4)
+    code = (
+        "import importlib, json, sys; sys.path.insert(0, %r)\n"
+        "K = importlib.import_module('icicle-snark_amd'); K.set_device('HIP', 0)\n"
+        "cm = K.CacheManager(); cm.load('k', open(%r, 'rb').read())\n"
+        "pj, qj, _ = cm.prove_mem('k', open(%r, 'rb').read(), 9, 4); print(json.dumps([json.loads(pj), json.loads(qj)]))\n"
+    ) % (ROOT, str(tmp_path / "c.zkey"), str(tmp_path / "w.wtns"))
+    for env in ({"ICICLE_SNARK_REDUCE_TWO_LEVEL": "1", "ICICLE_SNARK_H_REDUCE": "0", "ICICLE_SNARK_SCAN_REDUCE_MAX_L": "0"},
+                {"ICICLE_SNARK_H_AFTER": "acc", "ICICLE_SNARK_EARLY": "0"}, {"ICICLE_SNARK_NTT_FUSE": "0"}):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stderr[-2000:]
+        got = json.loads(out.stdout.strip().splitlines()[-1])
+        assert got == [proof, public], env
