@@ -13,6 +13,7 @@
 //              The order inside a bucket is arbitrary — addition is commutative, results are not affected.
 // HBM traffic: 2 × 32 B per scalar read, 4 B per digit written (the key is implicit in the position): the
 // reference moves 8-byte (key, value) pairs through three CUB radix sorts + RLE + scan (cuda_msm.cuh:401-485, :561-636).
+#include <atomic>
 #include <mutex>
 #include <string.h>
 
@@ -466,6 +467,297 @@ __global__ __launch_bounds__(256) void msm_fine_place_kernel(const uint32_t* __r
   }
 }
 
+
+// ---- LDS-staged two-pass sort (table mode, large sets) ------------------------------------------------------------------
+// PMC of the two-level scatter above on MI355X (profiles/r02_pmc_*): the partition pass WRITES 640 MB for 83 MB of entries
+// and the place pass 197 MB — a store instruction costs one 32-byte fabric write per sector it touches and the L2 does not
+// merge the 4-byte stores of different instructions, so entries must leave a workgroup as runs of consecutive lanes.  Here
+// both passes sort their tile in LDS first and copy it out linearly:
+//  A  a tile of 2048 scalars counts its digits per PARTITION (top bits of the bucket), a scan over tiles gives every
+//     (tile, partition) run its place (no atomics, deterministic), and the tile is written as ≤ P runs of ≈ 26 entries.  Entries
+//     carry the scalar's index WITHIN THE TILE (11 bits), which leaves room for up to 16 low bucket bits in 32 bits — P can be
+//     1024 instead of 8192, runs are 8× longer;
+//  B  a partition (≈ 25 K entries; chunks of 30 K when a skewed witness makes one larger) is counting-sorted by its low
+//     bucket bits in LDS and written out as ONE contiguous block; the tile of an entry — needed to restore the global scalar
+//     index — is found from its position in the partition (runs are in tile order) by a binary search in the partition's
+//     column of run offsets.  Per-bucket counts and offsets fall out of the chunk histograms.
+// HBM bytes: scalars 2 × 32·L, entries 4·L·W written and read twice, 4·L·W written — each once, in full lines.
+constexpr int S2_TILE = 2048;         // scalars per tile (pass A)
+constexpr int S2_CHUNK = 30720;       // entries per chunk (pass B): 120 KiB of LDS
+constexpr int S2_W_SHIFT = 11, S2_LOW_SHIFT = 15;
+constexpr int S2_THREADS = 1024;
+constexpr size_t S2_LDS_MAX = 159 * 1024; // dynamic LDS next to a few static words (160 KiB per workgroup)
+
+// largest i < n with a[i] <= x (a non-decreasing, a[0] <= x)
+__device__ __forceinline__ uint32_t s2_upper(const uint32_t* a, uint32_t n, uint32_t x)
+{
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] <= x) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t* __restrict__ cnt)
+{
+  extern __shared__ uint32_t sh[];
+  for (uint32_t p = threadIdx.x; p < P; p += 256) sh[p] = 0;
+  __syncthreads();
+  const uint32_t first = blockIdx.x * S2_TILE;
+  for (int u = 0; u < S2_TILE / 256; u++) {
+    const uint32_t i = first + u * 256 + threadIdx.x;
+    if (i < L) {
+      uint32_t t[9], neg;
+      recode(scalars, i, g, mont, t, neg);
+      for (int w = 0; w < g.W; w++) {
+        const uint32_t d = digit(t, w, g);
+        if (d) atomicAdd(&sh[((d & 0x7fffffffu) - 1) >> low_b], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < P; p += 256) cnt[(size_t)blockIdx.x * P + p] = sh[p];
+}
+// exclusive scan over the tiles of every partition: cnt[t][p] ← entries of partition p in tiles < t; the same numbers
+// transposed (off_T[p][0..ntiles], last = total) for pass B; totals[p]
+__global__ __launch_bounds__(256) void sort2_tile_scan_kernel(uint32_t* __restrict__ cnt, uint32_t ntiles, uint32_t P, uint32_t* __restrict__ off_T, uint32_t* __restrict__ totals)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  uint32_t run = 0;
+  uint32_t* row = off_T + (size_t)p * (ntiles + 1);
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const uint32_t c = cnt[(size_t)t * P + p];
+    cnt[(size_t)t * P + p] = run;
+    row[t] = run;
+    run += c;
+  }
+  row[ntiles] = run;
+  totals[p] = run;
+}
+// partition starts and first chunk of every partition (one workgroup; P ≤ 4096)
+__global__ __launch_bounds__(1024) void sort2_part_scan_kernel(const uint32_t* __restrict__ totals, uint32_t P, uint32_t* __restrict__ part_start, uint32_t* __restrict__ chunk_first)
+{
+  __shared__ uint32_t a[4096], b[4096];
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) a[p] = totals[p];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0, crun = 0;
+    for (uint32_t p = 0; p < P; p++) {
+      const uint32_t t = a[p];
+      a[p] = run;
+      b[p] = crun;
+      run += t;
+      crun += (t + S2_CHUNK - 1) / S2_CHUNK;
+    }
+    part_start[P] = run;
+    chunk_first[P] = crun;
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+    part_start[p] = a[p];
+    chunk_first[p] = b[p];
+  }
+}
+// pass A: the tile's entries sorted by partition in LDS, then copied out run by run
+__global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P,
+                                                                           const uint32_t* __restrict__ off, const uint32_t* __restrict__ part_start, uint32_t* __restrict__ tmp)
+{
+  extern __shared__ uint32_t sh[];
+  uint32_t* base = sh;          // [P + 1] exclusive prefix of the tile's partition counts
+  uint32_t* cur = sh + P + 1;   // [P] rank counters, then the global position minus the local one
+  uint32_t* buf = cur + P;      // [S2_TILE · W]
+  __shared__ uint32_t s_total;
+  const uint32_t first = blockIdx.x * S2_TILE;
+  const uint32_t low_mask = (1u << low_b) - 1;
+  for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = 0;
+  __syncthreads();
+  for (int u = 0; u < S2_TILE / S2_THREADS; u++) {
+    const uint32_t i = first + u * S2_THREADS + threadIdx.x;
+    if (i < L) {
+      uint32_t t[9], neg;
+      recode(scalars, i, g, mont, t, neg);
+      for (int w = 0; w < g.W; w++) {
+        const uint32_t d = digit(t, w, g);
+        if (d) atomicAdd(&cur[((d & 0x7fffffffu) - 1) >> low_b], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    // exclusive scan of P counters by one wave: lane l owns P/64 consecutive ones
+    const uint32_t per = (P + 63) / 64, lo = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < per; k++)
+      if (lo + k < P) s += cur[lo + k];
+    uint32_t incl = s;
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t o = __shfl_up(incl, dlt, 64);
+      if ((int)threadIdx.x >= dlt) incl += o;
+    }
+    uint32_t run = incl - s;
+    for (uint32_t k = 0; k < per; k++)
+      if (lo + k < P) {
+        base[lo + k] = run;
+        run += cur[lo + k];
+      }
+    if (threadIdx.x == 63) {
+      base[P] = incl;
+      s_total = incl;
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = 0;
+  __syncthreads();
+  for (int u = 0; u < S2_TILE / S2_THREADS; u++) {
+    const uint32_t li = u * S2_THREADS + threadIdx.x, i = first + li;
+    if (i < L) {
+      uint32_t t[9], neg;
+      recode(scalars, i, g, mont, t, neg);
+      for (int w = 0; w < g.W; w++) {
+        const uint32_t d = digit(t, w, g);
+        if (d) {
+          const uint32_t bk = (d & 0x7fffffffu) - 1, p = bk >> low_b;
+          const uint32_t r = atomicAdd(&cur[p], 1u);
+          buf[base[p] + r] = li | ((uint32_t)w << S2_W_SHIFT) | ((bk & low_mask) << S2_LOW_SHIFT) | (((d >> 31) ^ neg) << 31);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // cur[p] ← where the run of partition p starts in tmp, minus its start in buf
+  for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = part_start[p] + off[(size_t)blockIdx.x * P + p] - base[p];
+  __syncthreads();
+  const uint32_t total = s_total;
+  for (uint32_t e = threadIdx.x; e < total; e += S2_THREADS) {
+    const uint32_t p = s2_upper(base, P, e);
+    tmp[e + cur[p]] = buf[e];
+  }
+}
+// the chunk a workgroup owns: partition, first entry, number of entries (false: beyond the last chunk)
+__device__ __forceinline__ bool s2_chunk_of(uint32_t c, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, uint32_t& p, uint32_t& start, uint32_t& n)
+{
+  __shared__ uint32_t s_p;
+  if (c >= chunk_first[P]) return false;
+  if (threadIdx.x == 0) s_p = s2_upper(chunk_first, P, c); // the partition whose first chunk is the last one ≤ c (empty partitions share a value: the largest wins, and only a non-empty one can be it)
+  __syncthreads();
+  p = s_p;
+  const uint32_t k = c - chunk_first[p];
+  start = part_start[p] + k * S2_CHUNK;
+  const uint32_t end = part_start[p + 1];
+  n = end - start < (uint32_t)S2_CHUNK ? end - start : (uint32_t)S2_CHUNK;
+  return true;
+}
+// pass B, step 1: histogram of a chunk over the partition's 2^low_b buckets
+__global__ __launch_bounds__(S2_THREADS) void sort2_chunk_hist_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, int low_b,
+                                                                       uint32_t* __restrict__ chunk_hist)
+{
+  __shared__ uint32_t hist[1024];
+  uint32_t p, start, n;
+  if (!s2_chunk_of(blockIdx.x, part_start, chunk_first, P, p, start, n)) return;
+  const uint32_t NL = 1u << low_b;
+  for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) hist[b] = 0;
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < n; q += S2_THREADS) atomicAdd(&hist[(tmp[start + q] >> S2_LOW_SHIFT) & (NL - 1)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) chunk_hist[(size_t)blockIdx.x * NL + b] = hist[b];
+}
+// pass B, step 2: one workgroup per partition, one thread per bucket: counts, offsets, the chunk's place inside each bucket,
+// large buckets registered (as msm_fine_place_kernel does)
+__global__ __launch_bounds__(1024) void sort2_bucket_scan_kernel(const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ part_start,
+                                                                  const uint32_t* __restrict__ chunk_first, int low_b, uint32_t thr, uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                                  uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list, uint32_t* __restrict__ large_first, uint2* __restrict__ large_items,
+                                                                  uint32_t item_cap)
+{
+  __shared__ uint32_t sc[1024];
+  const uint32_t NL = 1u << low_b, p = blockIdx.x, b = threadIdx.x;
+  const uint32_t c0 = chunk_first[p], c1 = chunk_first[p + 1];
+  uint32_t run = 0;
+  for (uint32_t c = c0; c < c1; c++) {
+    const uint32_t h = chunk_hist[(size_t)c * NL + b];
+    chunk_off[(size_t)c * NL + b] = run;
+    run += h;
+  }
+  sc[b] = run;
+  __syncthreads();
+  for (uint32_t d = 1; d < NL; d <<= 1) { // inclusive scan over the partition's buckets
+    const uint32_t x = b >= d ? sc[b - d] : 0;
+    __syncthreads();
+    sc[b] += x;
+    __syncthreads();
+  }
+  const uint32_t bucket = (p << low_b) + b;
+  counts[bucket] = run;
+  offsets[bucket] = part_start[p] + sc[b] - run;
+  if (run > thr) {
+    const uint32_t li = atomicAdd(n_large, 1u);
+    const uint32_t nch = (run + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK;
+    const uint32_t firsti = atomicAdd(n_large + 2, nch);
+    large_list[li] = bucket;
+    large_first[li] = firsti;
+    for (uint32_t q = 0; q < nch && firsti + q < item_cap; q++) large_items[firsti + q] = make_uint2(bucket, q);
+  }
+}
+// pass B, step 3: the chunk counting-sorted by bucket in LDS (entries rewritten with the global scalar index), copied out
+__global__ __launch_bounds__(S2_THREADS) void sort2_chunk_place_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, int low_b,
+                                                                        const uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ offsets,
+                                                                        const uint32_t* __restrict__ off_T, uint32_t ntiles, MsmGeom g, uint32_t* __restrict__ sorted)
+{
+  extern __shared__ uint32_t sh[];
+  const uint32_t NL = 1u << low_b;
+  uint32_t* lbase = sh;             // [NL + 1]
+  uint32_t* lcur = sh + NL + 1;     // [NL] rank counters, then global position minus local one
+  uint32_t* col = lcur + NL;        // [ntiles + 1] first entry of every tile's run inside the partition
+  uint32_t* buf = col + ntiles + 1; // [S2_CHUNK]
+  uint32_t p, start, n;
+  if (!s2_chunk_of(blockIdx.x, part_start, chunk_first, P, p, start, n)) return;
+  for (uint32_t t = threadIdx.x; t <= ntiles; t += S2_THREADS) col[t] = off_T[(size_t)p * (ntiles + 1) + t];
+  for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) {
+    lcur[b] = chunk_hist[(size_t)blockIdx.x * NL + b];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t per = (NL + 63) / 64, lo = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < per; k++)
+      if (lo + k < NL) s += lcur[lo + k];
+    uint32_t incl = s;
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t o = __shfl_up(incl, dlt, 64);
+      if ((int)threadIdx.x >= dlt) incl += o;
+    }
+    uint32_t run = incl - s;
+    for (uint32_t k = 0; k < per; k++)
+      if (lo + k < NL) {
+        lbase[lo + k] = run;
+        run += lcur[lo + k];
+      }
+    if (threadIdx.x == 63) lbase[NL] = incl;
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) lcur[b] = 0;
+  __syncthreads();
+  const uint32_t in_part = start - part_start[p]; // position of the chunk inside its partition
+  for (uint32_t q = threadIdx.x; q < n; q += S2_THREADS) {
+    const uint32_t v = tmp[start + q];
+    const uint32_t b = (v >> S2_LOW_SHIFT) & (NL - 1);
+    const uint32_t tile = s2_upper(col, ntiles + 1, in_part + q);
+    const uint32_t i = tile * S2_TILE + (v & ((1u << S2_W_SHIFT) - 1));
+    const uint32_t w = (v >> S2_W_SHIFT) & 15u;
+    const uint32_t r = atomicAdd(&lcur[b], 1u);
+    buf[lbase[b] + r] = entry_idx(g, (int)w, i) | (v & 0x80000000u);
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) lcur[b] = offsets[(p << low_b) + b] + chunk_off[(size_t)blockIdx.x * NL + b] - lbase[b];
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < n; e += S2_THREADS) {
+    const uint32_t b = s2_upper(lbase, NL, e);
+    sorted[e + lcur[b]] = buf[e];
+  }
+}
+
 int ilog2_ceil(uint64_t x)
 {
   int l = 0;
@@ -617,6 +909,63 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     tmp = tmp_block;
   }
 
+  // LDS-staged path (table mode, ≥ 2^20 entries): partitions of ≈ 25 K entries, ≤ 1024 buckets each
+  static const bool lds_sort_cfg = !(getenv("ICICLE_SNARK_LDS_SORT") && atoi(getenv("ICICLE_SNARK_LDS_SORT")) == 0);
+  bool lds_sort = false;
+  int s2_pb = 0, s2_low = 0;
+  uint32_t s2_ntiles = 0, s2_maxchunks = 0;
+  size_t s2_lds_a = 0, s2_lds_b = 0;
+  if (lds_sort_cfg && g.tab && nentries >= (1u << 20) && g.W <= 16) {
+    while ((nentries >> s2_pb) > 28000) s2_pb++;
+    s2_low = (g.c - 1) - s2_pb;
+    if (s2_low > 10) {
+      s2_pb += s2_low - 10;
+      s2_low = 10;
+    }
+    s2_ntiles = (L + S2_TILE - 1) / S2_TILE;
+    s2_maxchunks = (uint32_t)(nentries / S2_CHUNK) + (1u << s2_pb);
+    s2_lds_a = ((size_t)2 * (1u << s2_pb) + 1 + (size_t)S2_TILE * g.W) * 4;
+    s2_lds_b = ((size_t)2 * (1u << (s2_low > 0 ? s2_low : 0)) + 1 + s2_ntiles + 1 + S2_CHUNK) * 4;
+    lds_sort = s2_low >= 0 && s2_pb <= 12 && (1u << s2_pb) * (uint64_t)(1u << s2_low) == nb && s2_lds_a <= S2_LDS_MAX && s2_lds_b <= S2_LDS_MAX;
+  }
+  if (lds_sort) {
+    const uint32_t P = 1u << s2_pb, NL = 1u << s2_low;
+    // workspace: cnt[ntiles][P] | off_T[P][ntiles + 1] | totals[P] | part_start[P + 1] | chunk_first[P + 1] | chunk_hist | chunk_off [maxchunks][NL]
+    WsScoped<uint32_t> s2ws;
+    const size_t n_cnt = (size_t)s2_ntiles * P, n_offT = (size_t)P * (s2_ntiles + 1), n_ch = (size_t)s2_maxchunks * NL;
+    HIP_TRY(s2ws.alloc(n_cnt + n_offT + 3 * (size_t)P + 2 + 2 * n_ch, s), ICICLE_ALLOCATION_FAILED);
+    uint32_t* cnt = s2ws.p;
+    uint32_t* off_T = cnt + n_cnt;
+    uint32_t* totals = off_T + n_offT;
+    uint32_t* pstart = totals + P;
+    uint32_t* cfirst = pstart + P + 1;
+    uint32_t* chist = cfirst + P + 1;
+    uint32_t* coff = chist + n_ch;
+    WsScoped<uint32_t> s2tmp_own;
+    uint32_t* s2tmp = tmp; // the scatter buffer of the two-level path when that one was set up as well
+    if (!s2tmp) {
+      HIP_TRY(s2tmp_own.alloc((size_t)nentries, s), ICICLE_ALLOCATION_FAILED);
+      s2tmp = s2tmp_own.p;
+    }
+    static std::atomic<int> attr_dev_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_dev_mask.load() & (1 << (dev & 31)))) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_chunk_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
+      attr_dev_mask.fetch_or(1 << (dev & 31));
+    }
+    hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + TK); // n_large | tickets
+    hipLaunchKernelGGL(sort2_tile_hist_kernel, dim3(s2_ntiles), dim3(256), (size_t)P * 4, s, d_scalars, L, g, mont_sc, s2_low, P, cnt);
+    hipLaunchKernelGGL(sort2_tile_scan_kernel, dim3((P + 255) / 256), dim3(256), 0, s, cnt, s2_ntiles, P, off_T, totals);
+    hipLaunchKernelGGL(sort2_part_scan_kernel, dim3(1), dim3(1024), 0, s, totals, P, pstart, cfirst);
+    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(s2_ntiles), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, cnt, pstart, s2tmp);
+    hipLaunchKernelGGL(sort2_chunk_hist_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), 0, s, s2tmp, pstart, cfirst, P, s2_low, chist);
+    hipLaunchKernelGGL(sort2_bucket_scan_kernel, dim3(P), dim3(NL), 0, s, chist, coff, pstart, cfirst, s2_low, thr, pl->counts, pl->offsets, pl->n_large, pl->large_list, pl->large_first,
+                       pl->large_items, pl->item_cap);
+    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, off_T, s2_ntiles, g, pl->sorted);
+    ICICLE_TRY(check_launch("msm_sort (LDS-staged)"));
+  } else {
   unsigned zb = (3 * nb + 255) / 256;
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, 3 * nb); // counts | offsets | cursor
@@ -640,6 +989,7 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
     hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, pl->counts, nb, bsum, pl->offsets, cursor, thr, pl->n_large, pl->large_list, pl->large_first, pl->large_items, pl->item_cap);
     if (L) hipLaunchKernelGGL(msm_scatter_kernel, dim3(lgrid), dim3(256), 0, s, d_scalars, L, g, mont_sc, cursor, pl->sorted);
+  }
   }
   // bucket ids by decreasing size
   hipLaunchKernelGGL(msm_order_hist_kernel, dim3(oblk), dim3(ORDER_BINS), 0, s, pl->counts, nb, oblk, blockhist);
