@@ -43,7 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SORT_KERNELS = ("msm_zero_kernel", "msm_coarse_hist_kernel", "msm_part_scan_kernel", "msm_partition_kernel", "msm_fine_count_kernel",
-                "msm_fine_place_kernel", "msm_recode_kernel", "msm_digit_hist_kernel", "msm_digit_scatter_kernel")
+                "msm_fine_place_kernel", "sort2_tile_hist_kernel", "sort2_col_sum_kernel", "sort2_col_base_kernel", "sort2_col_apply_kernel",
+                "sort2_tile_partition_kernel", "sort2_chunk_hist_kernel", "sort2_bucket_scan_kernel", "sort2_chunk_place_kernel")
 
 
 def log(*a):

@@ -482,11 +482,13 @@ __global__ __launch_bounds__(256) void msm_fine_place_kernel(const uint32_t* __r
 //     index — is found from its position in the partition (runs are in tile order) by a binary search in the partition's
 //     column of run offsets.  Per-bucket counts and offsets fall out of the chunk histograms.
 // HBM bytes: scalars 2 × 32·L, entries 4·L·W written and read twice, 4·L·W written — each once, in full lines.
-constexpr int S2_TILE = 2048;         // scalars per tile (pass A)
-constexpr int S2_CHUNK = 30720;       // entries per chunk (pass B): 120 KiB of LDS
+constexpr int S2_TILE = 2048;    // scalars per tile (pass A)
+constexpr int S2_WGRP = 7;       // windows per row: a row = (tile, window group) stages ≤ 2048·7 entries = 56 KiB in LDS
+constexpr int S2_CHUNK = 12288;  // entries per chunk (pass B): 48 KiB of LDS
 constexpr int S2_W_SHIFT = 11, S2_LOW_SHIFT = 15;
-constexpr int S2_THREADS = 1024;
-constexpr size_t S2_LDS_MAX = 159 * 1024; // dynamic LDS next to a few static words (160 KiB per workgroup)
+constexpr int S2_THREADS = 512;
+constexpr int S2_RG = 32;        // row groups of the column scan
+constexpr size_t S2_LDS_MAX = 76 * 1024; // two workgroups per CU; ≤ 66 KiB at the benchmark sizes (room next to one NTT workgroup)
 
 // largest i < n with a[i] <= x (a non-decreasing, a[0] <= x)
 __device__ __forceinline__ uint32_t s2_upper(const uint32_t* a, uint32_t n, uint32_t x)
@@ -499,11 +501,34 @@ __device__ __forceinline__ uint32_t s2_upper(const uint32_t* a, uint32_t n, uint
   }
   return lo;
 }
-
-__global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t* __restrict__ cnt)
+// exclusive scan of n ≤ 64·per LDS counters by wave 0 (in → out, out[n] = total); the other waves wait at the caller's barrier
+__device__ __forceinline__ void s2_wave_scan(const uint32_t* in, uint32_t* out, uint32_t n)
 {
-  extern __shared__ uint32_t sh[];
-  for (uint32_t p = threadIdx.x; p < P; p += 256) sh[p] = 0;
+  if (threadIdx.x >= 64) return;
+  const uint32_t per = (n + 63) / 64, lo = threadIdx.x * per;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < per; k++)
+    if (lo + k < n) s += in[lo + k];
+  uint32_t incl = s;
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const uint32_t o = __shfl_up(incl, dlt, 64);
+    if ((int)threadIdx.x >= dlt) incl += o;
+  }
+  uint32_t run = incl - s;
+  for (uint32_t k = 0; k < per; k++)
+    if (lo + k < n) {
+      const uint32_t v = in[lo + k];
+      out[lo + k] = run;
+      run += v;
+    }
+  if (threadIdx.x == 63) out[n] = incl;
+}
+
+// pass A, step 1: digits of a tile counted per (window group, partition): cnt[(tile·HS + h)·P + p]
+__global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t HS, uint32_t* __restrict__ cnt)
+{
+  extern __shared__ uint32_t sh[]; // [HS][P]
+  for (uint32_t p = threadIdx.x; p < HS * P; p += 256) sh[p] = 0;
   __syncthreads();
   const uint32_t first = blockIdx.x * S2_TILE;
   for (int u = 0; u < S2_TILE / 256; u++) {
@@ -513,64 +538,70 @@ __global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restri
       recode(scalars, i, g, mont, t, neg);
       for (int w = 0; w < g.W; w++) {
         const uint32_t d = digit(t, w, g);
-        if (d) atomicAdd(&sh[((d & 0x7fffffffu) - 1) >> low_b], 1u);
+        if (d) atomicAdd(&sh[(uint32_t)(w / S2_WGRP) * P + (((d & 0x7fffffffu) - 1) >> low_b)], 1u);
       }
     }
   }
   __syncthreads();
-  for (uint32_t p = threadIdx.x; p < P; p += 256) cnt[(size_t)blockIdx.x * P + p] = sh[p];
+  for (uint32_t p = threadIdx.x; p < HS * P; p += 256) cnt[(size_t)blockIdx.x * HS * P + p] = sh[p];
 }
-// exclusive scan over the tiles of every partition: cnt[t][p] ← entries of partition p in tiles < t; the same numbers
-// transposed (off_T[p][0..ntiles], last = total) for pass B; totals[p]
-__global__ __launch_bounds__(256) void sort2_tile_scan_kernel(uint32_t* __restrict__ cnt, uint32_t ntiles, uint32_t P, uint32_t* __restrict__ off_T, uint32_t* __restrict__ totals)
+// column scan of cnt[R][P] over the rows, three short kernels: sums per row group, scan of the group sums (+ partition starts
+// and chunk numbering), running offsets written back — every load and store coalesced over p
+__global__ __launch_bounds__(256) void sort2_col_sum_kernel(const uint32_t* __restrict__ cnt, uint32_t R, uint32_t P, uint32_t* __restrict__ partial)
 {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
-  uint32_t run = 0;
-  uint32_t* row = off_T + (size_t)p * (ntiles + 1);
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const uint32_t c = cnt[(size_t)t * P + p];
-    cnt[(size_t)t * P + p] = run;
-    row[t] = run;
+  const uint32_t rpg = (R + S2_RG - 1) / S2_RG, r0 = blockIdx.y * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
+  uint32_t s = 0;
+  for (uint32_t r = r0; r < r1; r++) s += cnt[(size_t)r * P + p];
+  partial[(size_t)blockIdx.y * P + p] = s;
+}
+__global__ __launch_bounds__(1024) void sort2_col_base_kernel(uint32_t* __restrict__ partial, uint32_t P, uint32_t* __restrict__ part_start, uint32_t* __restrict__ chunk_first)
+{
+  __shared__ uint32_t ps[4097], cf[4097]; // totals / chunk counts, scanned in place
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+    uint32_t run = 0;
+    for (uint32_t gidx = 0; gidx < (uint32_t)S2_RG; gidx++) {
+      const uint32_t t = partial[(size_t)gidx * P + p];
+      partial[(size_t)gidx * P + p] = run;
+      run += t;
+    }
+    ps[p] = run;
+    cf[p] = (run + S2_CHUNK - 1) / S2_CHUNK;
+  }
+  __syncthreads();
+  s2_wave_scan(ps, ps, P);
+  __syncthreads();
+  s2_wave_scan(cf, cf, P);
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p <= P; p += blockDim.x) {
+    part_start[p] = ps[p];
+    chunk_first[p] = cf[p];
+  }
+}
+__global__ __launch_bounds__(256) void sort2_col_apply_kernel(uint32_t* __restrict__ cnt, uint32_t R, uint32_t P, const uint32_t* __restrict__ partial)
+{
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const uint32_t rpg = (R + S2_RG - 1) / S2_RG, r0 = blockIdx.y * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
+  uint32_t run = partial[(size_t)blockIdx.y * P + p];
+  for (uint32_t r = r0; r < r1; r++) {
+    const uint32_t c = cnt[(size_t)r * P + p];
+    cnt[(size_t)r * P + p] = run;
     run += c;
   }
-  row[ntiles] = run;
-  totals[p] = run;
 }
-// partition starts and first chunk of every partition (one workgroup; P ≤ 4096)
-__global__ __launch_bounds__(1024) void sort2_part_scan_kernel(const uint32_t* __restrict__ totals, uint32_t P, uint32_t* __restrict__ part_start, uint32_t* __restrict__ chunk_first)
-{
-  __shared__ uint32_t a[4096], b[4096];
-  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) a[p] = totals[p];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0, crun = 0;
-    for (uint32_t p = 0; p < P; p++) {
-      const uint32_t t = a[p];
-      a[p] = run;
-      b[p] = crun;
-      run += t;
-      crun += (t + S2_CHUNK - 1) / S2_CHUNK;
-    }
-    part_start[P] = run;
-    chunk_first[P] = crun;
-  }
-  __syncthreads();
-  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
-    part_start[p] = a[p];
-    chunk_first[p] = b[p];
-  }
-}
-// pass A: the tile's entries sorted by partition in LDS, then copied out run by run
-__global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P,
+// pass A, step 2: the row's entries (one tile, one window group) sorted by partition in LDS, then copied out run by run
+__global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t HS,
                                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ part_start, uint32_t* __restrict__ tmp)
 {
   extern __shared__ uint32_t sh[];
-  uint32_t* base = sh;          // [P + 1] exclusive prefix of the tile's partition counts
-  uint32_t* cur = sh + P + 1;   // [P] rank counters, then the global position minus the local one
-  uint32_t* buf = cur + P;      // [S2_TILE · W]
-  __shared__ uint32_t s_total;
-  const uint32_t first = blockIdx.x * S2_TILE;
+  uint32_t* base = sh;          // [P + 1] exclusive prefix of the row's partition counts
+  uint32_t* cur = sh + P + 1;   // [P] counts / rank counters, then the global position minus the local one
+  uint32_t* buf = cur + P;      // [S2_TILE · S2_WGRP]
+  const uint32_t row = blockIdx.x, tile = row / HS, h = row % HS;
+  const int w0 = (int)h * S2_WGRP, w1 = w0 + S2_WGRP < g.W ? w0 + S2_WGRP : g.W;
+  const uint32_t first = tile * S2_TILE;
   const uint32_t low_mask = (1u << low_b) - 1;
   for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = 0;
   __syncthreads();
@@ -579,35 +610,14 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const 
     if (i < L) {
       uint32_t t[9], neg;
       recode(scalars, i, g, mont, t, neg);
-      for (int w = 0; w < g.W; w++) {
+      for (int w = w0; w < w1; w++) {
         const uint32_t d = digit(t, w, g);
         if (d) atomicAdd(&cur[((d & 0x7fffffffu) - 1) >> low_b], 1u);
       }
     }
   }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    // exclusive scan of P counters by one wave: lane l owns P/64 consecutive ones
-    const uint32_t per = (P + 63) / 64, lo = threadIdx.x * per;
-    uint32_t s = 0;
-    for (uint32_t k = 0; k < per; k++)
-      if (lo + k < P) s += cur[lo + k];
-    uint32_t incl = s;
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-      const uint32_t o = __shfl_up(incl, dlt, 64);
-      if ((int)threadIdx.x >= dlt) incl += o;
-    }
-    uint32_t run = incl - s;
-    for (uint32_t k = 0; k < per; k++)
-      if (lo + k < P) {
-        base[lo + k] = run;
-        run += cur[lo + k];
-      }
-    if (threadIdx.x == 63) {
-      base[P] = incl;
-      s_total = incl;
-    }
-  }
+  s2_wave_scan(cur, base, P);
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = 0;
   __syncthreads();
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const 
     if (i < L) {
       uint32_t t[9], neg;
       recode(scalars, i, g, mont, t, neg);
-      for (int w = 0; w < g.W; w++) {
+      for (int w = w0; w < w1; w++) {
         const uint32_t d = digit(t, w, g);
         if (d) {
           const uint32_t bk = (d & 0x7fffffffu) - 1, p = bk >> low_b;
@@ -628,9 +638,9 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const 
   }
   __syncthreads();
   // cur[p] ← where the run of partition p starts in tmp, minus its start in buf
-  for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = part_start[p] + off[(size_t)blockIdx.x * P + p] - base[p];
+  for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = part_start[p] + off[(size_t)row * P + p] - base[p];
   __syncthreads();
-  const uint32_t total = s_total;
+  const uint32_t total = base[P];
   for (uint32_t e = threadIdx.x; e < total; e += S2_THREADS) {
     const uint32_t p = s2_upper(base, P, e);
     tmp[e + cur[p]] = buf[e];
@@ -641,7 +651,7 @@ __device__ __forceinline__ bool s2_chunk_of(uint32_t c, const uint32_t* __restri
 {
   __shared__ uint32_t s_p;
   if (c >= chunk_first[P]) return false;
-  if (threadIdx.x == 0) s_p = s2_upper(chunk_first, P, c); // the partition whose first chunk is the last one ≤ c (empty partitions share a value: the largest wins, and only a non-empty one can be it)
+  if (threadIdx.x == 0) s_p = s2_upper(chunk_first, P, c); // partitions without chunks share a value with their successor: the largest index wins, a non-empty one
   __syncthreads();
   p = s_p;
   const uint32_t k = c - chunk_first[p];
@@ -700,51 +710,34 @@ __global__ __launch_bounds__(1024) void sort2_bucket_scan_kernel(const uint32_t*
     for (uint32_t q = 0; q < nch && firsti + q < item_cap; q++) large_items[firsti + q] = make_uint2(bucket, q);
   }
 }
-// pass B, step 3: the chunk counting-sorted by bucket in LDS (entries rewritten with the global scalar index), copied out
+// pass B, step 3: the chunk counting-sorted by bucket in LDS (entries rewritten with the global scalar index), copied out.
+// The tile of an entry follows from its position inside the partition: the partition's column of cnt (first entry of every
+// row's run) is searched; row = tile·HS + window group.
 __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_place_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, int low_b,
                                                                         const uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ offsets,
-                                                                        const uint32_t* __restrict__ off_T, uint32_t ntiles, MsmGeom g, uint32_t* __restrict__ sorted)
+                                                                        const uint32_t* __restrict__ cnt, uint32_t R, uint32_t HS, MsmGeom g, uint32_t* __restrict__ sorted)
 {
   extern __shared__ uint32_t sh[];
   const uint32_t NL = 1u << low_b;
   uint32_t* lbase = sh;             // [NL + 1]
-  uint32_t* lcur = sh + NL + 1;     // [NL] rank counters, then global position minus local one
-  uint32_t* col = lcur + NL;        // [ntiles + 1] first entry of every tile's run inside the partition
-  uint32_t* buf = col + ntiles + 1; // [S2_CHUNK]
+  uint32_t* lcur = sh + NL + 1;     // [NL] counts / rank counters, then global position minus local one
+  uint32_t* col = lcur + NL;        // [R + 1] first entry of every row's run inside the partition
+  uint32_t* buf = col + R + 1;      // [S2_CHUNK]
   uint32_t p, start, n;
   if (!s2_chunk_of(blockIdx.x, part_start, chunk_first, P, p, start, n)) return;
-  for (uint32_t t = threadIdx.x; t <= ntiles; t += S2_THREADS) col[t] = off_T[(size_t)p * (ntiles + 1) + t];
-  for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) {
-    lcur[b] = chunk_hist[(size_t)blockIdx.x * NL + b];
-  }
+  const uint32_t in_part = start - part_start[p]; // position of the chunk inside its partition
+  for (uint32_t r = threadIdx.x; r <= R; r += S2_THREADS) col[r] = r < R ? cnt[(size_t)r * P + p] : 0xffffffffu;
+  for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) lcur[b] = chunk_hist[(size_t)blockIdx.x * NL + b];
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const uint32_t per = (NL + 63) / 64, lo = threadIdx.x * per;
-    uint32_t s = 0;
-    for (uint32_t k = 0; k < per; k++)
-      if (lo + k < NL) s += lcur[lo + k];
-    uint32_t incl = s;
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-      const uint32_t o = __shfl_up(incl, dlt, 64);
-      if ((int)threadIdx.x >= dlt) incl += o;
-    }
-    uint32_t run = incl - s;
-    for (uint32_t k = 0; k < per; k++)
-      if (lo + k < NL) {
-        lbase[lo + k] = run;
-        run += lcur[lo + k];
-      }
-    if (threadIdx.x == 63) lbase[NL] = incl;
-  }
+  s2_wave_scan(lcur, lbase, NL);
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) lcur[b] = 0;
   __syncthreads();
-  const uint32_t in_part = start - part_start[p]; // position of the chunk inside its partition
   for (uint32_t q = threadIdx.x; q < n; q += S2_THREADS) {
     const uint32_t v = tmp[start + q];
     const uint32_t b = (v >> S2_LOW_SHIFT) & (NL - 1);
-    const uint32_t tile = s2_upper(col, ntiles + 1, in_part + q);
-    const uint32_t i = tile * S2_TILE + (v & ((1u << S2_W_SHIFT) - 1));
+    const uint32_t row = s2_upper(col, R, in_part + q);
+    const uint32_t i = (row / HS) * S2_TILE + (v & ((1u << S2_W_SHIFT) - 1));
     const uint32_t w = (v >> S2_W_SHIFT) & 15u;
     const uint32_t r = atomicAdd(&lcur[b], 1u);
     buf[lbase[b] + r] = entry_idx(g, (int)w, i) | (v & 0x80000000u);
@@ -915,6 +908,7 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   int s2_pb = 0, s2_low = 0;
   uint32_t s2_ntiles = 0, s2_maxchunks = 0;
   size_t s2_lds_a = 0, s2_lds_b = 0;
+  uint32_t s2_hs = 1, s2_rows = 0;
   if (lds_sort_cfg && g.tab && nentries >= (1u << 20) && g.W <= 16) {
     while ((nentries >> s2_pb) > 28000) s2_pb++;
     s2_low = (g.c - 1) - s2_pb;
@@ -923,21 +917,22 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
       s2_low = 10;
     }
     s2_ntiles = (L + S2_TILE - 1) / S2_TILE;
+    s2_hs = (uint32_t)((g.W + S2_WGRP - 1) / S2_WGRP);
+    s2_rows = s2_ntiles * s2_hs;
     s2_maxchunks = (uint32_t)(nentries / S2_CHUNK) + (1u << s2_pb);
-    s2_lds_a = ((size_t)2 * (1u << s2_pb) + 1 + (size_t)S2_TILE * g.W) * 4;
-    s2_lds_b = ((size_t)2 * (1u << (s2_low > 0 ? s2_low : 0)) + 1 + s2_ntiles + 1 + S2_CHUNK) * 4;
-    lds_sort = s2_low >= 0 && s2_pb <= 12 && (1u << s2_pb) * (uint64_t)(1u << s2_low) == nb && s2_lds_a <= S2_LDS_MAX && s2_lds_b <= S2_LDS_MAX;
+    s2_lds_a = ((size_t)2 * (1u << s2_pb) + 1 + (size_t)S2_TILE * S2_WGRP) * 4;
+    s2_lds_b = ((size_t)2 * (1u << (s2_low > 0 ? s2_low : 0)) + 1 + s2_rows + 1 + S2_CHUNK) * 4;
+    lds_sort = s2_low >= 0 && s2_pb <= 12 && (1u << s2_pb) * (uint64_t)(1u << s2_low) == nb && s2_lds_a <= S2_LDS_MAX && s2_lds_b <= S2_LDS_MAX && (size_t)s2_hs * (1u << s2_pb) * 4 <= 64 * 1024;
   }
   if (lds_sort) {
-    const uint32_t P = 1u << s2_pb, NL = 1u << s2_low;
-    // workspace: cnt[ntiles][P] | off_T[P][ntiles + 1] | totals[P] | part_start[P + 1] | chunk_first[P + 1] | chunk_hist | chunk_off [maxchunks][NL]
+    const uint32_t P = 1u << s2_pb, NL = 1u << s2_low, R = s2_rows, HS = s2_hs;
+    // workspace: cnt[R][P] | partial[S2_RG][P] | part_start[P + 1] | chunk_first[P + 1] | chunk_hist | chunk_off [maxchunks][NL]
     WsScoped<uint32_t> s2ws;
-    const size_t n_cnt = (size_t)s2_ntiles * P, n_offT = (size_t)P * (s2_ntiles + 1), n_ch = (size_t)s2_maxchunks * NL;
-    HIP_TRY(s2ws.alloc(n_cnt + n_offT + 3 * (size_t)P + 2 + 2 * n_ch, s), ICICLE_ALLOCATION_FAILED);
+    const size_t n_cnt = (size_t)R * P, n_part = (size_t)S2_RG * P, n_ch = (size_t)s2_maxchunks * NL;
+    HIP_TRY(s2ws.alloc(n_cnt + n_part + 2 * (size_t)P + 2 + 2 * n_ch, s), ICICLE_ALLOCATION_FAILED);
     uint32_t* cnt = s2ws.p;
-    uint32_t* off_T = cnt + n_cnt;
-    uint32_t* totals = off_T + n_offT;
-    uint32_t* pstart = totals + P;
+    uint32_t* partial = cnt + n_cnt;
+    uint32_t* pstart = partial + n_part;
     uint32_t* cfirst = pstart + P + 1;
     uint32_t* chist = cfirst + P + 1;
     uint32_t* coff = chist + n_ch;
@@ -955,15 +950,17 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_chunk_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
       attr_dev_mask.fetch_or(1 << (dev & 31));
     }
+    const dim3 cgrid((P + 255) / 256, S2_RG);
     hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + TK); // n_large | tickets
-    hipLaunchKernelGGL(sort2_tile_hist_kernel, dim3(s2_ntiles), dim3(256), (size_t)P * 4, s, d_scalars, L, g, mont_sc, s2_low, P, cnt);
-    hipLaunchKernelGGL(sort2_tile_scan_kernel, dim3((P + 255) / 256), dim3(256), 0, s, cnt, s2_ntiles, P, off_T, totals);
-    hipLaunchKernelGGL(sort2_part_scan_kernel, dim3(1), dim3(1024), 0, s, totals, P, pstart, cfirst);
-    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(s2_ntiles), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, cnt, pstart, s2tmp);
+    hipLaunchKernelGGL(sort2_tile_hist_kernel, dim3(s2_ntiles), dim3(256), (size_t)HS * P * 4, s, d_scalars, L, g, mont_sc, s2_low, P, HS, cnt);
+    hipLaunchKernelGGL(sort2_col_sum_kernel, cgrid, dim3(256), 0, s, cnt, R, P, partial);
+    hipLaunchKernelGGL(sort2_col_base_kernel, dim3(1), dim3(1024), 0, s, partial, P, pstart, cfirst);
+    hipLaunchKernelGGL(sort2_col_apply_kernel, cgrid, dim3(256), 0, s, cnt, R, P, partial);
+    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(R), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, HS, cnt, pstart, s2tmp);
     hipLaunchKernelGGL(sort2_chunk_hist_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), 0, s, s2tmp, pstart, cfirst, P, s2_low, chist);
     hipLaunchKernelGGL(sort2_bucket_scan_kernel, dim3(P), dim3(NL), 0, s, chist, coff, pstart, cfirst, s2_low, thr, pl->counts, pl->offsets, pl->n_large, pl->large_list, pl->large_first,
                        pl->large_items, pl->item_cap);
-    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, off_T, s2_ntiles, g, pl->sorted);
+    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, cnt, R, HS, g, pl->sorted);
     ICICLE_TRY(check_launch("msm_sort (LDS-staged)"));
   } else {
   unsigned zb = (3 * nb + 255) / 256;

@@ -722,6 +722,10 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // ---- stream gq: construct_r1cs (src/proof_helper.rs:31-170) on the device
   hipStream_t gq = z->s_qap;
   P_HIP(hipStreamWaitEvent(gq, z->ev_witness, 0));
+  // measurement knob: the QAP chain starts behind the witness sort, so that the sort's event time (roofline.scatter) is its
+  // solo time instead of its time next to the spmv and the first transform pass
+  static const bool sort_solo = getenv("ICICLE_SNARK_SORT_SOLO") && atoi(getenv("ICICLE_SNARK_SORT_SOLO")) != 0;
+  if (sort_solo) P_HIP(hipStreamWaitEvent(gq, z->ev_sort, 0));
   P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, gq));
   NTTConfig nc;
   memset(&nc, 0, sizeof nc);
