@@ -409,6 +409,17 @@ def msm_precompute_bases(group: str, bases: np.ndarray, precompute_factor: int, 
     return out
 
 
+def raw_to_host(ptr: int, nbytes: int) -> bytes:
+    """device memory at a raw pointer → bytes (exchange emulation in tests / the gloo fallback)"""
+    buf = (C.c_uint8 * nbytes)()
+    check(lib().icicle_copy_to_host(buf, C.c_void_p(ptr), C.c_size_t(nbytes)), "copy_to_host")
+    return bytes(buf)
+
+
+def raw_to_device(ptr: int, data: bytes):
+    check(lib().icicle_copy_to_device(C.c_void_p(ptr), data, C.c_size_t(len(data))), "copy_to_device")
+
+
 def last_msm_timings():
     out = (C.c_float * 4)()
     check(lib().icicle_snark_last_msm_timings(out), "last_msm_timings")
@@ -592,6 +603,23 @@ class CacheManager:
                                              C.c_size_t(len(pj)), qj, C.c_size_t(len(qj)), C.byref(tm)), "prove_resident")
         return pj.value.decode(), qj.value.decode(), tm
 
+    # ---- distributed QAP front end (2, 4 or 8 strided shards): see include/groth16_prover.h ----
+    def dist_supported(self, key: str) -> bool:
+        return bool(lib().groth16_dist_supported(self._h, key.encode()))
+
+    def dist_stage1(self, key: str, wtns: bytes):
+        """→ (send ptr, recv ptr, rows, row_bytes, chunk_bytes): device buffers of exchange 1"""
+        send, recv = C.c_void_p(), C.c_void_p()
+        rows, rb, cb = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _pcheck(lib().groth16_dist_stage1(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), C.byref(send), C.byref(recv), C.byref(rows), C.byref(rb), C.byref(cb)), "dist_stage1")
+        return send.value, recv.value, rows.value, rb.value, cb.value
+
+    def dist_stage2(self, key: str):
+        """→ (send ptr, recv ptr) of exchange 2 (same geometry as exchange 1)"""
+        send, recv = C.c_void_p(), C.c_void_p()
+        _pcheck(lib().groth16_dist_stage2(self._h, key.encode(), C.byref(send), C.byref(recv)), "dist_stage2")
+        return send.value, recv.value
+
     def prove_files(self, witness: str, zkey: str, proof: str, public: str, device: str = "HIP"):
         """groth16_prove — src/lib.rs:33-61: files in, files out (the reference's timed region)"""
         return self.prove(witness, zkey, proof, public, device)
@@ -610,6 +638,7 @@ PROVER_SYMBOLS = """
 groth16_cache_manager_new groth16_cache_manager_free groth16_prove groth16_cache_load groth16_cache_load_file
 groth16_cache_contains groth16_cache_evict groth16_commitments groth16_sum_commitments groth16_assemble_proof
 groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error groth16_last_timings
+groth16_dist_supported groth16_dist_stage1 groth16_dist_stage2
 groth16_verify groth16_verify_json groth16_verify_last_error
 """.split()
 

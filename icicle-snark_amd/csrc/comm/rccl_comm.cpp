@@ -86,6 +86,38 @@ API int icicle_snark_rccl_allgather(void* comm, const void* in, size_t bytes, vo
   return 0;
 }
 
+// all-to-all of DEVICE buffers for the distributed QAP front end (include/groth16_prover.h: groth16_dist_stage1/2): for every
+// row q < rows and every peer p the chunk at q·row_bytes + p·chunk_bytes of `d_send` goes to rank p, and what rank p sent for
+// this rank lands at the same offset of `d_recv` (both buffers are [row][peer][chunk]).  One grouped ncclSend / ncclRecv
+// batch — point-to-point over the xGMI links, which is what an all-to-all is on this fabric; 3·(n/G)·32·(G−1)/G bytes per
+// rank and exchange (22 MB at n = 2^21, G = 8).
+API int icicle_snark_rccl_alltoall_rows(void* comm, const void* d_send, void* d_recv, int rows, size_t row_bytes, size_t chunk_bytes)
+{
+  Comm* c = (Comm*)comm;
+  if (!c || !d_send || !d_recv || rows < 1) return fail("alltoall: bad arguments", -1);
+  if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice", -1);
+  int me = 0;
+  ncclResult_t r = ncclCommUserRank(c->comm, &me);
+  if (r != ncclSuccess) return fail("ncclCommUserRank", (int)r);
+  r = ncclGroupStart();
+  if (r != ncclSuccess) return fail("ncclGroupStart", (int)r);
+  for (int q = 0; q < rows && r == ncclSuccess; q++)
+    for (int p = 0; p < c->world && r == ncclSuccess; p++) {
+      const size_t off = (size_t)q * row_bytes + (size_t)p * chunk_bytes;
+      if (p == me) {
+        if (hipMemcpyAsync((uint8_t*)d_recv + off, (const uint8_t*)d_send + off, chunk_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) r = ncclSystemError;
+        continue;
+      }
+      r = ncclSend((const uint8_t*)d_send + off, chunk_bytes, ncclUint8, p, c->comm, c->stream);
+      if (r == ncclSuccess) r = ncclRecv((uint8_t*)d_recv + off, chunk_bytes, ncclUint8, p, c->comm, c->stream);
+    }
+  const ncclResult_t r2 = ncclGroupEnd();
+  if (r != ncclSuccess) return fail("ncclSend/ncclRecv", (int)r);
+  if (r2 != ncclSuccess) return fail("ncclGroupEnd", (int)r2);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("sync", -1);
+  return 0;
+}
+
 // max over ranks of one double (used for the benchmark's max-over-ranks timing)
 API int icicle_snark_rccl_allreduce_max(void* comm, double* value)
 {

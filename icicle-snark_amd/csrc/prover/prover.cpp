@@ -186,6 +186,10 @@ struct ZKeyCache {
   fe* d_witness = nullptr; // n_vars
   fe* d_vec = nullptr;     // 3n
   fe* d_fold = nullptr;    // 3·n/G: folded rows of a strided H shard (qap_coset_fold3)
+  // distributed front end (groth16_dist_stage1/2; strided H shards only): Y rows of stage 1, what exchange 1 delivers,
+  // what stage 2 sends, the scale table n⁻¹·ω_n^{−r·k2} — 3·m elements each, m = n / shard_count; exchange 2 delivers into d_fold
+  fe *d_dist_y = nullptr, *d_dist_recv1 = nullptr, *d_dist_send2 = nullptr, *d_tw1 = nullptr;
+  bool dist_ready = false; // d_fold holds the Z rows of this rank: the next commitments call skips its own inverse transform + fold
   fe* d_skeys = nullptr;   // n: n⁻¹·g^i — 1/n and the coset keys folded into the inverse transform's last pass (ntt_fuse.h); built on first use
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
@@ -204,7 +208,7 @@ struct ZKeyCache {
     if (s_g3) (void)hipStreamSynchronize(s_g3);
     if (s_g4) (void)hipStreamSynchronize(s_g4);
     if (s_g5) (void)hipStreamSynchronize(s_g5);
-    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_partials})
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_dist_y, (void*)d_dist_recv1, (void*)d_dist_send2, (void*)d_tw1, (void*)d_partials})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
     if (s_qap) (void)icicle_destroy_stream(s_qap);
@@ -726,7 +730,9 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // solo time instead of its time next to the spmv and the first transform pass
   static const bool sort_solo = getenv("ICICLE_SNARK_SORT_SOLO") && atoi(getenv("ICICLE_SNARK_SORT_SOLO")) != 0;
   if (sort_solo) P_HIP(hipStreamWaitEvent(gq, z->ev_sort, 0));
-  P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, gq));
+  const bool dist_ready = z->dist_ready && z->H.stride > 1; // the distributed stages already left this rank's Z rows in d_fold
+  z->dist_ready = false;
+  if (!dist_ready) P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, gq));
   NTTConfig nc;
   memset(&nc, 0, sizeof nc);
   nc.stream = gq;
@@ -741,9 +747,11 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   static const bool fuse_cfg = !(getenv("ICICLE_SNARK_NTT_FUSE") && atoi(getenv("ICICLE_SNARK_NTT_FUSE")) == 0);
   if (z->H.stride > 1) {
     // strided H shard: coset keys, the fold over the shard count and the twist in one pass, then a size-n/G transform
-    P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
     const uint32_t m = z->H.len();
-    P_HIP(qap_coset_fold3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, z->H.stride, z->H.first, z->d_fold, gq));
+    if (!dist_ready) {
+      P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
+      P_HIP(qap_coset_fold3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, z->H.stride, z->H.first, z->d_fold, gq));
+    }
     if (fuse_cfg && ntt_fusable(m)) {
       NttFuse f;
       f.fused_out = z->d_fold + m;
@@ -928,6 +936,90 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   return 0;
 }
 } // namespace
+
+
+extern "C" {
+
+// ---- distributed front end: stage 1 and stage 2 (include/groth16_prover.h) ----------------------------------------------
+__attribute__((visibility("default"))) int groth16_dist_supported(Groth16CacheManager* cm, const char* key)
+{
+  if (!cm) return 0;
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  if (!zp) return 0;
+  const ZKeyCache* z = zp.get();
+  const uint32_t G = (uint32_t)z->shard_count;
+  if (z->H.stride <= 1 || (G != 2 && G != 4 && G != 8)) return 0;
+  const uint32_t m = z->domain_size / G;
+  return m % G == 0 && ntt_fusable(m) ? 1 : 0;
+}
+
+__attribute__((visibility("default"))) int groth16_dist_stage1(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, void** d_send, void** d_recv, uint32_t* rows,
+                                                               uint64_t* row_bytes, uint64_t* chunk_bytes)
+{
+  if (!cm || !wtns || !d_send || !d_recv) return fail(ERR_ARG, "null argument");
+  if (!groth16_dist_supported(cm, key)) return fail(ERR_ARG, "cache entry '%s' is not a strided shard of 2, 4 or 8 (or too small) — use groth16_commitments", key ? key : "");
+  std::lock_guard<std::mutex> lk(cm->mu);
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  ZKeyCache* z = zp.get();
+  IcicleDevice dev;
+  memset(&dev, 0, sizeof dev);
+  strcpy(dev.type, "HIP");
+  dev.id = z->device_id;
+  P_ICICLE(icicle_set_device(&dev));
+  if (int rc = ensure_domain(cm, z)) return rc;
+  const uint32_t n = z->domain_size, G = (uint32_t)z->shard_count, r = (uint32_t)z->shard_rank, m = n / G;
+  Wtns w;
+  if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
+  if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
+  if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
+  const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
+  if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)z->n_vars * 32}}, lanes, 3)) return rc;
+  z->witness_resident = true;
+  hipStream_t gq = z->s_qap;
+  int dom_log = 0;
+  const fe* tw = ntt_domain_table(&dom_log);
+  if (!z->d_dist_y) {
+    P_HIP(hipMalloc((void**)&z->d_dist_y, (size_t)3 * m * 32));
+    P_HIP(hipMalloc((void**)&z->d_dist_recv1, (size_t)3 * m * 32));
+    P_HIP(hipMalloc((void**)&z->d_dist_send2, (size_t)3 * m * 32));
+    P_HIP(hipMalloc((void**)&z->d_tw1, (size_t)m * 32));
+    z->device_bytes += (size_t)10 * m * 32;
+    P_HIP(qap_dist_tw1(tw, 1u << dom_log, n, G, r, z->d_tw1, gq));
+  }
+  P_HIP(qap_spmv_strided(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, G, r, z->d_dist_y, gq));
+  NttFuse f;
+  f.scale_tab = z->d_tw1;
+  P_ICICLE(ntt_fused(z->d_dist_y, m, 3, true, gq, f));
+  P_HIP(hipStreamSynchronize(gq)); // the exchange runs on the communicator's stream
+  *d_send = z->d_dist_y;
+  *d_recv = z->d_dist_recv1;
+  if (rows) *rows = 3;
+  if (row_bytes) *row_bytes = (uint64_t)m * 32;
+  if (chunk_bytes) *chunk_bytes = (uint64_t)(m / G) * 32;
+  return 0;
+}
+
+__attribute__((visibility("default"))) int groth16_dist_stage2(Groth16CacheManager* cm, const char* key, void** d_send, void** d_recv)
+{
+  if (!cm || !d_send || !d_recv) return fail(ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(cm->mu);
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  ZKeyCache* z = zp.get();
+  if (!z || !z->d_dist_recv1) return fail(ERR_ARG, "groth16_dist_stage1 has not run for '%s'", key ? key : "");
+  (void)hipSetDevice(z->device_id);
+  const uint32_t n = z->domain_size, G = (uint32_t)z->shard_count, r = (uint32_t)z->shard_rank;
+  int dom_log = 0;
+  const fe* tw = ntt_domain_table(&dom_log);
+  if (!tw || (1u << dom_log) < 2 * n) return fail((int)ICICLE_INVALID_ARGUMENT, "the NTT domain was released between the stages");
+  P_HIP(qap_dist_mid(z->d_dist_recv1, z->d_dist_send2, tw, 1u << dom_log, n, G, r, z->s_qap));
+  P_HIP(hipStreamSynchronize(z->s_qap));
+  *d_send = z->d_dist_send2;
+  *d_recv = z->d_fold; // exchange 2 delivers this rank's Z rows [row][m] where stage 3 (groth16_commitments) expects them
+  z->dist_ready = true;
+  return 0;
+}
+
+} // extern "C"
 
 extern "C" {
 

@@ -26,6 +26,16 @@ hipError_t qap_coset_fold3(const bn254::fe* d_vec, const bn254::fe* tw, uint32_t
 // dst[k] = src[first + k·stride] for elements of `elem_fe` field elements (strided point-range shard of the H bases)
 hipError_t qap_gather_strided(const bn254::fe* src, bn254::fe* dst, uint32_t elem_fe, uint32_t count, uint32_t stride, uint32_t first, hipStream_t s);
 
+// Distributed front end for G ∈ {2, 4, 8} GPUs (icicle-snark_amd/dist_qap.py has the algebra and its CPU restatement):
+//   stage 1  qap_spmv_strided (rows c ≡ r mod G → [B | A | A∘B] over m = n/G elements) + size-m inverse transform whose
+//            per-element scale is the table of qap_dist_tw1 (n⁻¹·ω_n^{−r·k2}); exchange 1 = all-to-all of blocks of m/G;
+//   stage 2  qap_dist_mid: size-G inverse DFT over the sources, coset key g^k, size-G forward DFT, twist ω_n^{k2·i1};
+//            exchange 2 = all-to-all of blocks of m/G;  stage 3 = size-m forward transform with the A·B − C epilogue.
+// tw = ω_N^i table of the NTT domain, N ≥ 2n.  Buffers of stage 2 are [row][peer][m/G] (= [row][m]).
+hipError_t qap_spmv_strided(const bn254::fe* witness, const uint32_t* rowptr, const uint32_t* cols, const bn254::fe* vals, uint32_t n, uint32_t G, uint32_t r, bn254::fe* out, hipStream_t s);
+hipError_t qap_dist_tw1(const bn254::fe* tw, uint32_t N, uint32_t n, uint32_t G, uint32_t r, bn254::fe* tab, hipStream_t s);
+hipError_t qap_dist_mid(const bn254::fe* recv, bn254::fe* send, const bn254::fe* tw, uint32_t N, uint32_t n, uint32_t G, uint32_t b, hipStream_t s);
+
 // cold path (csr.hip): CSR of zkey section 4 built on the device from the raw 44-byte records
 // {m:u32 c:u32 s:u32 value[32 B]} (src/cache.rs:126-166); vals come out as Montgomery-form coefficients (:214).
 // rowptr has 2n+1 entries.  *first_bad = index of the first out-of-range record, 0xffffffff if none.  Synchronises `s`.

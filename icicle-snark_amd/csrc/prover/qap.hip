@@ -96,6 +96,83 @@ __global__ __launch_bounds__(256) void qap_gather_strided_kernel(const fe* __res
   st(dst + i, ld(src + ((uint64_t)first + k * stride) * elem_fe + c));
 }
 
+
+// ---- distributed front end (power-of-two shard count G, rank r): see qap.h / icicle-snark_amd/dist_qap.py -----------------
+// rows c ≡ r (mod G) of the spmv only: out = [B | A | A∘B] over j2 < m, c = r + G·j2
+__global__ __launch_bounds__(256) void qap_spmv_strided_kernel(const fe* __restrict__ w, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ cols,
+                                                                const fe* __restrict__ vals, uint32_t n, uint32_t G, uint32_t r, fe* __restrict__ out)
+{
+  const uint32_t m = n / G;
+  const uint32_t j2 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j2 >= m) return;
+  const uint32_t c = r + G * j2;
+  uint32_t ka = rowptr[c], kb = rowptr[n + c];
+  const uint32_t ha = rowptr[c + 1], hb = rowptr[n + c + 1];
+  fe a = Fr::zero(), b = Fr::zero();
+  while (ka < ha || kb < hb) {
+    const bool da = ka < ha, db = kb < hb;
+    const uint32_t ia = da ? ka : 0u, ib = db ? kb : 0u;
+    const uint32_t ca = cols[ia], cb = cols[ib];
+    const fe va = ld(vals + ia), vb = ld(vals + ib);
+    const fe wa = ld(w + ca), wb = ld(w + cb);
+    if (da) a = Fr::add(a, Fr::mul(va, wa));
+    if (db) b = Fr::add(b, Fr::mul(vb, wb));
+    ka++;
+    kb++;
+  }
+  st(out + j2, b);
+  st(out + (size_t)m + j2, a);
+  st(out + 2 * (size_t)m + j2, Fr::mul(Fr::mul(a, b), Fr::r2()));
+}
+// tab[k2] = n⁻¹ · ω_n^{−r·k2}, k2 < m (Montgomery): the per-element scale of stage 1's inverse transform (ntt_fuse.h)
+__global__ __launch_bounds__(256) void qap_dist_tw1_kernel(const fe* __restrict__ tw, uint32_t N, uint32_t n, uint32_t G, uint32_t r, fe ninv_mont, fe* __restrict__ tab)
+{
+  const uint32_t m = n / G;
+  const uint32_t k2 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k2 >= m) return;
+  const uint32_t e = (uint32_t)(((uint64_t)r * k2) % n);
+  const uint32_t idx = (uint32_t)((N - (uint64_t)e * (N / n)) % N);
+  st(tab + k2, Fr::mul(ld(tw + idx), ninv_mont));
+}
+// stage 2: per (row, k2 of this rank's block) the size-G inverse DFT over the sources, the coset key, the size-G forward DFT
+// and the twist ω_n^{k2·i1}.  recv / send are [row][peer][mb]; data in standard form, twiddles in Montgomery form.
+template <int G>
+__global__ __launch_bounds__(256) void qap_dist_mid_kernel(const fe* __restrict__ recv, fe* __restrict__ send, const fe* __restrict__ tw, uint32_t N, uint32_t n, uint32_t b)
+{
+  const uint32_t m = n / G, mb = m / G;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= mb) return;
+  const uint32_t row = blockIdx.y;
+  const uint32_t k2 = b * mb + t;
+  const uint32_t sn = N / n;      // ω_n = tw[sn]
+  const uint32_t sg = sn * m;     // ω_G = tw[sg]
+  fe y[G], a[G];
+#pragma unroll
+  for (int j1 = 0; j1 < G; j1++) y[j1] = ld(recv + ((size_t)row * G + j1) * mb + t);
+#pragma unroll
+  for (int k1 = 0; k1 < G; k1++) {
+    fe acc = y[0];
+#pragma unroll
+    for (int j1 = 1; j1 < G; j1++) {
+      const uint32_t e = (uint32_t)((G - (j1 * k1) % G) % G); // ω_G^{−j1·k1}
+      acc = Fr::add(acc, e ? Fr::mul(y[j1], ld(tw + (size_t)e * sg)) : y[j1]);
+    }
+    a[k1] = Fr::mul(acc, ld(tw + ((size_t)k1 * m + k2) * (sn / 2))); // · g^k, g = ω_2n = tw[sn / 2]
+  }
+#pragma unroll
+  for (int i1 = 0; i1 < G; i1++) {
+    fe acc = a[0];
+#pragma unroll
+    for (int k1 = 1; k1 < G; k1++) {
+      const uint32_t e = (uint32_t)((k1 * i1) % G);
+      acc = Fr::add(acc, e ? Fr::mul(a[k1], ld(tw + (size_t)e * sg)) : a[k1]);
+    }
+    const uint32_t e2 = (uint32_t)(((uint64_t)k2 * i1) % n);
+    if (e2) acc = Fr::mul(acc, ld(tw + (size_t)e2 * sn));
+    st(send + ((size_t)row * G + i1) * mb + t, acc);
+  }
+}
+
 } // namespace
 
 namespace isnark {
@@ -110,6 +187,35 @@ hipError_t qap_gather_strided(const fe* src, fe* dst, uint32_t elem_fe, uint32_t
 {
   const uint64_t total = (uint64_t)count * elem_fe;
   if (total) hipLaunchKernelGGL(qap_gather_strided_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, elem_fe, count, stride, first);
+  return hipGetLastError();
+}
+
+
+hipError_t qap_spmv_strided(const fe* witness, const uint32_t* rowptr, const uint32_t* cols, const fe* vals, uint32_t n, uint32_t G, uint32_t r, fe* out, hipStream_t s)
+{
+  const uint32_t m = n / G;
+  hipLaunchKernelGGL(qap_spmv_strided_kernel, dim3((m + 255) / 256), dim3(256), 0, s, witness, rowptr, cols, vals, n, G, r, out);
+  return hipGetLastError();
+}
+hipError_t qap_dist_tw1(const fe* tw, uint32_t N, uint32_t n, uint32_t G, uint32_t r, fe* tab, hipStream_t s)
+{
+  const uint32_t m = n / G;
+  fe nn = Fr::zero();
+  nn.l[0] = n;
+  const fe ninv = Fr::inv(Fr::to_mont(nn));
+  hipLaunchKernelGGL(qap_dist_tw1_kernel, dim3((m + 255) / 256), dim3(256), 0, s, tw, N, n, G, r, ninv, tab);
+  return hipGetLastError();
+}
+hipError_t qap_dist_mid(const fe* recv, fe* send, const fe* tw, uint32_t N, uint32_t n, uint32_t G, uint32_t b, hipStream_t s)
+{
+  const uint32_t mb = n / G / G;
+  const dim3 grid((mb + 255) / 256, 3);
+  switch (G) {
+  case 2: hipLaunchKernelGGL(qap_dist_mid_kernel<2>, grid, dim3(256), 0, s, recv, send, tw, N, n, b); break;
+  case 4: hipLaunchKernelGGL(qap_dist_mid_kernel<4>, grid, dim3(256), 0, s, recv, send, tw, N, n, b); break;
+  case 8: hipLaunchKernelGGL(qap_dist_mid_kernel<8>, grid, dim3(256), 0, s, recv, send, tw, N, n, b); break;
+  default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

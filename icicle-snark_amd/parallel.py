@@ -83,6 +83,21 @@ class GlooExchange:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def alltoall_rows(self, send_ptr: int, recv_ptr: int, rows: int, row_bytes: int, chunk_bytes: int):
+        """stand-in for the RCCL all-to-all on device buffers: staged through the host (gloo has no all_to_all: every rank
+        gathers every send buffer and keeps the chunks addressed to it)"""
+        import torch
+        mine = torch.frombuffer(bytearray(K.raw_to_host(send_ptr, rows * row_bytes)), dtype=torch.uint8)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(outs, mine)
+        recv = bytearray(rows * row_bytes)
+        for q in range(rows):
+            for p in range(self.world):
+                src = q * row_bytes + self.rank * chunk_bytes          # what rank p addressed to this rank
+                dst = q * row_bytes + p * chunk_bytes
+                recv[dst:dst + chunk_bytes] = bytes(outs[p][src:src + chunk_bytes].numpy())
+        K.raw_to_device(recv_ptr, bytes(recv))
+
     def barrier(self):
         self.dist.barrier()
 
@@ -127,6 +142,11 @@ class RcclExchange:
         self._check(self.lib.icicle_snark_rccl_allreduce_max(self.comm, C.byref(v)), "allreduce_max")
         return v.value
 
+    def alltoall_rows(self, send_ptr: int, recv_ptr: int, rows: int, row_bytes: int, chunk_bytes: int):
+        """device-to-device all-to-all over xGMI (grouped ncclSend / ncclRecv, csrc/comm/rccl_comm.cpp)"""
+        self._check(self.lib.icicle_snark_rccl_alltoall_rows(self.comm, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), rows, C.c_size_t(row_bytes),
+                                                             C.c_size_t(chunk_bytes)), "alltoall_rows")
+
     def barrier(self):
         self.dist.barrier()
 
@@ -136,9 +156,22 @@ class RcclExchange:
             self.comm = None
 
 
+def sharded_commitments(cm, key: str, wtns, exch, distributed_qap: bool = True):
+    """this rank's five partial commitments.  With 2, 4 or 8 ranks (H sharded by residue class) the QAP front end is
+    distributed too: every rank transforms 1/world of the rows and two all-to-alls move the blocks (dist_qap.py); otherwise
+    (or with distributed_qap=False, or when the witness is already resident: wtns=None) it is replicated, communication-free."""
+    if distributed_qap and wtns is not None and exch.world > 1 and cm.dist_supported(key):
+        send, recv, rows, rb, cb = cm.dist_stage1(key, wtns)
+        exch.alltoall_rows(send, recv, rows, rb, cb)
+        send, recv = cm.dist_stage2(key)
+        exch.alltoall_rows(send, recv, rows, rb, cb)
+        return cm.commitments(key, None)
+    return cm.commitments(key, wtns)
+
+
 def sharded_prove(cm, key: str, wtns, exch, r=None, s=None, wtns_for_public=None):
     """one prove across exch.world GPUs: partial commitments → all-gather → group sum → blinding + JSON."""
-    blk, tm = cm.commitments(key, wtns)
+    blk, tm = sharded_commitments(cm, key, wtns, exch)
     if exch.world > 1:
         blk = K.sum_commitments(exch.allgather(blk), exch.world)
     proof, public = cm.assemble(key, wtns_for_public if wtns is None else wtns, blk, r, s)

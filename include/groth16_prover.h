@@ -63,6 +63,19 @@ typedef struct {
 int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len,
                         uint8_t out_points[GROTH16_COMMITMENTS_BYTES], Groth16Timings* timings /* may be NULL */);
 
+/* Distributed QAP front end for 2, 4 or 8 shards (H sharded by residue class; DESIGN.md §5, icicle-snark_amd/dist_qap.py):
+ * instead of replicating the spmv and the inverse transform on every rank, each rank transforms 1/count of the rows and
+ * two all-to-alls move the blocks.  Sequence per prove, on every rank:
+ *     groth16_dist_stage1(wtns)  →  all-to-all(send, recv)  →  groth16_dist_stage2()  →  all-to-all(send, recv)
+ *     →  groth16_commitments(wtns = NULL)         (finishes with the size-n/count forward transform and the five MSMs)
+ * The buffers are device memory owned by the cache entry: 3 rows of row_bytes; the chunk a rank exchanges with `peer` for
+ * row `q` sits at q·row_bytes + peer·chunk_bytes in BOTH the send and the receive buffer.  groth16_dist_supported tells
+ * whether the entry can take this path (otherwise groth16_commitments alone does everything, replicated). */
+int groth16_dist_supported(Groth16CacheManager* cm, const char* key);
+int groth16_dist_stage1(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, void** d_send,
+                        void** d_recv, uint32_t* rows, uint64_t* row_bytes, uint64_t* chunk_bytes);
+int groth16_dist_stage2(Groth16CacheManager* cm, const char* key, void** d_send, void** d_recv);
+
 /* Element-wise group sum of `count` commitment blocks (gathered from the shards): out = Σ_k blocks[k]. */
 int groth16_sum_commitments(const uint8_t* blocks, int count, uint8_t out_points[GROTH16_COMMITMENTS_BYTES]);
 
