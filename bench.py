@@ -121,13 +121,15 @@ def cpu_baseline(zkey, wtns, N, what):
     host cores (bounded: one prove, ~10-40 s).  Reported next to the GPU number, never mixed into it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    threads = O.calibrate_threads()   # the host exposes more logical CPUs than the container may run
+    threads = O.calibrate_threads()   # the cgroup CPU quota when there is one (the MI355X boxes: 16 of 256 logical CPUs), else a sweep
+    quota = O.cpu_quota()
     cache = O.build_cache(O.parse_zkey(zkey))
     tm = {}
     O.groth16_prove(zkey, wtns, 1, 1, cache=cache, timings=tm)
     return dict(value=N / tm["total_s"], unit="constraints/s", cores=threads, kind="port",
-                sample=f"one full Groth16 prove of {what} by oracle/bn254_oracle.c (clang -O3 + OpenMP, {threads} threads = fastest of a "
-                       f"calibration sweep on {os.cpu_count()} logical CPUs): {tm['total_s']:.2f} s, of which MSMs {tm['msm_s']:.2f} s, "
+                sample=f"one full Groth16 prove of {what} by oracle/bn254_oracle.c (clang -O3 + OpenMP, {threads} threads = "
+                       f"{'the cgroup CPU quota of this container' if quota else 'fastest of a calibration sweep'}; {os.cpu_count()} logical CPUs visible): "
+                       f"{tm['total_s']:.2f} s, of which MSMs {tm['msm_s']:.2f} s, "
                        f"construct_r1cs {tm['qap_s']:.2f} s; {N / tm['total_s'] / threads:.0f} constraints/s per thread")
 
 
