@@ -327,6 +327,83 @@ def calibrate_threads(candidates=(8, 16, 32, 64, 128, 256)) -> int:
     return best or min(ncpu, 8)
 
 
+# --------------------------------------------------------------------------- snarkjs containers
+def read_sections(data: bytes, expected_type: bytes, max_version: int = 2):
+    """FileWrapper::read_bin_file — src/file_wrapper.rs:45-103. Returns {id: (offset, size)}."""
+    if data[:4] != expected_type:
+        raise ValueError("Invalid File format")
+    version, nsec = struct.unpack_from("<II", data, 4)
+    if version > max_version:
+        raise ValueError("Version not supported")
+    pos = 12
+    sections = {}
+    for _ in range(nsec):
+        ht, hl = struct.unpack_from("<IQ", data, pos)
+        pos += 12
+        sections.setdefault(ht, []).append((pos, hl))
+        pos += hl
+    return sections
+
+
+def _section(data, sections, sid):
+    (off, size), = sections[sid]
+    return memoryview(data)[off:off + size]
+
+
+def parse_wtns(data: bytes):
+    """read_wtns_header — src/file_wrapper.rs:169-177 ; section 2 = n_witness × 32 B standard form."""
+    sec = read_sections(data, b"wtns")
+    h = _section(data, sec, 1)
+    n8 = struct.unpack_from("<I", h, 0)[0]
+    q = from_le(h[4:4 + n8])
+    n_witness = struct.unpack_from("<I", h, 4 + n8)[0]
+    w = np.frombuffer(_section(data, sec, 2), dtype=np.uint64).reshape(-1, 4)
+    return {"n8": n8, "q": q, "n_witness": n_witness, "witness": w}
+
+
+def parse_zkey(data: bytes):
+    """read_zkey_header + the section views of CacheManager::compute —
+    src/zkey.rs:47-85, src/cache.rs:126-181.  Everything is returned exactly as stored
+    (Montgomery form); conversions happen in build_cache()."""
+    sec = read_sections(data, b"zkey")
+    if struct.unpack_from("<I", _section(data, sec, 1), 0)[0] != 1:
+        raise ValueError("Protocol not supported")
+    h = _section(data, sec, 2)
+    pos = 0
+    n8q = struct.unpack_from("<I", h, pos)[0]; pos += 4
+    q = from_le(h[pos:pos + n8q]); pos += n8q
+    n8r = struct.unpack_from("<I", h, pos)[0]; pos += 4
+    r = from_le(h[pos:pos + n8r]); pos += n8r
+    n_vars, n_public, domain_size = struct.unpack_from("<III", h, pos); pos += 12
+
+    def g1():
+        nonlocal pos
+        a = np.frombuffer(h[pos:pos + 64], dtype=np.uint64).reshape(2, 4).copy(); pos += 64
+        return a
+
+    def g2():
+        nonlocal pos
+        a = np.frombuffer(h[pos:pos + 128], dtype=np.uint64).reshape(4, 4).copy(); pos += 128
+        return a
+
+    z = dict(n8q=n8q, q=q, n8r=n8r, r=r, n_vars=n_vars, n_public=n_public, domain_size=domain_size)
+    z["vk_alpha_1"] = g1(); z["vk_beta_1"] = g1(); z["vk_beta_2"] = g2()
+    z["vk_gamma_2"] = g2(); z["vk_delta_1"] = g1(); z["vk_delta_2"] = g2()
+    coeffs = _section(data, sec, 4)
+    n_coef = (len(coeffs) - 4) // (12 + n8r)
+    rec = np.frombuffer(coeffs[4:4 + n_coef * 44], dtype=np.uint8).reshape(n_coef, 44)
+    z["m"] = rec[:, 0].astype(np.uint32)  # only byte 0 is read — src/cache.rs:159
+    z["c"] = rec[:, 4:8].copy().view(np.uint32).reshape(-1)
+    z["s"] = rec[:, 8:12].copy().view(np.uint32).reshape(-1)
+    z["coef"] = rec[:, 12:44].copy().view(np.uint64).reshape(-1, 4)
+    z["A"] = np.frombuffer(_section(data, sec, 5), dtype=np.uint64).reshape(-1, 2, 4)
+    z["B1"] = np.frombuffer(_section(data, sec, 6), dtype=np.uint64).reshape(-1, 2, 4)
+    z["B2"] = np.frombuffer(_section(data, sec, 7), dtype=np.uint64).reshape(-1, 4, 4)
+    z["C"] = np.frombuffer(_section(data, sec, 8), dtype=np.uint64).reshape(-1, 2, 4)
+    z["H"] = np.frombuffer(_section(data, sec, 9), dtype=np.uint64).reshape(-1, 2, 4)
+    return z
+
+
 def build_cache(z: dict) -> dict:
     """CacheManager::compute — src/cache.rs:117-241: from_mont on every point array and on the
     coefficient values (once: file holds value·R², the cache value·R), coset keys inc^i."""
