@@ -54,6 +54,52 @@ def test_msm_linearity_and_additivity_full_size(gpu, O, grp):
     assert np.array_equal(K.ec(grp, "to_affine", m(s1, 0, k)), want)
 
 
+@pytest.mark.parametrize("grp,logn", [("g1", 20), ("g2", 18)])
+def test_classic_msm_equals_oracle_at_size(gpu, O, grp, logn):
+    """bn254_msm / bn254_g2_msm (classic layout: the path the reference's host reaches) against the CPU oracle's Pippenger at
+    2^20 (G1) / 2^18 (G2) random scalars — distinct random bases, two identities, the extremal scalars 0, 1, r − 1 —
+    on device-resident inputs, standard and Montgomery form"""
+    K = gpu
+    O.calibrate_threads()
+    n = 1 << logn
+    rng = np.random.default_rng(1000 + logn)
+    sc = rand_fr(rng, n)
+    sc[0] = 0
+    sc[1] = 0; sc[1, 0] = 1
+    sc[2] = np.frombuffer((O.R_MOD - 1).to_bytes(32, "little"), dtype=np.uint64)
+    pts = K.generator_mul(grp, rand_fr(rng, n))
+    pts[7] = 0
+    pts[n - 3] = 0
+    want = O.ec_to_affine(grp, O.msm(grp, sc, pts))
+    d_s, d_p = K.DeviceVec.from_host(sc), K.DeviceVec.from_host(pts)
+    assert np.array_equal(K.ec(grp, "to_affine", K.msm(grp, d_s, d_p, size=n)), want)
+    assert np.array_equal(K.ec(grp, "to_affine", K.msm(grp, d_s, d_p, size=n, c=13)), want)
+    K.scalar_convert_montgomery(d_s, True)
+    K.affine_convert_montgomery(grp, d_p, True)
+    assert np.array_equal(K.ec(grp, "to_affine", K.msm(grp, d_s, d_p, size=n, scalars_mont=True, points_mont=True)), want)
+    d_s.free(); d_p.free()
+
+
+def test_batched_ntt_3x2p21_equals_oracle(gpu, O):
+    """the prover's transform configuration at benchmark/1600k size — 3 rows of 2^21, in place on the device, domain 2^22 —
+    against the oracle's radix-2 transform, both directions"""
+    K = gpu
+    O.calibrate_threads()
+    n = 1 << 21
+    K.release_domain()
+    K.initialize_domain(K.get_root_of_unity(2 * n))
+    rng = np.random.default_rng(21)
+    x = rand_fr(rng, 3 * n)
+    d = K.DeviceVec.from_host(x)
+    K.ntt(d, True, batch_size=3)
+    assert np.array_equal(d.to_host(x.shape), O.fr_ntt(x, True, batch=3, domain_log=22))
+    d.copy_from_host(x)
+    K.ntt(d, False, batch_size=3)
+    assert np.array_equal(d.to_host(x.shape), O.fr_ntt(x, False, batch=3, domain_log=22))
+    d.free()
+    K.release_domain()
+
+
 def test_ntt_round_trip_and_linearity_full_size(gpu):
     K = gpu
     n = 1 << 21
@@ -237,6 +283,10 @@ def test_benchmark_3200k_sharded_commitments(gpu, O):
     got, _ = cm.assemble("full", wtns, K.sum_commitments(blocks, 4), 5, 9)
     assert got == want
     assert json.loads(public) == [str(pow(3, 1 << N, S.R_MOD))]
+    # … and the proof itself equals the CPU oracle's (≈ 15 s of host time at this size)
+    O.calibrate_threads()
+    proof, pub = O.groth16_prove(zkey, wtns, 5, 9)
+    assert json.loads(want) == proof and json.loads(public) == pub
     vk = _vk_of(O, zkey)
     assert K.groth16_verify_json(want, public, S.vk_to_json(vk))
     import ref as R
