@@ -17,6 +17,7 @@
 //    so cache construction needs no conversion pass over ~1 GB of points;
 //  * the NTT domain is sized 2·domain_size so that the coset keys g^i (g = ω_2n, src/cache.rs:183-184,
 //    264-289) are read from the twiddle table instead of a separate array + CWD file cache.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <fcntl.h>
@@ -684,8 +685,9 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
     const auto tu = std::chrono::steady_clock::now();
     // three lanes: 51 MB in 1.4 ms, stable; with six, one upload in four stalled for ~15 ms on the GPU box (host threads
     // of this call, the MSM tails and the runtime's own compete for the container's CPU quota)
-    const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
-    if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, 3)) return rc;
+    const hipStream_t lanes[6] = {z->s_qap, z->s_g2, z->s_g3, z->s_g1, z->s_g4, z->s_g5};
+    static const int n_lanes = getenv("ICICLE_SNARK_UPLOAD_LANES") ? std::max(1, std::min(6, atoi(getenv("ICICLE_SNARK_UPLOAD_LANES")))) : 3;
+    if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, n_lanes)) return rc;
     h2d_host_ms = ms_since(tu);
   }
   P_HIP(hipEventRecord(z->ev[0], g1));
