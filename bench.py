@@ -199,6 +199,7 @@ def pmc_traffic(workload, timeout=600):
         # H is the launch with the most fetched bytes among the last four
         k = max(range(len(f) - 4, len(f)), key=lambda i: f[i])
         out["acc_h"] = f[k] * 1024 * 2 + w[k] * 1024
+        out["acc_h_raw"] = f[k] * 1024 + w[k] * 1024
         out["detail"]["acc_h"] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w[k]}
     # digit sort: per prove two sorts (witness, then H), each launching every sort kernel the same number of times
     tot_f = tot_w = 0.0
@@ -482,6 +483,10 @@ def main():
         n_add = g["L"] * g["W"]
         roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": pmc.get("acc_h") if pmc else None, "traffic_source": pmc_note,
+                # FETCH_SIZE without the guide's x2 (which is calibrated for wide coalesced streams): the calibration probe with this
+                # kernel's own pattern — random 64-byte gathers — counts 1.49x its bytes in the RAW counter (profiles/r02_pmc_calibration.txt),
+                # so the raw figure is the better estimate of the gather traffic and `traffic` an upper bound
+                "traffic_raw": pmc.get("acc_h_raw") if pmc else None,
                 "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
                 "algorithmic_bytes": alg_bytes, "geometry": g,
                 # the kernel is integer-VALU bound, not HBM bound (PMC: profiles/).  Its ceiling is the issue rate of the 4-cycle

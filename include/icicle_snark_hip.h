@@ -262,6 +262,10 @@ eIcicleError icicle_snark_last_msm_timings(float out_ms[4]);
  * reduction + tail, total, the digit sort alone (0 if this MSM re-used another one's sort)};
  * geom = {L, nbuckets, c, W, is_g2}. */
 eIcicleError icicle_snark_msm_profile(int back, float out_ms[5], uint32_t geom[5]);
+/* PMC calibration: five kernels (probe_gather_kernel ×2, probe_stream_kernel, probe_store_kernel ×2) that move KNOWN byte counts
+ * with the access patterns of this library — 64-byte and 128-byte random gathers, coalesced streaming reads, scattered and
+ * coalesced 4-byte stores; out = those byte counts.  Run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (scratch/pmc_calibrate.sh). */
+eIcicleError icicle_snark_pmc_probes(double out_bytes[5]);
 /* measured machine constants for bench.py: out[0] = device-to-device copy GB/s (read + write bytes),
  * out[1] = v_mad_u64_u32 lane-operations per second / 10^12 */
 eIcicleError icicle_snark_microbench(double out[2]);
