@@ -127,6 +127,21 @@ class RcclExchange:
         got = self.allgather(bytes([self.rank & 0xff]) * 8)
         if got != b"".join(bytes([r & 0xff]) * 8 for r in range(self.world)):
             raise RuntimeError("rccl all-gather self-test returned wrong data")
+        # … and one all-to-all on device buffers (grouped ncclSend / ncclRecv: the transport of the distributed QAP front
+        # end), two rows of 256-byte chunks: rank r sends (r, peer, row) patterns and must receive (peer, r, row)
+        chunk, rows = 256, 2
+        row_bytes = chunk * self.world
+        send = b"".join(bytes([self.rank, p, q, 0xA5]) * (chunk // 4) for q in range(rows) for p in range(self.world))
+        d_send, d_recv = K.DeviceVec(rows * row_bytes), K.DeviceVec(rows * row_bytes)
+        try:
+            K.raw_to_device(d_send.ptr, send)
+            self.alltoall_rows(d_send.ptr, d_recv.ptr, rows, row_bytes, chunk)
+            got = K.raw_to_host(d_recv.ptr, rows * row_bytes)
+        finally:
+            d_send.free(); d_recv.free()
+        want = b"".join(bytes([p, self.rank, q, 0xA5]) * (chunk // 4) for q in range(rows) for p in range(self.world))
+        if got != want:
+            raise RuntimeError("rccl all-to-all self-test returned wrong data")
 
     def _check(self, rc, what):
         if rc != 0:
