@@ -368,18 +368,17 @@ def main():
 
     def collect_profiles():
         # HIP-event timings of the last prove's MSMs (their streams were synchronised inside the call)
-        best, wsort = None, None
-        for back in range(5):
-            ms, geom = K.msm_profile(back)
-            if not geom["is_g2"] and (best is None or geom["L"] > best[1]["L"]):
-                best = (ms, geom)
-            if geom["is_g2"]:
-                wsort = (ms, geom)       # the witness sort is issued (and timed) with the G2 MSM
+        # the prover takes its five profile slots in the order A, B1, B2, C, H: back = 4 … 0
+        best = K.msm_profile(0)                                   # H: the largest G1 accumulation
         acc_ms.append(best[0][1])
         acc_geom[0] = best[1]
-        if wsort is not None and wsort[0][4] > 0:
-            sort_ms.append(wsort[0][4])
-            sort_geom[0] = wsort[1]
+        # the witness sort is issued (and timed) with the G2 MSM — with A when the key's B side is sparse (B2 then has its own sort)
+        for back in (2, 4):
+            ms, geom = K.msm_profile(back)
+            if ms[4] > 0:
+                sort_ms.append(ms[4])
+                sort_geom[0] = geom
+                break
 
     def step(timed=False):
         if world == 1:
@@ -530,6 +529,7 @@ def main():
                        "prove_ms_dropin_sequence": dropin_ms, "dropin_sequence_detail": dropin_detail,
                        # cold path, reported separately: zkey bytes in host memory → device-resident cache
                        "cold_cache_build_ms": cold_ms, "cache_device_mb": info.device_bytes / 1e6,
+                       "b_msm_bases": info.b_bases, "n_vars": info.n_vars,
                        "prove_ms_bit_heavy_witness_standin": skew_ms,
                        "phase_ms": {"qap_ntt": phases["qap"] / args.steps, "msm": phases["msm"] / args.steps}},
             "roofline": roof,

@@ -101,7 +101,7 @@ bn254_msm_precompute_bases bn254_g2_msm_precompute_bases
 bn254_pairing_target_field_add bn254_pairing_target_field_sub bn254_pairing_target_field_mul bn254_pairing_target_field_inv
 bn254_pairing_target_field_pow bn254_pairing_target_field_from_u32 bn254_pairing_target_field_generate_scalars
 icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
-icicle_snark_msm_profile icicle_snark_microbench
+icicle_snark_msm_profile icicle_snark_microbench icicle_snark_pmc_probes
 """.split()
 
 _lib = None
@@ -524,7 +524,7 @@ class Timings(C.Structure):
 
 class CircuitInfo(C.Structure):
     _fields_ = [("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32), ("n_coef", C.c_uint32),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("b_bases", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ProverError(RuntimeError):

@@ -162,50 +162,6 @@ __device__ __forceinline__ typename C::X block_reduce(typename C::X v, typename 
   return v;
 }
 
-// large buckets, step 1: one workgroup per (bucket, chunk) work item sums ≤ MSM_LARGE_CHUNK entries
-template <class C>
-__global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                                    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint2* __restrict__ items, uint32_t item_cap,
-                                                                    uint32_t skip_below, uint32_t stride, int ib, int pts_mont, typename C::X* __restrict__ item_partials)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
-  const uint32_t ni = min(n_large[2], item_cap);
-  for (uint32_t it = blockIdx.x; it < ni; it += gridDim.x) {
-    const uint2 w = items[it];
-    const uint32_t b = w.x;
-    const uint32_t lo = offsets[b] + w.y * MSM_LARGE_CHUNK, hi = min(offsets[b] + counts[b], lo + MSM_LARGE_CHUNK);
-    typedef typename Lazy<C>::type CL;
-    typename CL::X lacc = CL::x_zero();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-      bool z;
-      const typename CL::A p = load_base_lazy<C>(bases, sorted[k], skip_below, stride, ib, pts_mont, z);
-      if (!z) CL::x_madd(lacc, p);
-    }
-    typename C::X acc = block_reduce<C>(CL::x_store(lacc), sh, blockDim.x);
-    if (threadIdx.x == 0) item_partials[it] = acc;
-    __syncthreads();
-  }
-}
-// large buckets, step 2: one workgroup per large bucket sums its chunk partials into the bucket
-template <class C>
-__global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint32_t* __restrict__ large_list,
-                                                                 const uint32_t* __restrict__ large_first, const typename C::X* __restrict__ item_partials, typename C::X* __restrict__ buckets)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typename C::X* sh = reinterpret_cast<typename C::X*>(smem);
-  const uint32_t nl = n_large[0];
-  for (uint32_t li = blockIdx.x; li < nl; li += gridDim.x) {
-    const uint32_t b = large_list[li];
-    const uint32_t nch = (counts[b] + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK, first = large_first[li];
-    typename C::X acc = C::x_zero();
-    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) acc = C::x_add(acc, item_partials[first + k]);
-    acc = block_reduce<C>(acc, sh, blockDim.x);
-    if (threadIdx.x == 0) buckets[b] = Lazy<C>::type::x_store_internal(Lazy<C>::type::x_from_old(acc)); // bucket array encoding
-    __syncthreads();
-  }
-}
-
 // tree sum over the workgroup on the lazy field; LDS holds unpacked lazy XYZZ (144 B G1 / 288 B G2 per thread)
 template <class C>
 __device__ __forceinline__ typename Lazy<C>::type::X block_reduce_lazy(typename Lazy<C>::type::X v, typename Lazy<C>::type::X* sh, int nthreads)
@@ -222,6 +178,61 @@ __device__ __forceinline__ typename Lazy<C>::type::X block_reduce_lazy(typename 
     __syncthreads();
   }
   return v;
+}
+
+// large buckets, step 1: one workgroup per (bucket, chunk) work item sums ≤ MSM_LARGE_CHUNK entries: strided mixed additions per
+// thread, then a tree over the lazy field no wider than the item (a 200-entry bucket folds 256 → 1 in 8 levels of which the
+// first is free).  LDS: blockDim lazy XYZZ.
+template <class C>
+__global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                                    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint2* __restrict__ items, uint32_t item_cap,
+                                                                    uint32_t skip_below, uint32_t stride, int ib, int pts_mont, typename C::X* __restrict__ item_partials)
+{
+  typedef typename Lazy<C>::type CL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typename CL::X* sh = reinterpret_cast<typename CL::X*>(smem);
+  const uint32_t ni = min(n_large[2], item_cap);
+  for (uint32_t it = blockIdx.x; it < ni; it += gridDim.x) {
+    const uint2 w = items[it];
+    const uint32_t b = w.x;
+    const uint32_t lo = offsets[b] + w.y * MSM_LARGE_CHUNK, hi = min(offsets[b] + counts[b], lo + MSM_LARGE_CHUNK);
+    typename CL::X lacc = CL::x_zero();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+      bool z;
+      const typename CL::A p = load_base_lazy<C>(bases, sorted[k], skip_below, stride, ib, pts_mont, z);
+      if (!z) CL::x_madd(lacc, p);
+    }
+    int width = 1;
+    while (width < (int)blockDim.x && (uint32_t)width < hi - lo) width <<= 1;
+    lacc = block_reduce_lazy<C>(lacc, sh, width);
+    if (threadIdx.x == 0) item_partials[it] = CL::x_store_internal(lacc); // the bucket array's encoding
+    __syncthreads();
+  }
+}
+// large buckets, step 2: one workgroup per large bucket sums its chunk partials into the bucket
+template <class C>
+__global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint32_t* __restrict__ large_list,
+                                                                 const uint32_t* __restrict__ large_first, const typename C::X* __restrict__ item_partials, typename C::X* __restrict__ buckets)
+{
+  typedef typename Lazy<C>::type CL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typename CL::X* sh = reinterpret_cast<typename CL::X*>(smem);
+  const uint32_t nl = n_large[0];
+  for (uint32_t li = blockIdx.x; li < nl; li += gridDim.x) {
+    const uint32_t b = large_list[li];
+    const uint32_t nch = (counts[b] + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK, first = large_first[li];
+    if (nch == 1) { // one chunk (most buckets just above the threshold): nothing to sum
+      if (threadIdx.x == 0) buckets[b] = item_partials[first];
+      continue;
+    }
+    typename CL::X acc = CL::x_zero();
+    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) acc = CL::x_add(acc, CL::x_load_internal(item_partials[first + k]));
+    int width = 1;
+    while (width < (int)blockDim.x && (uint32_t)width < nch) width <<= 1;
+    acc = block_reduce_lazy<C>(acc, sh, width);
+    if (threadIdx.x == 0) buckets[b] = CL::x_store_internal(acc);
+    __syncthreads();
+  }
 }
 
 // two tree sums side by side over n ≤ blockDim entries (n a power of two): the lower half of the workgroup folds sa, the
@@ -751,9 +762,10 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
+  const size_t lds_l = lb * sizeof(typename Lazy<C>::type::X); // 36 KiB
   HIP_TRY(item_partials.alloc(pl->item_cap, s), ICICLE_ALLOCATION_FAILED);
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lb * sizeof(X), s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
-  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lb * sizeof(X), s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lds_l, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
+  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lds_l, s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
   WsScoped<X> raw;
@@ -953,7 +965,7 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   ICICLE_TRY(ss.in(scalars, (size_t)L * batch * sizeof(fe), cfg->are_scalars_on_device, s));
   ICICLE_TRY(sb.in(bases, (size_t)L * stride * (shared ? 1 : batch) * sizeof(A), cfg->are_points_on_device, s));
 
-  int lbf = 10;
+  int lbf = 0; // 0 = this library's default (msm_sort_run)
   ext_get_int(cfg->ext, "large_bucket_factor", &lbf);
   MsmProfile* prof = nullptr;
   for (uint32_t bi = 0; bi < batch; bi++) {

@@ -850,10 +850,19 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->stream = s;
   const uint32_t nb = g.NBb * (uint32_t)g.Wb;
   pl->nbuckets = nb;
-  // large-bucket threshold (the reference: large_bucket_factor(10) × average, cuda_msm.cuh:205-220)
+  // Large-bucket threshold.  One thread sums one bucket, so the accumulation kernel lasts as long as its longest chain: buckets
+  // with more than `thr` entries go to the workgroup-per-chunk kernels instead.  The reference takes large_bucket_factor (10) ×
+  // the average (cuda_msm.cuh:205-220); here the default is 3 × the average with a floor of 64 — uniform scalars have no bucket
+  // beyond 2 × the average, while witnesses of real circuits (0/1 wires, bytes, small packed values) put hundreds of entries
+  // into the low buckets of the first window: with 10 × / floor 512 the synthetic stand-in circuits spent 2 ms (G1) / 6.5 ms (G2)
+  // in 500-addition chains of single threads (prove 11.2 → 6.3 ms at 1.0 M constraints, 14.1 → 8.3 ms at 1.4 M; 1.6 M uniform:
+  // unchanged).  The caller's large_bucket_factor (ConfigExtension) is honoured when given.
+  static const int env_factor = getenv("ICICLE_SNARK_LARGE_FACTOR") ? atoi(getenv("ICICLE_SNARK_LARGE_FACTOR")) : 0;
+  static const uint32_t env_floor = getenv("ICICLE_SNARK_LARGE_FLOOR") ? (uint32_t)atoi(getenv("ICICLE_SNARK_LARGE_FLOOR")) : 64u;
   const uint64_t avg = (g.tab ? (uint64_t)L * g.W : (uint64_t)L * g.pf) / g.NB + 1;
-  uint32_t thr = (uint32_t)(avg * (uint64_t)(lbf > 0 ? lbf : 10));
-  if (thr < 512) thr = 512;
+  uint32_t thr = (uint32_t)(avg * (uint64_t)(env_factor > 0 ? env_factor : lbf > 0 ? lbf : 3));
+  if (thr < env_floor) thr = env_floor;
+  if (thr < 8) thr = 8;
   pl->large_thr = thr;
   const uint32_t nblocks = (nb + SCAN_B - 1) / SCAN_B;
   const uint64_t nentries = (uint64_t)L * g.W;

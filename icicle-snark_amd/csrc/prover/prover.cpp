@@ -180,6 +180,16 @@ struct ZKeyCache {
   // device
   int device_id = 0, shard_rank = 0, shard_count = 1;
   MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM, fixed at cache build
+  // Sparse B: a wire that never occurs on the B side of a constraint has the identity as its B1 and B2 base (snarkjs writes
+  // all-zero bytes).  One thread accumulates one bucket, so an identity base skipped inside the shared witness sort saves
+  // nothing (the other lanes of the wave still add).  When at most ICICLE_SNARK_SPARSE_B (default 0.9; 0 = off) of this
+  // rank's wires have a B base, B1/B2 hold only those nb bases (d_bidx = their wire numbers relative to A.lo), and the two B
+  // MSMs run on their own digit sort of the gathered scalars d_wb (geometry geom_b).
+  bool sparse_b = false;
+  uint32_t nb = 0;
+  uint32_t* d_bidx = nullptr;
+  fe* d_wb = nullptr;
+  MsmGeom geom_b;
   uint32_t* d_rowptr = nullptr; // 2n+1
   uint32_t* d_cols = nullptr;   // n_coef
   fe* d_vals = nullptr;         // n_coef, Montgomery form
@@ -195,7 +205,7 @@ struct ZKeyCache {
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
-  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
+  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_b = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
              ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
@@ -209,7 +219,7 @@ struct ZKeyCache {
     if (s_g3) (void)hipStreamSynchronize(s_g3);
     if (s_g4) (void)hipStreamSynchronize(s_g4);
     if (s_g5) (void)hipStreamSynchronize(s_g5);
-    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_dist_y, (void*)d_dist_recv1, (void*)d_dist_send2, (void*)d_tw1, (void*)d_partials})
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_dist_y, (void*)d_dist_recv1, (void*)d_dist_send2, (void*)d_tw1, (void*)d_partials, (void*)d_bidx, (void*)d_wb})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
     if (s_qap) (void)icicle_destroy_stream(s_qap);
@@ -220,6 +230,7 @@ struct ZKeyCache {
     if (s_g5) (void)icicle_destroy_stream(s_g5);
     if (ev_witness) (void)hipEventDestroy(ev_witness);
     if (ev_sort) (void)hipEventDestroy(ev_sort);
+    if (ev_sort_b) (void)hipEventDestroy(ev_sort_b);
     if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
     if (ev_g2done) (void)hipEventDestroy(ev_g2done);
     if (ev_g4done) (void)hipEventDestroy(ev_g4done);
@@ -408,6 +419,46 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
   }
   lap("device CSR build");
+  {
+    // sparse B (see ZKeyCache): keep only the wires of this rank's range whose B1 or B2 base is not the identity
+    const double max_density = getenv("ICICLE_SNARK_SPARSE_B") ? atof(getenv("ICICLE_SNARK_SPARSE_B")) : 0.9;
+    const uint32_t L = z->B1.len();
+    if (max_density > 0 && L >= 2) {
+      uint8_t* d_flags = nullptr;
+      P_HIP(hipMalloc((void**)&d_flags, L));
+      FreeTmp free_flags{d_flags};
+      P_HIP(qap_points_nonzero(z->B1.d_points, z->B2.d_points, L, d_flags, nullptr));
+      std::vector<uint8_t> flags(L);
+      P_HIP(hipMemcpy(flags.data(), d_flags, L, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> idx;
+      idx.reserve(L);
+      for (uint32_t i = 0; i < L; i++)
+        if (flags[i]) idx.push_back(i);
+      const uint32_t nb = (uint32_t)idx.size();
+      if (nb >= 1 && (double)nb <= max_density * (double)L) {
+        P_HIP(hipMalloc((void**)&z->d_bidx, (size_t)nb * 4));
+        P_HIP(hipMemcpy(z->d_bidx, idx.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+        void *c1 = nullptr, *c2 = nullptr;
+        P_HIP(hipMalloc(&c1, (size_t)nb * 64));
+        FreeTmp free_c1{c1};
+        P_HIP(hipMalloc(&c2, (size_t)nb * 128));
+        FreeTmp free_c2{c2};
+        P_HIP(qap_gather_idx(z->B1.d_points, z->d_bidx, c1, nb, 64, nullptr));
+        P_HIP(qap_gather_idx(z->B2.d_points, z->d_bidx, c2, nb, 128, nullptr));
+        P_HIP(hipStreamSynchronize(nullptr));
+        std::swap(free_c1.p, z->B1.d_points); // the dense arrays are freed at the end of this block
+        std::swap(free_c2.p, z->B2.d_points);
+        z->B1.lo = z->B2.lo = 0;
+        z->B1.hi = z->B2.hi = nb;
+        P_HIP(hipMalloc((void**)&z->d_wb, (size_t)nb * 32));
+        z->device_bytes -= (uint64_t)(L - nb) * (64 + 128);
+        z->device_bytes += (uint64_t)nb * (4 + 32);
+        z->sparse_b = true;
+        z->nb = nb;
+      }
+    }
+  }
+  lap("sparse B detection");
   // bases: the file's Montgomery form (R = 2^256) → the bucket kernels' internal encoding (R' = 2^261), once.  Table mode
   // (msm_plan.h; ICICLE_SNARK_TABLES=0 disables it): every base array becomes W rows 2^(c·w)·P so that all digits of a
   // scalar share one bucket set — 13 instead of 16 mixed additions per scalar at 1.6 M constraints for 13× the base memory.
@@ -415,23 +466,25 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
     z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
     z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
+    z->geom_b = z->sparse_b ? msm_geometry(z->nb, 0, tables ? 1 : 0) : z->geom_w;
     if (tables) {
       // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
       // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
       size_t free_b = 0, total_b = 0;
       release_cached_device_memory(); // blocks parked by icicle_free count as free
       P_HIP(hipMemGetInfo(&free_b, &total_b));
-      const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W;
-      const uint64_t need = ww * ((uint64_t)z->A.len() * 64 * 2 + (uint64_t)z->C.len() * 64 + (uint64_t)z->B2.len() * 128) + wh * (uint64_t)z->H.len() * 64 +
-                            ww * (uint64_t)z->B2.len() * (192 + 64) + ((uint64_t)n * 128 + (uint64_t)z->n_vars * 32 + (64u << 20));
+      const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W, wb = (uint64_t)z->geom_b.W;
+      const uint64_t need = ww * ((uint64_t)z->A.len() * 64 + (uint64_t)z->C.len() * 64) + wb * (uint64_t)z->B1.len() * (64 + 128) + wh * (uint64_t)z->H.len() * 64 +
+                            wb * (uint64_t)z->B2.len() * (192 + 64) + ((uint64_t)n * 128 + (uint64_t)z->n_vars * 32 + (64u << 20));
       if (need > free_b) {
         tables = false;
         z->geom_w = msm_geometry(z->A.len(), 0, 0);
         z->geom_h = msm_geometry(z->H.len(), 0, 0);
+        z->geom_b = z->sparse_b ? msm_geometry(z->nb, 0, 0) : z->geom_w;
       }
     }
     struct Job { Shard* sh; bool g2; const MsmGeom* g; };
-    const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_w}, {&z->B2, true, &z->geom_w}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
+    const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_b}, {&z->B2, true, &z->geom_b}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
     for (const Job& j : jobs5) {
       if (j.g->tab) {
         void* table = nullptr;
@@ -471,6 +524,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   }
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_sort_b, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_g2done, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_g4done, hipEventDisableTiming));
@@ -615,6 +669,8 @@ __attribute__((visibility("default"))) int groth16_cache_info(const Groth16Cache
   info->domain_size = z->domain_size;
   info->n_coef = z->n_coef;
   info->device_bytes = z->device_bytes;
+  info->b_bases = z->B1.len();
+  info->reserved = 0;
   return 0;
 }
 
@@ -698,7 +754,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // ---- stream g2: ONE digit sort of witness[wlo:whi] (shared by A, B1, B2, C), then the G2 bucket stages
   P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));
   const uint32_t wlo = z->A.lo, wlen = z->A.len(), skip = npub + 1;
-  SortPlan plan_w, plan_h;
+  SortPlan plan_w, plan_h, plan_b; // plan_b: the B pair's own sort (sparse B only)
   // declared after the plans, so it runs before their destructors: on an error return the kernels already enqueued may
   // still read the plans' workspace, which ~SortPlan hands back to the arena — drain the six streams first
   struct DrainOnError {
@@ -713,13 +769,27 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   } drain{z};
   MsmProfile* prof[5]; // A, B1, B2, C, H
   for (auto& p : prof) p = msm_profile_next();
-  (void)hipEventRecord(prof[2]->ev[0], g2);
-  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 10, 0, g2, &plan_w, z->geom_w.tab));
+  // the witness sort is timed with the profile of the G2 MSM that follows it on g2 — of A when B2 runs on the sparse-B sort
+  MsmProfile* psort = z->sparse_b ? prof[0] : prof[2];
+  (void)hipEventRecord(psort->ev[0], g2);
+  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w, z->geom_w.tab));
   if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
-  (void)hipEventRecord(prof[2]->ev[4], g2); // end of the witness digit sort (roofline.scatter)
-  prof[2]->has_sort_end = true;
+  (void)hipEventRecord(psort->ev[4], g2); // end of the witness digit sort (roofline.scatter)
+  psort->has_sort_end = true;
   P_HIP(hipEventRecord(z->ev_sort, g2));
   mark("wsort");
+  if (z->sparse_b) {
+    // sparse B: the scalars of the wires that have a B base, gathered and sorted on B1's stream next to the witness sort
+    hipStream_t gb = z->s_g4;
+    P_HIP(hipStreamWaitEvent(gb, z->ev_witness, 0));
+    P_HIP(qap_gather_idx(z->d_witness + wlo, z->d_bidx, z->d_wb, z->nb, 32, gb));
+    P_ICICLE(msm_sort_run(z->d_wb, z->nb, 0, 0, 0, gb, &plan_b, z->geom_b.tab));
+    if (plan_b.g.tab != z->geom_b.tab || plan_b.g.c != z->geom_b.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the B sort");
+    P_HIP(hipEventRecord(z->ev_sort_b, gb));
+    P_HIP(hipStreamWaitEvent(g2, z->ev_sort_b, 0));
+    mark("bsort");
+  }
+  const SortPlan& plan_b12 = z->sparse_b ? plan_b : plan_w; // the plan B1 and B2 run on
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
     p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
   };
@@ -797,8 +867,9 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // fills every CU with ~4 ms workgroups, and the NTT passes of the (longer) g1 chain measured 8× slower
   // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
   if (!early) P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
-  fill(prof[2], plan_w, 1);
-  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len(), 3)); // commitment_b — src/proof_helper.rs:206
+  fill(prof[2], plan_b12, 1);
+  if (z->sparse_b) (void)hipEventRecord(prof[2]->ev[0], g2);
+  P_ICICLE(msm_g2_partials(&plan_b12, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len(), 3)); // commitment_b — src/proof_helper.rs:206
   (void)hipEventRecord(prof[2]->ev[3], g2);
   prof[2]->valid = true;
   P_HIP(hipEventRecord(z->ev_g2done, g2));
@@ -807,7 +878,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
   P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
   (void)hipEventRecord(prof[4]->ev[0], g3);
-  P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 10, 0, g3, &plan_h, z->geom_h.tab));
+  P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab));
   if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
   (void)hipEventRecord(prof[4]->ev[4], g3);
   prof[4]->has_sort_end = true;
@@ -823,11 +894,12 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   hipStream_t st3[3] = {g1, z->s_g4, z->s_g5};
   for (int k = 0; k < 3; k++) {
     MsmProfile* p = prof[order[k]];
-    fill(p, plan_w, 0);
-    P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
+    const SortPlan& pl = k == 1 ? plan_b12 : plan_w;
+    fill(p, pl, 0);
+    P_HIP(hipStreamWaitEvent(st3[k], k == 1 && z->sparse_b ? z->ev_sort_b : z->ev_sort, 0));
     if (k && !early) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
-    (void)hipEventRecord(p->ev[0], st3[k]);
-    P_ICICLE(msm_g1_partials(&plan_w, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len(), k)); // ticket slots 0-2 of the witness plan (B2: 3)
+    if (p != psort) (void)hipEventRecord(p->ev[0], st3[k]);
+    P_ICICLE(msm_g1_partials(&pl, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len(), k)); // ticket slots 0-2 of the plan (B2: 3)
     (void)hipEventRecord(p->ev[3], st3[k]);
     p->valid = true;
   }
@@ -864,9 +936,10 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // Each MSM's partial sums go to pinned memory on ITS OWN stream as soon as its reduction is done, and a host
   // thread per MSM waits for that copy and runs the Horner tail — the tails of the early finishers (B2, A, B1, C)
   // overlap the GPU work still in flight; only the last one (H) is exposed.
-  uint32_t Ww = 0, bw1 = 0, bw2 = 0, Wh = 0, bh = 0;
-  const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Ww, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
-  const size_t sizes[5] = {by1, by1, by2, by1, byh};
+  uint32_t Ww = 0, bw1 = 0, Wb = 0, bb1 = 0, bw2 = 0, Wh = 0, bh = 0;
+  const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), byb = msm_partials_bytes(&plan_b12, false, &Wb, &bb1), by2 = msm_partials_bytes(&plan_b12, true, &Wb, &bw2),
+               byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
+  const size_t sizes[5] = {by1, byb, by2, by1, byh};
   hipStream_t st5[5] = {st3[0], st3[1], g2, st3[2], gh};
   if (h_chain) {
     // the copy of the MSM in front of H must not wait for H (same stream): its partials were complete at its ev[3], copy them on g3 instead
@@ -882,14 +955,14 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   mark("copies");
   {
     const uint8_t* HP = z->h_partials;
-    const int cw = plan_w.g.c, ch = plan_h.g.c;
+    const int cw = plan_w.g.c, cb = plan_b12.g.c, ch = plan_h.g.c;
     hipEvent_t* evd = z->ev_done;
     const int dev = z->device_id;
-    const MsmGeom gw = plan_w.g, gh = plan_h.g;
+    const MsmGeom gw = plan_w.g, gb = plan_b12.g, gh = plan_h.g;
     auto g1tail = [&](int k, uint32_t W, uint32_t bpw, int c, size_t off) {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[k]);
-      const MsmGeom& gg = k == 4 ? gh : gw;
+      const MsmGeom& gg = k == 4 ? gh : k == 1 ? gb : gw;
       if (gg.tab) msm_g1_host_tail_tab(HP + k * PARTIALS_STRIDE, W, bpw, gg.NBb, (bn254_projective_t*)(out_points + off));
       else msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, 1, c, gg.wide, (bn254_projective_t*)(out_points + off));
       if (et && k < 2) {
@@ -903,13 +976,13 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
       }
     };
     std::thread t0(g1tail, 0, Ww, bw1, cw, (size_t)0);
-    std::thread t1(g1tail, 1, Ww, bw1, cw, (size_t)96);
+    std::thread t1(g1tail, 1, Wb, bb1, cb, (size_t)96);
     std::thread t3(g1tail, 3, Ww, bw1, cw, (size_t)384);
     std::thread t2([&] {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[2]);
-      if (gw.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Ww, bw2, gw.NBb, (bn254_g2_projective_t*)(out_points + 192));
-      else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Ww, 1, cw, gw.wide, (bn254_g2_projective_t*)(out_points + 192));
+      if (gb.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Wb, bw2, gb.NBb, (bn254_g2_projective_t*)(out_points + 192));
+      else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Wb, 1, cb, gb.wide, (bn254_g2_projective_t*)(out_points + 192));
     });
     g1tail(4, Wh, bh, ch, 480);
     t0.join(); t1.join(); t2.join(); t3.join();
@@ -922,8 +995,17 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   P_HIP(hipStreamSynchronize(z->s_g5));
   P_HIP(hipStreamSynchronize(z->s_qap));
   drain.armed = false;
+  if (getenv("ICICLE_SNARK_TRACE_LARGE")) {
+    // debug: large buckets / work items / threshold of the three digit sorts of this prove
+    for (const SortPlan* pl : {(const SortPlan*)&plan_w, (const SortPlan*)&plan_b12, (const SortPlan*)&plan_h}) {
+      uint32_t nl[4] = {0, 0, 0, 0};
+      if (pl->n_large) (void)hipMemcpy(nl, pl->n_large, sizeof nl, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[large] L=%u buckets=%u thr=%u: %u large buckets, %u entries in them, %u work items (cap %u)\n", pl->L, pl->nbuckets, pl->large_thr, nl[0], nl[1], nl[2], pl->item_cap);
+    }
+  }
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
+  if (z->sparse_b) msm_sort_release(&plan_b);
   {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);

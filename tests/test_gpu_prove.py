@@ -261,3 +261,35 @@ def test_optional_schedules_and_reductions_give_the_same_proof(gpu, O, S, tmp_pa
         assert out.returncode == 0, out.stderr[-2000:]
         got = json.loads(out.stdout.strip().splitlines()[-1])
         assert got == [proof, public], env
+
+
+def test_sparse_b_subset_equals_dense(gpu, O, S, monkeypatch):
+    """Wires without a B-side occurrence have identity B1/B2 bases; the cache then runs the two B MSMs over the other
+    wires only (their own digit sort).  Same proof, byte for byte, as with the subset switched off, equal to the oracle's;
+    the same through three point-range shards (each shard keeps its own subset)."""
+    K = gpu
+    r1, w = S.random_circuit(3000, 3, 40, bit_fraction=0.7)
+    zkey, _ = S.setup(r1, _fbm(K), points_to_mont=lambda a: O.fq_convert_montgomery(a, True))
+    wtns = S.write_wtns(w)
+    r, s = 0x1234567, 0x7654321
+    out = {}
+    for mode, val in (("dense", "0"), ("sparse", "1.0")):
+        monkeypatch.setenv("ICICLE_SNARK_SPARSE_B", val)
+        c = K.CacheManager()
+        c.load("k", zkey)
+        info = c.info("k")
+        pj, qj, _ = c.prove_mem("k", wtns, r, s)
+        out[mode] = (pj, qj, info.b_bases, info.n_vars)
+        if mode == "sparse":
+            blocks = []
+            for rank in range(3):
+                c.load(f"s{rank}", zkey, shard_rank=rank, shard_count=3)
+                blocks.append(c.commitments(f"s{rank}", wtns)[0])
+            sj, sq = c.assemble("k", wtns, K.sum_commitments(b"".join(blocks), 3), r, s)[:2]
+            assert (sj, sq) == (pj, qj)
+        c.close()
+    assert out["dense"][2] == out["dense"][3]
+    assert 0 < out["sparse"][2] < out["sparse"][3], "the random circuit should leave some wires without a B base"
+    assert out["dense"][:2] == out["sparse"][:2]
+    proof, public = O.groth16_prove(zkey, wtns, r, s)
+    assert json.loads(out["sparse"][0]) == proof and json.loads(out["sparse"][1]) == public
