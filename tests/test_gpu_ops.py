@@ -205,7 +205,12 @@ def test_msm_skewed_scalars(gpu, O, grp):
     sc = rand_fr(O, rng, n)
     kind = rng.integers(0, 10, size=n)
     sc[kind < 4] = 0
-    sc[(kind >= 4) & (kind < 8)] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    sc[(kind >= 4) & (kind < 7)] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    # bytes / small packed values: a few hundred entries in each of the lowest buckets — above the large-bucket threshold
+    # (3 × average, at least 64), below one 1024-entry work item; the 0/1 bucket above spans several work items
+    small = kind == 7
+    sc[small] = 0
+    sc[small, 0] = rng.integers(2, 10, size=int(small.sum()), dtype=np.uint64)
     sc[kind == 8] = O.ints_to_arr([O.R_MOD - 1])[0]
     bases = _bases(O, grp, rng, n, distinct=50)
     want = O.ec_to_affine(grp, O.msm(grp, sc, bases))
