@@ -50,6 +50,8 @@ struct CopyJob {
 };
 constexpr int STAGED_LANES = 8;
 hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes = nullptr, int n_lanes = 0, bool own_temp_streams = false);
+// the calling thread's next staged copies read sources inside [base, base + len) from file descriptor fd (fd < 0: off)
+void staged_copy_file_hint(const void* base, size_t len, int fd);
 // true when hipMemcpyAsync can DMA straight from/to `host_ptr` (pinned / registered memory)
 bool is_pinned_host(const void* host_ptr);
 // copies of at least this many bytes from/to pageable memory take the staged path
