@@ -1,5 +1,8 @@
 // msm_g2.hip — G2 (Fq2 coordinates) instantiation of the MSM pipeline (see msm_impl.h).
 #define ISNARK_G2_ACC_EXTERN 1
+#ifdef G2_REDUCE_MIN_BLOCKS
+#define REDUCE_MIN_BLOCKS G2_REDUCE_MIN_BLOCKS
+#endif
 #include "msm_impl.h"
 
 namespace isnark {

@@ -69,6 +69,9 @@ template <> struct Lazy<G2> { typedef G2L type; };
 #ifndef ACC_MIN_WAVES
 #define ACC_MIN_WAVES 1
 #endif
+#ifndef REDUCE_MIN_BLOCKS
+#define REDUCE_MIN_BLOCKS 1 // experiment hook (msm_g2.hip: -DG2_REDUCE_MIN_BLOCKS=2 caps the G2 reduction at 256 VGPRs)
+#endif
 // `form`: encoding of the affine bases in memory — 0 standard, 1 Montgomery R = 2^256 (zkey files), 2 internal
 // (packed canonical Montgomery R' = 2^261, produced once by msm_points_to_internal; no per-load conversion)
 // `ib` = 0: classic entry (point index; base = bases[(i − skip)·stride]).  ib > 0: table mode, entry = i | w << ib and
@@ -275,7 +278,7 @@ __device__ __forceinline__ bool last_workgroup_of_window(uint32_t* tickets)
 // raw / tickets: scratch for the per-workgroup results (internal encoding) and one zeroed counter per window, used when
 // gridDim.x > 1.
 template <class C>
-__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ out, int emit_line,
+__global__ __launch_bounds__(256, REDUCE_MIN_BLOCKS) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ out, int emit_line,
                                                                 typename C::X* raw, uint32_t* tickets)
 {
   typedef typename Lazy<C>::type CL;
