@@ -392,7 +392,7 @@ def main():
             return None
         # host witness → this rank's partial commitments; with 2, 4 or 8 ranks the QAP front end is distributed too
         # (two all-to-alls of the exchange), otherwise replicated
-        blk, tm = P.sharded_commitments(cm, key, wtns, exch, distributed_qap=dist_qap[0])
+        blk, tm = P.sharded_commitments(cm, key, wtns, exch, distributed_qap=dist_qap[0], shard_witness=shard_w[0])
         if timed:
             phases["qap"] += tm.qap_ms
             phases["msm"] += tm.msm_ms
@@ -401,8 +401,11 @@ def main():
         return cm.assemble(key, wtns, blk)                        # random r, s like the reference default build
 
     dist_qap = [world > 1 and cm.dist_supported(key) and os.environ.get("ICICLE_SNARK_BENCH_DIST_QAP", "1") != "0"]
-    if world > 1 and dist_qap[0]:
-        # one untimed distributed step; if the all-to-all fails on any rank, every rank falls back to the replicated front end
+    # every rank uploads 1/world of the witness; an in-place all-gather over the exchange completes it on every device
+    shard_w = [world > 1 and os.environ.get("ICICLE_SNARK_SHARD_WITNESS", "1") != "0"]
+    if world > 1 and (dist_qap[0] or shard_w[0]):
+        # one untimed distributed step; if a device collective fails on any rank, every rank falls back to full witness uploads
+        # and the replicated front end
         import torch
         ok = 1
         try:
@@ -414,7 +417,8 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             dist_qap[0] = False
-            log("falling back to the replicated QAP front end on every rank")
+            shard_w[0] = False
+            log("falling back to full witness uploads and the replicated QAP front end on every rank")
     for _ in range(max(1, args.warmup)):
         step()
     sync(); barrier()
@@ -523,6 +527,8 @@ def main():
                        "exchange": type(exch).__name__,
                        "qap_front_end": ("distributed: rows split by residue class, two all-to-alls of 3*(n/N)*32 B per rank" if world > 1 and dist_qap[0]
                                          else ("replicated on every rank" if world > 1 else "single GPU")),
+                       "witness_upload": ("1/N of the witness per rank over PCIe + in-place all-gather over the exchange" if world > 1 and shard_w[0]
+                                          else ("whole witness on every rank over PCIe" if world > 1 else "whole witness over PCIe")),
                        "prove_ms_files": ms_per_step if world == 1 else None,
                        "prove_ms_host_witness": host_ms, "prove_ms_hbm_resident": resident_ms,
                        "value_hbm_resident": N / (resident_ms * 1e-3) if resident_ms else None,

@@ -607,12 +607,23 @@ class CacheManager:
     def dist_supported(self, key: str) -> bool:
         return bool(lib().groth16_dist_supported(self._h, key.encode()))
 
-    def dist_stage1(self, key: str, wtns: bytes):
-        """→ (send ptr, recv ptr, rows, row_bytes, chunk_bytes): device buffers of exchange 1"""
+    def dist_stage1(self, key: str, wtns: bytes | None):
+        """→ (send ptr, recv ptr, rows, row_bytes, chunk_bytes): device buffers of exchange 1.  wtns=None: the witness is
+        already resident (upload_witness_slice + all-gather + witness_ready)"""
         send, recv = C.c_void_p(), C.c_void_p()
         rows, rb, cb = C.c_uint32(), C.c_uint64(), C.c_uint64()
-        _pcheck(lib().groth16_dist_stage1(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), C.byref(send), C.byref(recv), C.byref(rows), C.byref(rb), C.byref(cb)), "dist_stage1")
+        _pcheck(lib().groth16_dist_stage1(self._h, key.encode(), wtns, C.c_size_t(len(wtns) if wtns else 0), C.byref(send), C.byref(recv), C.byref(rows), C.byref(rb), C.byref(cb)), "dist_stage1")
         return send.value, recv.value, rows.value, rb.value, cb.value
+
+    def upload_witness_slice(self, key: str, wtns: bytes):
+        """this rank's 1/shard_count of the witness → its place in the device witness buffer.
+        → (device pointer of the whole buffer, bytes per rank of the in-place all-gather that completes it)"""
+        ptr, sb = C.c_void_p(), C.c_uint64()
+        _pcheck(lib().groth16_upload_witness_slice(self._h, key.encode(), wtns, C.c_size_t(len(wtns)), C.byref(ptr), C.byref(sb)), "upload_witness_slice")
+        return ptr.value, sb.value
+
+    def witness_ready(self, key: str):
+        _pcheck(lib().groth16_witness_ready(self._h, key.encode()), "witness_ready")
 
     def dist_stage2(self, key: str):
         """→ (send ptr, recv ptr) of exchange 2 (same geometry as exchange 1)"""
@@ -638,7 +649,7 @@ PROVER_SYMBOLS = """
 groth16_cache_manager_new groth16_cache_manager_free groth16_prove groth16_cache_load groth16_cache_load_file
 groth16_cache_contains groth16_cache_evict groth16_commitments groth16_sum_commitments groth16_assemble_proof
 groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error groth16_last_timings
-groth16_dist_supported groth16_dist_stage1 groth16_dist_stage2
+groth16_dist_supported groth16_dist_stage1 groth16_dist_stage2 groth16_upload_witness_slice groth16_witness_ready
 groth16_verify groth16_verify_json groth16_verify_last_error
 """.split()
 

@@ -118,6 +118,23 @@ API int icicle_snark_rccl_alltoall_rows(void* comm, const void* d_send, void* d_
   return 0;
 }
 
+// in-place all-gather of a DEVICE buffer of world × slice_bytes bytes: this rank's slice sits at d_buf + rank·slice_bytes
+// (the witness of a sharded prove: every rank uploads 1/world of it over PCIe and the rest arrives over xGMI —
+// include/groth16_prover.h: groth16_upload_witness_slice)
+API int icicle_snark_rccl_allgather_device(void* comm, void* d_buf, size_t slice_bytes)
+{
+  Comm* c = (Comm*)comm;
+  if (!c || !d_buf || slice_bytes == 0) return fail("allgather_device: bad arguments", -1);
+  if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice", -1);
+  int me = 0;
+  ncclResult_t r = ncclCommUserRank(c->comm, &me);
+  if (r != ncclSuccess) return fail("ncclCommUserRank", (int)r);
+  r = ncclAllGather((const uint8_t*)d_buf + (size_t)me * slice_bytes, d_buf, slice_bytes, ncclUint8, c->comm, c->stream);
+  if (r != ncclSuccess) return fail("ncclAllGather (device, in place)", (int)r);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("sync", -1);
+  return 0;
+}
+
 // max over ranks of one double (used for the benchmark's max-over-ranks timing)
 API int icicle_snark_rccl_allreduce_max(void* comm, double* value)
 {

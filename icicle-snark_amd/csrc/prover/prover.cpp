@@ -284,6 +284,9 @@ int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint
   return 0;
 }
 
+// elements per rank when the witness is uploaded in shard_count slices
+inline uint64_t witness_slice_elems(uint32_t n_vars, int count) { return ((uint64_t)n_vars + count - 1) / count; }
+
 // CacheManager::compute — src/cache.rs:117-241
 int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out)
 {
@@ -500,7 +503,8 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipStreamSynchronize(nullptr));
   lap("points to internal form / tables");
 
-  P_HIP(hipMalloc((void**)&z->d_witness, (size_t)z->n_vars * 32));
+  // room for shard_count equal slices (groth16_upload_witness_slice: the in-place all-gather wants equal counts)
+  P_HIP(hipMalloc((void**)&z->d_witness, (size_t)witness_slice_elems(z->n_vars, count) * count * 32));
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
   if (z->H.stride > 1) P_HIP(hipMalloc((void**)&z->d_fold, (size_t)z->H.len() * 3 * 32));
   P_HIP(hipMalloc((void**)&z->d_partials, 5 * PARTIALS_STRIDE));
@@ -1041,10 +1045,48 @@ __attribute__((visibility("default"))) int groth16_dist_supported(Groth16CacheMa
   return m % G == 0 && ntt_fusable(m) ? 1 : 0;
 }
 
+// Multi-GPU witness distribution (see include/groth16_prover.h)
+__attribute__((visibility("default"))) int groth16_upload_witness_slice(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, void** d_witness, uint64_t* slice_bytes)
+{
+  if (!cm || !wtns || !d_witness || !slice_bytes) return fail(ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(cm->mu);
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  ZKeyCache* z = zp.get();
+  if (!z) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  IcicleDevice dev;
+  memset(&dev, 0, sizeof dev);
+  strcpy(dev.type, "HIP");
+  dev.id = z->device_id;
+  P_ICICLE(icicle_set_device(&dev));
+  Wtns w;
+  if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
+  if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
+  if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
+  z->witness_resident = false; // until groth16_witness_ready
+  const uint64_t slice = witness_slice_elems(z->n_vars, z->shard_count);
+  const uint64_t lo = std::min<uint64_t>(z->n_vars, slice * (uint64_t)z->shard_rank), hi = std::min<uint64_t>(z->n_vars, lo + slice);
+  if (hi > lo) {
+    const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
+    if (int rc = staged_upload(z->device_id, {{z->d_witness + lo, (const uint8_t*)w.values + lo * 32, (size_t)(hi - lo) * 32}}, lanes, 3)) return rc;
+  }
+  *d_witness = z->d_witness;
+  *slice_bytes = slice * 32;
+  return 0;
+}
+__attribute__((visibility("default"))) int groth16_witness_ready(Groth16CacheManager* cm, const char* key)
+{
+  if (!cm) return fail(ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(cm->mu);
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  if (!zp) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  zp->witness_resident = true;
+  return 0;
+}
+
 __attribute__((visibility("default"))) int groth16_dist_stage1(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, void** d_send, void** d_recv, uint32_t* rows,
                                                                uint64_t* row_bytes, uint64_t* chunk_bytes)
 {
-  if (!cm || !wtns || !d_send || !d_recv) return fail(ERR_ARG, "null argument");
+  if (!cm || !d_send || !d_recv) return fail(ERR_ARG, "null argument");
   if (!groth16_dist_supported(cm, key)) return fail(ERR_ARG, "cache entry '%s' is not a strided shard of 2, 4 or 8 (or too small) — use groth16_commitments", key ? key : "");
   std::lock_guard<std::mutex> lk(cm->mu);
   const std::shared_ptr<ZKeyCache> zp = find(cm, key);
@@ -1056,13 +1098,16 @@ __attribute__((visibility("default"))) int groth16_dist_stage1(Groth16CacheManag
   P_ICICLE(icicle_set_device(&dev));
   if (int rc = ensure_domain(cm, z)) return rc;
   const uint32_t n = z->domain_size, G = (uint32_t)z->shard_count, r = (uint32_t)z->shard_rank, m = n / G;
-  Wtns w;
-  if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
-  if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
-  if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
-  const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
-  if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)z->n_vars * 32}}, lanes, 3)) return rc;
-  z->witness_resident = true;
+  if (wtns) {
+    Wtns w;
+    if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
+    if (!Fr::eq(z->r, w.q)) return fail(ERR_FORMAT, "Curve of the witness does not match the curve of the proving key");
+    if (w.n_witness != z->n_vars) return fail(ERR_FORMAT, "Invalid witness length. Circuit: %u, witness: %u", z->n_vars, w.n_witness);
+    const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
+    if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)z->n_vars * 32}}, lanes, 3)) return rc;
+    z->witness_resident = true;
+  } else if (!z->witness_resident)
+    return fail(ERR_ARG, "no witness given and none resident on the device");
   hipStream_t gq = z->s_qap;
   int dom_log = 0;
   const fe* tw = ntt_domain_table(&dom_log);

@@ -55,6 +55,9 @@ class LocalExchange:
     def max(self, x: float) -> float:
         return x
 
+    def allgather_device(self, ptr: int, slice_bytes: int):
+        pass
+
     def barrier(self):
         pass
 
@@ -97,6 +100,14 @@ class GlooExchange:
                 dst = q * row_bytes + p * chunk_bytes
                 recv[dst:dst + chunk_bytes] = bytes(outs[p][src:src + chunk_bytes].numpy())
         K.raw_to_device(recv_ptr, bytes(recv))
+
+    def allgather_device(self, ptr: int, slice_bytes: int):
+        """stand-in for the in-place RCCL all-gather of a device buffer (world × slice_bytes): staged through the host"""
+        import torch
+        mine = torch.frombuffer(bytearray(K.raw_to_host(ptr + self.rank * slice_bytes, slice_bytes)), dtype=torch.uint8)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(outs, mine)
+        K.raw_to_device(ptr, b"".join(bytes(o.numpy()) for o in outs))
 
     def barrier(self):
         self.dist.barrier()
@@ -142,6 +153,17 @@ class RcclExchange:
         want = b"".join(bytes([p, self.rank, q, 0xA5]) * (chunk // 4) for q in range(rows) for p in range(self.world))
         if got != want:
             raise RuntimeError("rccl all-to-all self-test returned wrong data")
+        # … and one in-place all-gather of a device buffer (the witness distribution of a sharded prove)
+        sl = 512
+        d_buf = K.DeviceVec(sl * self.world)
+        try:
+            K.raw_to_device(d_buf.ptr + self.rank * sl, bytes([self.rank & 0xff, 0x5A]) * (sl // 2))
+            self.allgather_device(d_buf.ptr, sl)
+            got = K.raw_to_host(d_buf.ptr, sl * self.world)
+        finally:
+            d_buf.free()
+        if got != b"".join(bytes([r & 0xff, 0x5A]) * (sl // 2) for r in range(self.world)):
+            raise RuntimeError("rccl in-place device all-gather self-test returned wrong data")
 
     def _check(self, rc, what):
         if rc != 0:
@@ -162,6 +184,10 @@ class RcclExchange:
         self._check(self.lib.icicle_snark_rccl_alltoall_rows(self.comm, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), rows, C.c_size_t(row_bytes),
                                                              C.c_size_t(chunk_bytes)), "alltoall_rows")
 
+    def allgather_device(self, ptr: int, slice_bytes: int):
+        """in-place all-gather of a device buffer over xGMI: this rank's slice sits at ptr + rank·slice_bytes"""
+        self._check(self.lib.icicle_snark_rccl_allgather_device(self.comm, C.c_void_p(ptr), C.c_size_t(slice_bytes)), "allgather_device")
+
     def barrier(self):
         self.dist.barrier()
 
@@ -171,10 +197,25 @@ class RcclExchange:
             self.comm = None
 
 
-def sharded_commitments(cm, key: str, wtns, exch, distributed_qap: bool = True):
+def sharded_commitments(cm, key: str, wtns, exch, distributed_qap: bool = True, shard_witness: bool | None = None):
     """this rank's five partial commitments.  With 2, 4 or 8 ranks (H sharded by residue class) the QAP front end is
     distributed too: every rank transforms 1/world of the rows and two all-to-alls move the blocks (dist_qap.py); otherwise
-    (or with distributed_qap=False, or when the witness is already resident: wtns=None) it is replicated, communication-free."""
+    (or with distributed_qap=False, or when the witness is already resident: wtns=None) it is replicated, communication-free.
+    shard_witness (default: on with more than one rank; ICICLE_SNARK_SHARD_WITNESS=0 turns it off): every rank uploads
+    1/world of the witness over PCIe and an in-place all-gather over the exchange completes it on every device."""
+    if shard_witness is None:
+        shard_witness = exch.world > 1 and os.environ.get("ICICLE_SNARK_SHARD_WITNESS", "1") != "0"
+    if shard_witness and wtns is not None and exch.world > 1:
+        ptr, slice_bytes = cm.upload_witness_slice(key, wtns)
+        exch.allgather_device(ptr, slice_bytes)
+        cm.witness_ready(key)
+        wtns = None
+        if distributed_qap and cm.dist_supported(key):
+            send, recv, rows, rb, cb = cm.dist_stage1(key, None)
+            exch.alltoall_rows(send, recv, rows, rb, cb)
+            send, recv = cm.dist_stage2(key)
+            exch.alltoall_rows(send, recv, rows, rb, cb)
+        return cm.commitments(key, None)
     if distributed_qap and wtns is not None and exch.world > 1 and cm.dist_supported(key):
         send, recv, rows, rb, cb = cm.dist_stage1(key, wtns)
         exch.alltoall_rows(send, recv, rows, rb, cb)

@@ -63,6 +63,15 @@ typedef struct {
 int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len,
                         uint8_t out_points[GROTH16_COMMITMENTS_BYTES], Groth16Timings* timings /* may be NULL */);
 
+/* Multi-GPU witness distribution.  Every rank of a sharded key needs the whole witness on its device (its MSM range, and
+ * the rows of the QAP front end it evaluates read arbitrary wires).  Instead of shard_count full uploads over PCIe, rank r
+ * uploads elements [r·slice, min(n_vars, (r+1)·slice)), slice = ⌈n_vars / shard_count⌉, to their place in its device
+ * witness buffer; the caller completes the buffer with an IN-PLACE all-gather of `slice_bytes` bytes per rank over
+ * `*d_witness` (world × slice_bytes bytes; RCCL over xGMI: icicle_snark_rccl_allgather_device) and then calls
+ * groth16_witness_ready, after which groth16_commitments / groth16_dist_stage1 take wtns = NULL. */
+int groth16_upload_witness_slice(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, void** d_witness, uint64_t* slice_bytes);
+int groth16_witness_ready(Groth16CacheManager* cm, const char* key);
+
 /* Distributed QAP front end for 2, 4 or 8 shards (H sharded by residue class; DESIGN.md §5, icicle-snark_amd/dist_qap.py):
  * instead of replicating the spmv and the inverse transform on every rank, each rank transforms 1/count of the rows and
  * two all-to-alls move the blocks.  Sequence per prove, on every rank:

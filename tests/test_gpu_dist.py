@@ -59,3 +59,42 @@ def test_distributed_front_end_equals_single_gpu(gpu, O, N, G):
         cm.dist_stage1("full", wtns)
     cm.close()
     K.release_domain()
+
+
+@pytest.mark.parametrize("N,G", [(100_000, 4), (30_001, 3)])
+def test_witness_slices_and_all_gather_equal_full_uploads(gpu, O, N, G):
+    """multi-GPU witness distribution on one device: every shard cache uploads only its 1/G of the witness, the in-place
+    all-gather is emulated by copying the slices between the shards' device buffers, and the proof is the single-GPU one —
+    with the distributed front end (power-of-two G) and with the replicated one (G = 3, n_vars not a multiple of G)"""
+    K = gpu
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    S = importlib.import_module("icicle-snark_amd.synth")
+    zkey, wtns = bench.make_inputs(K, S, N)
+    cm = K.CacheManager()
+    cm.load("full", zkey)
+    want, _, _ = cm.prove_mem("full", wtns, 5, 9)
+    keys = [f"s{r}" for r in range(G)]
+    for r, k in enumerate(keys):
+        cm.load(k, zkey, shard_rank=r, shard_count=G)
+    n_vars = cm.info("full").n_vars
+    for rep in range(2):
+        up = [cm.upload_witness_slice(k, wtns) for k in keys]
+        sb = up[0][1]
+        assert all(u[1] == sb for u in up) and sb * G >= n_vars * 32 and (sb // 32 - 1) * G < n_vars
+        # before witness_ready the shard refuses to run on a half-filled buffer
+        with pytest.raises(K.ProverError, match="none resident"):
+            cm.commitments(keys[0], None)
+        slices = [K.raw_to_host(up[r][0] + r * sb, sb) for r in range(G)]
+        for r in range(G):
+            K.raw_to_device(up[r][0], b"".join(slices))
+            cm.witness_ready(keys[r])
+        if cm.dist_supported(keys[0]):
+            st = [cm.dist_stage1(k, None) for k in keys]
+            rows, rb, cb = st[0][2:]
+            _exchange(K, [(s[0], s[1]) for s in st], rows, rb, cb)
+            _exchange(K, [cm.dist_stage2(k) for k in keys], rows, rb, cb)
+        blocks = b"".join(cm.commitments(k, None)[0] for k in keys)
+        got, _ = cm.assemble("full", wtns, K.sum_commitments(blocks, G), 5, 9)
+        assert got == want, (N, G, rep)
+    cm.close()
