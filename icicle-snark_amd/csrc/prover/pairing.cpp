@@ -314,7 +314,27 @@ struct JParser {
     std::string r;
     p++; // opening quote
     while (p < end && *p != '"') {
-      if (*p == '\\' && p + 1 < end) p++;
+      const unsigned char ch = (unsigned char)*p;
+      // RFC 8259 strings: no raw control characters; the files this verifier reads (snarkjs JSON) are plain ASCII, so bytes
+      // above 0x7f are refused as well instead of being checked for well-formed UTF-8
+      if (ch < 0x20 || ch > 0x7e) { ok = false; break; }
+      if (ch == '\\') {
+        if (p + 1 >= end) { ok = false; break; }
+        p++;
+        const char e = *p;
+        if (e == 'u') {
+          if (end - p < 5) { ok = false; break; }
+          for (int k = 1; k <= 4; k++) {
+            const char h = p[k];
+            if (!((h >= '0' && h <= '9') || (h >= 'a' && h <= 'f') || (h >= 'A' && h <= 'F'))) ok = false;
+          }
+          if (!ok) break;
+          r.append(p - 1, 6); // kept verbatim: no field this verifier reads contains an escape
+          p += 5;
+          continue;
+        }
+        if (e != '"' && e != '\\' && e != '/' && e != 'b' && e != 'f' && e != 'n' && e != 'r' && e != 't') { ok = false; break; }
+      }
       r.push_back(*p++);
     }
     if (p < end) p++;
@@ -362,8 +382,29 @@ struct JParser {
     } else {
       v.t = JVal::NUM;
       while (p < end && *p != ',' && *p != ']' && *p != '}' && *p != ' ' && *p != '\n' && *p != '\r' && *p != '\t') v.s.push_back(*p++);
-      if (v.s.empty()) ok = false;
+      if (!bare_token_ok(v.s)) ok = false;
     }
+    return v;
+  }
+  // a bare token is a JSON number or one of the three literals — anything else is not JSON (serde_json rejects it too)
+  static bool bare_token_ok(const std::string& t)
+  {
+    if (t == "true" || t == "false" || t == "null") return true;
+    size_t i = 0;
+    const size_t n = t.size();
+    auto digits = [&] { const size_t b = i; while (i < n && t[i] >= '0' && t[i] <= '9') i++; return i > b; };
+    if (i < n && t[i] == '-') i++;
+    if (!digits()) return false;
+    if (i < n && t[i] == '.') { i++; if (!digits()) return false; }
+    if (i < n && (t[i] == 'e' || t[i] == 'E')) { i++; if (i < n && (t[i] == '+' || t[i] == '-')) i++; if (!digits()) return false; }
+    return i == n;
+  }
+  // the whole text must be ONE value: only white space may follow it
+  JVal document()
+  {
+    JVal v = val();
+    ws();
+    if (p != end) ok = false;
     return v;
   }
 };
@@ -420,6 +461,8 @@ bool g2_valid(const G2::A& a) // Montgomery form: on the twist y² = x³ + 3/ξ 
 bool read_g1(const JVal* v, G1::A* out) // deserialize_g1_affine — src/conversions.rs:58-70
 {
   if (!v || v->t != JVal::ARR || v->a.size() < 2) return false;
+  for (const JVal& e : v->a)
+    if (e.t != JVal::STR) return false; // Vec<String> in the reference: a bare number is a type error there
   fe x, y;
   if (!dec_to_fe(v->a[0].s, &x) || !dec_to_fe(v->a[1].s, &y)) return false;
   if (!Fq::is_canonical(x) || !Fq::is_canonical(y)) return false;
@@ -429,6 +472,11 @@ bool read_g1(const JVal* v, G1::A* out) // deserialize_g1_affine — src/convers
 bool read_g2(const JVal* v, G2::A* out) // deserialize_g2_affine — src/conversions.rs:72-96
 {
   if (!v || v->t != JVal::ARR || v->a.size() < 2 || v->a[0].a.size() < 2 || v->a[1].a.size() < 2) return false;
+  for (const JVal& row : v->a) {
+    if (row.t != JVal::ARR) return false; // Vec<Vec<String>>
+    for (const JVal& e : row.a)
+      if (e.t != JVal::STR) return false;
+  }
   fe c[4];
   if (!dec_to_fe(v->a[0].a[0].s, &c[0]) || !dec_to_fe(v->a[0].a[1].s, &c[1]) || !dec_to_fe(v->a[1].a[0].s, &c[2]) || !dec_to_fe(v->a[1].a[1].s, &c[3])) return false;
   for (const fe& ci : c)
@@ -546,7 +594,7 @@ __attribute__((visibility("default"))) int groth16_verify_json(const char* proof
 {
   if (!proof_json || !public_json || !vk_json) return vfail(-3, "null argument");
   JParser pp{proof_json, proof_json + strlen(proof_json)}, pq{public_json, public_json + strlen(public_json)}, pv{vk_json, vk_json + strlen(vk_json)};
-  JVal proof = pp.val(), pub = pq.val(), vk = pv.val();
+  JVal proof = pp.document(), pub = pq.document(), vk = pv.document();
   if (!pp.ok || !pq.ok || !pv.ok || proof.t != JVal::OBJ || pub.t != JVal::ARR || vk.t != JVal::OBJ) return vfail(-2, "malformed JSON");
   G1::A pi_a, pi_c, alpha1;
   G2::A pi_b, beta2, gamma2, delta2;
@@ -558,8 +606,12 @@ __attribute__((visibility("default"))) int groth16_verify_json(const char* proof
   const JVal* ic = vk.get("IC");
   const JVal* np = vk.get("nPublic");
   if (!ic || ic->t != JVal::ARR || !np) return vfail(-2, "verification key: IC / nPublic missing");
+  if ((np->t != JVal::NUM && np->t != JVal::STR) || np->s.empty() || np->s.size() > 9 || np->s.find_first_not_of("0123456789") != std::string::npos)
+    return vfail(-2, "verification key: nPublic is not a non-negative integer");
   const size_t n_public = (size_t)strtoul(np->s.c_str(), nullptr, 10);
   if (ic->a.size() < n_public + 1 || pub.a.size() < n_public) return vfail(-2, "public inputs / IC length mismatch");
+  for (size_t i = 0; i < n_public; i++)
+    if (pub.a[i].t != JVal::STR) return vfail(-2, "public signals must be decimal strings");
   // cpub = IC₀ + Σ pubᵢ·ICᵢ₊₁  (projective host arithmetic through the FFI functions)
   bn254_projective_t cpub, t;
   {

@@ -293,3 +293,42 @@ def test_sparse_b_subset_equals_dense(gpu, O, S, monkeypatch):
     assert out["dense"][:2] == out["sparse"][:2]
     proof, public = O.groth16_prove(zkey, wtns, r, s)
     assert json.loads(out["sparse"][0]) == proof and json.loads(out["sparse"][1]) == public
+
+
+def test_mutated_witness_files_never_crash(gpu, cm):
+    """400 random mutations of the golden .wtns (truncations, bit flips, overwritten length fields, insertions) through the
+    prover: each either proves (the mutation hit value bytes) or is refused with an error — none takes the process down or
+    wedges the cache entry (the golden proof still comes out afterwards)."""
+    import random
+    g = load_golden("groth16.json")
+    zkey, wtns = base64.b64decode(g["zkey"]), base64.b64decode(g["wtns"])
+    cm.load("fuzz", zkey)
+    rng = random.Random(7)
+    proved = refused = 0
+    for _ in range(400):
+        b = bytearray(wtns)
+        k = rng.randrange(5)
+        if k == 0:
+            del b[rng.randrange(len(b)):]
+        elif k == 1:
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif k == 2:
+            i = rng.randrange(0, len(b) - 8)
+            b[i:i + 8] = rng.choice([b"\xff" * 8, b"\0" * 8, (2 ** 63).to_bytes(8, "little"), (len(b) * 3).to_bytes(8, "little")])
+        elif k == 3:
+            i = rng.randrange(len(b))
+            b[i:i] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40)))
+        else:
+            i = rng.randrange(0, len(b) - 4)
+            b[i:i + 4] = rng.choice([b"\xff\xff\xff\xff", b"\0\0\0\0", b"\x01\0\0\x80"])
+        try:
+            cm.prove_mem("fuzz", bytes(b), 3, 5)
+            proved += 1
+        except gpu.ProverError:
+            refused += 1
+    assert proved + refused == 400 and refused > 100
+    c = g["cases"][0]
+    pj, qj, _ = cm.prove_mem("fuzz", wtns, unhex_int(c["r"]), unhex_int(c["s"]))
+    assert json.loads(pj) == c["proof"] and json.loads(qj) == c["public"]
+    cm.evict("fuzz")

@@ -108,6 +108,33 @@ def test_verify_reports_malformed_input(K, S):
         K.groth16_verify_json(pj, "[]", vkj)
 
 
+def test_verify_refuses_text_that_is_not_json(K, S):
+    """the reference parses with serde_json into Vec<String> / Vec<Vec<String>>: text after the document, bare garbage tokens, raw
+    control or non-ASCII bytes inside strings, bad escapes and numbers where strings belong are errors there — and here
+    (scratch/fuzz_containers.py found the first four accepted when they hit a field the verifier does not read)"""
+    g, vkj = _golden_vk_json(S)
+    c = g["cases"][0]
+    pj, qj = json.dumps(c["proof"]), json.dumps(c["public"])
+    assert K.groth16_verify_json(pj, qj, vkj)
+    assert K.groth16_verify_json(pj + " \n", qj, vkj)                                     # trailing white space is fine
+    third = pj.index('"1"')                                                               # a third (projective) coordinate: never read
+    cases = [
+        (pj + "x", qj, vkj), (pj, qj + "]", vkj), (pj, qj, vkj + "{}"),                    # text after the document
+        (pj[:third] + "\xff\xff" + pj[third + 3:], qj, vkj),                               # a bare token that is no number / literal
+        (pj[:third] + "1e" + pj[third + 3:], qj, vkj), (pj[:third] + "-" + pj[third + 3:], qj, vkj), (pj[:third] + "nul" + pj[third + 3:], qj, vkj),
+        (pj[:third] + '"1\x08"' + pj[third + 3:], qj, vkj),                                # raw control character in a string
+        (pj[:third] + '"1\xc3\xa9"' + pj[third + 3:], qj, vkj),                            # non-ASCII bytes in a string
+        (pj[:third] + '"1\\q"' + pj[third + 3:], qj, vkj), (pj[:third] + '"\\u12g4"' + pj[third + 3:], qj, vkj),   # bad escapes
+        (pj[:third] + "1" + pj[third + 3:], qj, vkj),                                       # a number where a string belongs
+        (pj, "[" + c["public"][0] + "]", vkj),                                             # public signal as a bare number
+    ]
+    for k, (a, b, v) in enumerate(cases):
+        with pytest.raises(K.ProverError, match="malformed|bad point|decimal strings"):
+            K.groth16_verify_json(a, b, v)
+    # valid JSON the verifier must keep accepting: escapes and literals in fields it does not read
+    assert K.groth16_verify_json(pj[:-1] + ', "note": "a\\n\\u00e9\\"b", "flag": true, "n": -1.5e3, "z": null}', qj, vkj)
+
+
 def test_verify_rejects_non_canonical_and_off_curve_input(K, S):
     """What a verifier facing an untrusted prover must refuse (the reference deserialises anything, src/conversions.rs:58-96):
     aliased public signals (x + r), coordinates >= q, points off the curve, G2 points outside the r-torsion, and JSON
