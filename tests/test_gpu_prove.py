@@ -332,3 +332,47 @@ def test_mutated_witness_files_never_crash(gpu, cm):
     pj, qj, _ = cm.prove_mem("fuzz", wtns, unhex_int(c["r"]), unhex_int(c["s"]))
     assert json.loads(pj) == c["proof"] and json.loads(qj) == c["public"]
     cm.evict("fuzz")
+
+
+def test_mutated_zkey_files_never_crash(gpu):
+    """200 random mutations of the golden .zkey through cache build + prove on the device: a mutated key is refused, or builds
+    and proves (bit flips inside point or coefficient bytes give a different, meaningless proof) — no crash, no hang, and the
+    untouched key still yields the golden proof afterwards."""
+    import random
+    K = gpu
+    g = load_golden("groth16.json")
+    zkey, wtns = base64.b64decode(g["zkey"]), base64.b64decode(g["wtns"])
+    rng = random.Random(11)
+    built = refused = 0
+    c = K.CacheManager()
+    for it in range(200):
+        b = bytearray(zkey)
+        k = rng.randrange(5)
+        if k == 0:
+            del b[rng.randrange(len(b)):]
+        elif k == 1:
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif k == 2:
+            i = rng.randrange(0, len(b) - 8)
+            b[i:i + 8] = rng.choice([b"\xff" * 8, b"\0" * 8, (2 ** 63).to_bytes(8, "little"), (len(b) * 3).to_bytes(8, "little")])
+        elif k == 3:
+            i = rng.randrange(len(b))
+            b[i:i] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40)))
+        else:
+            i = rng.randrange(0, len(b) - 4)
+            b[i:i + 4] = rng.choice([b"\xff\xff\xff\xff", b"\0\0\0\0", b"\x01\0\0\x80", b"\x09\0\0\0"])
+        key = f"m{it}"
+        try:
+            c.load(key, bytes(b))
+            c.prove_mem(key, wtns, 3, 5)
+            built += 1
+        except K.ProverError:
+            refused += 1
+        c.evict(key)
+    assert built + refused == 200 and refused > 20 and built > 20, (built, refused)
+    c.load("ok", zkey)
+    case = g["cases"][0]
+    pj, qj, _ = c.prove_mem("ok", wtns, unhex_int(case["r"]), unhex_int(case["s"]))
+    assert json.loads(pj) == case["proof"] and json.loads(qj) == case["public"]
+    c.close()
