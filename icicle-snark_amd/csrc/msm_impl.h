@@ -546,6 +546,9 @@ ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu, int pref = 
   while (k < 4 && (uint64_t)g.Wb * (g.NBb >> k) / rb_max > 128) k++; // ≤ 128 partial sums per kind for the host tail
   // (8 buckets per thread — twice the threads — was measured for both curves: stand-in circuits 6.1 → 5.9 ms, benchmark/1600k
   //  16.3 → 16.7 ms: the reductions are latency chains that run beside the accumulations, whose SIMDs they would take)
+  // the prover's LAST MSM (pref == 1: H) reduces on an otherwise idle GPU and its reduction is the tail of the prove: 8 buckets per thread
+  // (a chain of 16 + 16 + 10 instead of 32 + 16 + 8 additions on twice the threads): −0.1 ms at 1.6 M constraints; 4 per thread: none
+  if (pref == 1 && k > 3) k = 3;
   r.k_log = k < lnb ? k : lnb;
   for (;; r.k_log++) {
     r.tpw = g.NBb >> r.k_log;                            // reduce threads per (pseudo-)window
