@@ -1357,7 +1357,9 @@ __attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheMa
   th.join();
   if (rc) return rc;
   if (bl_rc) return fail(bl_rc, "no entropy source for the blinding scalars"); // (the message was set on the helper thread)
+  const auto ta = std::chrono::steady_clock::now();
   rc = assemble_impl(z, wtns, wtns_len, pts, bl, proof_json, proof_cap, public_json, public_cap, &et);
+  if (getenv("ICICLE_SNARK_TRACE_HOST")) fprintf(stderr, "[host] assemble %8.1f us (after %8.1f us)\n", ms_since(ta) * 1e3, std::chrono::duration<double, std::micro>(ta - t0).count());
   if (tm) tm->total_ms = ms_since(t0);
   return rc;
 }
