@@ -195,7 +195,9 @@ void bn254_g2_generator(bn254_g2_projective_t* out);
 bool bn254_g2_is_on_curve(const bn254_g2_projective_t* p);
 void bn254_g2_base_field_from_u32(uint32_t val, bn254_fq2_t* result);
 
-/* ---- pairing (host): icicle/src/pairing.cpp:11-26, models/bn.h; Rust: icicle-core/src/pairing/mod.rs:38-43 ---- */
+/* ---- pairing (host): icicle/src/pairing.cpp:11-26, models/bn.h; Rust: icicle-core/src/pairing/mod.rs:38-43 ----
+ * The reference's C++ symbol returns void (pairing.cpp:22-26) while its Rust declaration reads an eIcicleError from it
+ * (pairing/mod.rs:38-43); this one returns the code the Rust side expects (always ICICLE_SUCCESS for non-null arguments). */
 eIcicleError bn254_pairing(const bn254_affine_t* p, const bn254_g2_affine_t* q, bn254_fq12_t* out);
 /* TargetField host FFI: icicle/src/fields/ffi_extern_pairing_extension.cpp:6-52 (Rust: icicle-bn254/src/pairing/mod.rs:16) */
 void bn254_pairing_target_field_add(const bn254_fq12_t* a, const bn254_fq12_t* b, bn254_fq12_t* result);
