@@ -738,6 +738,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
   hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3;
   double h2d_host_ms = 0;
+  bool pinned_src = false;
   if (wtns) {
     Wtns w;
     if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
@@ -751,10 +752,16 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
     // of this call, the MSM tails and the runtime's own compete for the container's CPU quota)
     const hipStream_t lanes[6] = {z->s_qap, z->s_g2, z->s_g3, z->s_g1, z->s_g4, z->s_g5};
     static const int n_lanes = getenv("ICICLE_SNARK_UPLOAD_LANES") ? std::max(1, std::min(6, atoi(getenv("ICICLE_SNARK_UPLOAD_LANES")))) : 3;
-    if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, n_lanes)) return rc;
+    if (is_pinned_host(w.values)) {
+      // the caller's buffer is pinned (hipHostMalloc / hipHostRegister): one DMA straight from it on g1, in stream order with
+      // everything that waits for ev_witness — no staging copy, no host wait (51 MB: 0.9 instead of 1.35 ms)
+      P_HIP(hipEventRecord(z->ev[0], g1));
+      P_HIP(hipMemcpyAsync(z->d_witness, w.values, (size_t)nv * 32, hipMemcpyHostToDevice, g1));
+      pinned_src = true;
+    } else if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, n_lanes)) return rc;
     h2d_host_ms = ms_since(tu);
   }
-  P_HIP(hipEventRecord(z->ev[0], g1));
+  if (!pinned_src) P_HIP(hipEventRecord(z->ev[0], g1));
   z->witness_resident = true;
   P_HIP(hipEventRecord(z->ev_witness, g1));
   P_HIP(hipEventRecord(z->ev[1], g1));

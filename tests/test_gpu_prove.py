@@ -376,3 +376,31 @@ def test_mutated_zkey_files_never_crash(gpu):
     pj, qj, _ = c.prove_mem("ok", wtns, unhex_int(case["r"]), unhex_int(case["s"]))
     assert json.loads(pj) == case["proof"] and json.loads(qj) == case["public"]
     c.close()
+
+
+def test_pinned_witness_buffer_takes_the_direct_dma_path(gpu, cm):
+    """a witness handed over in pinned host memory (hipHostMalloc) is copied by one DMA in stream order instead of through the
+    staging workers: same proof as from a pageable buffer"""
+    import ctypes as C
+    g = load_golden("groth16.json")
+    zkey, wtns = base64.b64decode(g["zkey"]), base64.b64decode(g["wtns"])
+    cm.load("pin", zkey)
+    c = g["cases"][0]
+    r, s = unhex_int(c["r"]), unhex_int(c["s"])
+    want = cm.prove_mem("pin", wtns, r, s)[:2]
+    hip = C.CDLL("libamdhip64.so")
+    p = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(p), C.c_size_t(len(wtns)), 0) == 0
+    try:
+        C.memmove(p, wtns, len(wtns))
+        pinned = (C.c_char * len(wtns)).from_address(p.value)
+        pj, qj = C.create_string_buffer(1 << 14), C.create_string_buffer(1 << 16)
+        for _ in range(3):
+            rc = gpu.lib().groth16_prove_mem(cm._h, b"pin", pinned, C.c_size_t(len(wtns)), int(r).to_bytes(32, "little"), int(s).to_bytes(32, "little"),
+                                             pj, C.c_size_t(len(pj)), qj, C.c_size_t(len(qj)), None)
+            assert rc == 0
+            assert (pj.value.decode(), qj.value.decode()) == want
+    finally:
+        hip.hipHostFree(p)
+    assert json.loads(want[0]) == c["proof"]
+    cm.evict("pin")
