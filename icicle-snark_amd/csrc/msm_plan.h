@@ -66,7 +66,7 @@ struct SortPlan {
 };
 
 // geometry for a length-L MSM (c_cfg > 0 forces the window size); tab != 0 asks for the table mode (falls back to
-// the classic layout when the entry encoding would not fit)
+// the classic layout when the entry encoding would not fit; tab > 1 asks for the table mode with digits of `tab` bits)
 // `bits` (MSMConfig.bitsize, msm.h:32-34): every scalar is < 2^bits — W = ⌊bits / c⌋ + 1 windows instead of ⌊254 / c⌋ + 1
 // (0 = the scalar field's 254); `pf`: precompute factor of the base array (classic layout only).
 MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab = 0, int bits = 0, int pf = 1);

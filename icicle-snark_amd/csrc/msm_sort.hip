@@ -803,6 +803,8 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab, int bits, int pf)
       // same number of digits with a narrower digit: fewer buckets, and the top digit keeps enough bits to spread over
       // many buckets (c = 18 leaves it 2 bits — three buckets then hold a quarter of all entries each; c = 17 leaves 16)
       while (ct > c + 1 && 254 / (ct - 1) + 1 == 254 / ct + 1) ct--;
+      // tab > 1: table mode with THIS digit width (a base subset that keeps the geometry of the full set, prover.cpp: sparse B)
+      if (tab > 1 && tab <= 20 && tab_low_bits(tab, ib, 254 / tab + 1) >= 0) ct = tab;
     }
     if (ct) c = ct;
     else tab = 0;

@@ -426,7 +426,11 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     // sparse B (see ZKeyCache): keep only the wires of this rank's range whose B1 or B2 base is not the identity
     const double max_density = getenv("ICICLE_SNARK_SPARSE_B") ? atof(getenv("ICICLE_SNARK_SPARSE_B")) : 0.9;
     const uint32_t L = z->B1.len();
-    if (max_density > 0 && L >= 2) {
+    // Circuits whose witness MSMs start right after the witness sort (domain up to 2^19: `early` in commitments_impl) keep the
+    // dense arrays: there the second sort is not hidden behind the QAP front end but sits at the head of the G2 chain, the
+    // longest of the prove (stand-in at 0.4 M constraints: 4.9 ms with the subset, 3.9 ms without)
+    const bool starts_early = z->A.len() <= (1u << 19) && n <= (1u << 19) && !getenv("ICICLE_SNARK_SPARSE_B");
+    if (max_density > 0 && L >= 2 && !starts_early) {
       uint8_t* d_flags = nullptr;
       P_HIP(hipMalloc((void**)&d_flags, L));
       FreeTmp free_flags{d_flags};
@@ -469,7 +473,10 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
     z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
     z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
-    z->geom_b = z->sparse_b ? msm_geometry(z->nb, 0, tables ? 1 : 0) : z->geom_w;
+    // the B subset keeps the digit width of the full witness set: fewer buckets would mean longer single-thread chains for the
+    // 0/1-heavy witnesses this path exists for (404 k wires, 219 k with a B base: c = 17 instead of 19 cost 1.2 ms of a 4 ms prove)
+    z->geom_b = z->sparse_b ? msm_geometry(z->nb, 0, tables ? z->geom_w.c : 0) : z->geom_w;
+    if (z->sparse_b && tables && z->geom_b.c != z->geom_w.c) z->geom_b = msm_geometry(z->nb, 0, 1);
     if (tables) {
       // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
       // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
@@ -483,7 +490,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
         tables = false;
         z->geom_w = msm_geometry(z->A.len(), 0, 0);
         z->geom_h = msm_geometry(z->H.len(), 0, 0);
-        z->geom_b = z->sparse_b ? msm_geometry(z->nb, 0, 0) : z->geom_w;
+        z->geom_b = z->sparse_b ? msm_geometry(z->nb, z->geom_w.c, 0) : z->geom_w;
       }
     }
     struct Job { Shard* sh; bool g2; const MsmGeom* g; };
@@ -798,7 +805,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
     hipStream_t gb = z->s_g4;
     P_HIP(hipStreamWaitEvent(gb, z->ev_witness, 0));
     P_HIP(qap_gather_idx(z->d_witness + wlo, z->d_bidx, z->d_wb, z->nb, 32, gb));
-    P_ICICLE(msm_sort_run(z->d_wb, z->nb, 0, 0, 0, gb, &plan_b, z->geom_b.tab));
+    P_ICICLE(msm_sort_run(z->d_wb, z->nb, z->geom_b.tab ? 0 : z->geom_b.c, 0, 0, gb, &plan_b, z->geom_b.tab ? z->geom_b.c : 0));
     if (plan_b.g.tab != z->geom_b.tab || plan_b.g.c != z->geom_b.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the B sort");
     P_HIP(hipEventRecord(z->ev_sort_b, gb));
     P_HIP(hipStreamWaitEvent(g2, z->ev_sort_b, 0));
