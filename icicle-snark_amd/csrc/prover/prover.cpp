@@ -162,6 +162,10 @@ int parse_wtns(const uint8_t* data, size_t len, Wtns& w)
   return 0;
 }
 
+// circuits with a domain (and witness) of up to this many elements start their witness MSMs right after the witness sort instead
+// of behind the QAP front end (ICICLE_SNARK_EARLY overrides it per process)
+// (2^18 is 2-3 % better for the benchmark chain at 300-500 k constraints, 2^19 is 5 % better for the witness-light stand-in at 400 k)
+constexpr uint32_t EARLY_MAX_DEFAULT = 1u << 19;
 constexpr size_t PARTIALS_STRIDE = 64 * 16 * 256; // ≥ W·bpw·sizeof(XYZZ) for any geometry (W ≤ 64, bpw ≤ 16, G2 256 B)
 
 struct Shard {
@@ -182,9 +186,9 @@ struct ZKeyCache {
   MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM, fixed at cache build
   // Sparse B: a wire that never occurs on the B side of a constraint has the identity as its B1 and B2 base (snarkjs writes
   // all-zero bytes).  One thread accumulates one bucket, so an identity base skipped inside the shared witness sort saves
-  // nothing (the other lanes of the wave still add).  When at most ICICLE_SNARK_SPARSE_B (default 0.9; 0 = off) of this
-  // rank's wires have a B base, B1/B2 hold only those nb bases (d_bidx = their wire numbers relative to A.lo), and the two B
-  // MSMs run on their own digit sort of the gathered scalars d_wb (geometry geom_b).
+  // nothing (the other lanes of the wave still add).  Opt-in: with ICICLE_SNARK_SPARSE_B=<d> set and at most the fraction d of
+  // this rank's wires having a B base, B1/B2 hold only those nb bases (d_bidx = their wire numbers relative to A.lo), and the two
+  // B MSMs run on their own digit sort of the gathered scalars d_wb (geometry geom_b: the digit width of the full set).
   bool sparse_b = false;
   uint32_t nb = 0;
   uint32_t* d_bidx = nullptr;
@@ -423,14 +427,13 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   }
   lap("device CSR build");
   {
-    // sparse B (see ZKeyCache): keep only the wires of this rank's range whose B1 or B2 base is not the identity
-    const double max_density = getenv("ICICLE_SNARK_SPARSE_B") ? atof(getenv("ICICLE_SNARK_SPARSE_B")) : 0.9;
+    // sparse B (see ZKeyCache): keep only the wires of this rank's range whose B1 or B2 base is not the identity.  Opt-in
+    // (ICICLE_SNARK_SPARSE_B=<largest density>): measured on the stand-in circuits it pays at 1.4 M constraints (8.7 → 8.0 ms) and
+    // saves table memory, but costs 0.2–0.8 ms between 0.1 M and 1.0 M — the second digit sort heads the G2 chain, the longest of
+    // a witness-light prove
+    const double max_density = getenv("ICICLE_SNARK_SPARSE_B") ? atof(getenv("ICICLE_SNARK_SPARSE_B")) : 0.0;
     const uint32_t L = z->B1.len();
-    // Circuits whose witness MSMs start right after the witness sort (domain up to 2^19: `early` in commitments_impl) keep the
-    // dense arrays: there the second sort is not hidden behind the QAP front end but sits at the head of the G2 chain, the
-    // longest of the prove (stand-in at 0.4 M constraints: 4.9 ms with the subset, 3.9 ms without)
-    const bool starts_early = z->A.len() <= (1u << 19) && n <= (1u << 19) && !getenv("ICICLE_SNARK_SPARSE_B");
-    if (max_density > 0 && L >= 2 && !starts_early) {
+    if (max_density > 0 && L >= 2) {
       uint8_t* d_flags = nullptr;
       P_HIP(hipMalloc((void**)&d_flags, L));
       FreeTmp free_flags{d_flags};
@@ -881,7 +884,7 @@ int commitments_impl(Groth16CacheManager* cm, const char* key, const void* wtns,
   // after the witness sort instead of waiting for the QAP (200 k constraints: 3.71 → 3.51 ms, 400 k: 6.69 → 6.24 ms; the QAP
   // itself slows down — 1.1 → 3.9 ms at 400 k — which is why the large ones are held back: 800 k: 9.87 → 10.27 ms).
   // ICICLE_SNARK_EARLY=<max scalars> moves the threshold (0 = never).
-  const uint32_t early_max = early_cfg >= 0 ? (uint32_t)early_cfg : (1u << 19);
+  const uint32_t early_max = early_cfg >= 0 ? (uint32_t)early_cfg : EARLY_MAX_DEFAULT;
   const bool early = wlen <= early_max && n <= early_max; // shards of a large circuit keep the full-size inverse transform: neutral there
   if (!early) P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
 
