@@ -524,7 +524,7 @@ class Timings(C.Structure):
 
 class CircuitInfo(C.Structure):
     _fields_ = [("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32), ("n_coef", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("b_bases", C.c_uint32), ("reserved", C.c_uint32)]
+                ("device_bytes", C.c_uint64), ("b_bases", C.c_uint32), ("shards", C.c_uint32)]
 
 
 class ProverError(RuntimeError):
@@ -562,6 +562,16 @@ class CacheManager:
         else:
             p = (C.c_char * len(zkey)).from_buffer(zkey)   # bytearray / writable memoryview
         _pcheck(lib().groth16_cache_load(self._h, key.encode(), p, C.c_size_t(len(zkey)), device_id, shard_rank, shard_count), "cache_load")
+
+    def load_devices(self, key: str, zkey: bytes, device_ids):
+        """one key over a GROUP of devices in this process (what groth16_prove builds for "HIP:0-7"): shard k lives on
+        device_ids[k]; a device may be named several times (several shards on one GPU)."""
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        p = zkey.ctypes.data_as(C.c_void_p) if isinstance(zkey, np.ndarray) else C.c_char_p(zkey) if isinstance(zkey, bytes) else (C.c_char * len(zkey)).from_buffer(zkey)
+        _pcheck(lib().groth16_cache_load_devices(self._h, key.encode(), p, C.c_size_t(len(zkey)), ids, len(device_ids)), "cache_load_devices")
+
+    def set_budget(self, bytes_per_device: int):
+        lib().groth16_cache_set_budget(self._h, C.c_uint64(bytes_per_device))
 
     def load_file(self, key: str, path: str, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1):
         _pcheck(lib().groth16_cache_load_file(self._h, key.encode(), path.encode(), device_id, shard_rank, shard_count), "cache_load_file")
@@ -631,6 +641,10 @@ class CacheManager:
         _pcheck(lib().groth16_dist_stage2(self._h, key.encode(), C.byref(send), C.byref(recv)), "dist_stage2")
         return send.value, recv.value
 
+    def dist_exchange_done(self, key: str):
+        """the caller confirms that exchange 2 delivered: the next commitments(key, None) finishes from those rows"""
+        _pcheck(lib().groth16_dist_exchange_done(self._h, key.encode()), "dist_exchange_done")
+
     def prove_files(self, witness: str, zkey: str, proof: str, public: str, device: str = "HIP"):
         """groth16_prove — src/lib.rs:33-61: files in, files out (the reference's timed region)"""
         return self.prove(witness, zkey, proof, public, device)
@@ -649,9 +663,19 @@ PROVER_SYMBOLS = """
 groth16_cache_manager_new groth16_cache_manager_free groth16_prove groth16_cache_load groth16_cache_load_file
 groth16_cache_contains groth16_cache_evict groth16_commitments groth16_sum_commitments groth16_assemble_proof
 groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error groth16_last_timings
-groth16_dist_supported groth16_dist_stage1 groth16_dist_stage2 groth16_upload_witness_slice groth16_witness_ready
+groth16_dist_supported groth16_dist_stage1 groth16_dist_stage2 groth16_dist_exchange_done groth16_upload_witness_slice
+groth16_witness_ready groth16_cache_load_devices groth16_parse_device groth16_cache_set_budget groth16_cache_info_sized
 groth16_verify groth16_verify_json groth16_verify_last_error
 """.split()
+
+
+def parse_device(device: str, cap: int = 64):
+    """device string of groth16_prove → list of device ids ("HIP:0-7" → [0, …, 7]); raises ProverError for a bad string"""
+    ids = (C.c_int * cap)()
+    n = lib().groth16_parse_device(device.encode(), ids, cap)
+    if n < 0:
+        _pcheck(n, "parse_device")
+    return [ids[i] for i in range(min(n, cap))]
 
 
 def pairing(p_aff: np.ndarray, q_aff: np.ndarray) -> np.ndarray:

@@ -4,8 +4,12 @@
 // this is an all-gather of raw bytes + local adds, not an all-reduce).  Built as a separate small DSO
 // (libicicle_snark_rccl.so) so that the single-GPU library carries no RCCL dependency.
 //
-// Process model: one process per GPU (torch.distributed / torchrun provides rank, world size and the
-// rendezvous used to broadcast the ncclUniqueId); the collective itself runs on this library's HIP runtime.
+// Two process models:
+//  * one process per GPU (torch.distributed / torchrun provides rank, world size and the rendezvous used to broadcast the
+//    ncclUniqueId): icicle_snark_rccl_init + the host-synchronous calls below, driven from parallel.py;
+//  * ONE process that drives a group of GPUs (groth16_prove with the device string "HIP:0-7", prover/multi.cpp):
+//    icicle_snark_rccl_init_all (ncclCommInitAll) + the *_on calls, which only ENQUEUE the collective on the caller's
+//    stream — the prover's own — so that it is ordered with the kernels before and after it without any host wait.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
@@ -91,11 +95,12 @@ API int icicle_snark_rccl_allgather(void* comm, const void* in, size_t bytes, vo
 // this rank lands at the same offset of `d_recv` (both buffers are [row][peer][chunk]).  One grouped ncclSend / ncclRecv
 // batch — point-to-point over the xGMI links, which is what an all-to-all is on this fabric; 3·(n/G)·32·(G−1)/G bytes per
 // rank and exchange (22 MB at n = 2^21, G = 8).
-API int icicle_snark_rccl_alltoall_rows(void* comm, const void* d_send, void* d_recv, int rows, size_t row_bytes, size_t chunk_bytes)
+API int icicle_snark_rccl_alltoall_rows_on(void* comm, const void* d_send, void* d_recv, int rows, size_t row_bytes, size_t chunk_bytes, void* stream)
 {
   Comm* c = (Comm*)comm;
   if (!c || !d_send || !d_recv || rows < 1) return fail("alltoall: bad arguments", -1);
   if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice", -1);
+  hipStream_t st = (hipStream_t)stream;
   int me = 0;
   ncclResult_t r = ncclCommUserRank(c->comm, &me);
   if (r != ncclSuccess) return fail("ncclCommUserRank", (int)r);
@@ -105,15 +110,22 @@ API int icicle_snark_rccl_alltoall_rows(void* comm, const void* d_send, void* d_
     for (int p = 0; p < c->world && r == ncclSuccess; p++) {
       const size_t off = (size_t)q * row_bytes + (size_t)p * chunk_bytes;
       if (p == me) {
-        if (hipMemcpyAsync((uint8_t*)d_recv + off, (const uint8_t*)d_send + off, chunk_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) r = ncclSystemError;
+        if (hipMemcpyAsync((uint8_t*)d_recv + off, (const uint8_t*)d_send + off, chunk_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) r = ncclSystemError;
         continue;
       }
-      r = ncclSend((const uint8_t*)d_send + off, chunk_bytes, ncclUint8, p, c->comm, c->stream);
-      if (r == ncclSuccess) r = ncclRecv((uint8_t*)d_recv + off, chunk_bytes, ncclUint8, p, c->comm, c->stream);
+      r = ncclSend((const uint8_t*)d_send + off, chunk_bytes, ncclUint8, p, c->comm, st);
+      if (r == ncclSuccess) r = ncclRecv((uint8_t*)d_recv + off, chunk_bytes, ncclUint8, p, c->comm, st);
     }
   const ncclResult_t r2 = ncclGroupEnd();
   if (r != ncclSuccess) return fail("ncclSend/ncclRecv", (int)r);
   if (r2 != ncclSuccess) return fail("ncclGroupEnd", (int)r2);
+  return 0;
+}
+API int icicle_snark_rccl_alltoall_rows(void* comm, const void* d_send, void* d_recv, int rows, size_t row_bytes, size_t chunk_bytes)
+{
+  Comm* c = (Comm*)comm;
+  if (!c) return fail("alltoall: bad arguments", -1);
+  if (int rc = icicle_snark_rccl_alltoall_rows_on(comm, d_send, d_recv, rows, row_bytes, chunk_bytes, c->stream)) return rc;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("sync", -1);
   return 0;
 }
@@ -121,7 +133,7 @@ API int icicle_snark_rccl_alltoall_rows(void* comm, const void* d_send, void* d_
 // in-place all-gather of a DEVICE buffer of world × slice_bytes bytes: this rank's slice sits at d_buf + rank·slice_bytes
 // (the witness of a sharded prove: every rank uploads 1/world of it over PCIe and the rest arrives over xGMI —
 // include/groth16_prover.h: groth16_upload_witness_slice)
-API int icicle_snark_rccl_allgather_device(void* comm, void* d_buf, size_t slice_bytes)
+API int icicle_snark_rccl_allgather_device_on(void* comm, void* d_buf, size_t slice_bytes, void* stream)
 {
   Comm* c = (Comm*)comm;
   if (!c || !d_buf || slice_bytes == 0) return fail("allgather_device: bad arguments", -1);
@@ -129,9 +141,34 @@ API int icicle_snark_rccl_allgather_device(void* comm, void* d_buf, size_t slice
   int me = 0;
   ncclResult_t r = ncclCommUserRank(c->comm, &me);
   if (r != ncclSuccess) return fail("ncclCommUserRank", (int)r);
-  r = ncclAllGather((const uint8_t*)d_buf + (size_t)me * slice_bytes, d_buf, slice_bytes, ncclUint8, c->comm, c->stream);
+  r = ncclAllGather((const uint8_t*)d_buf + (size_t)me * slice_bytes, d_buf, slice_bytes, ncclUint8, c->comm, (hipStream_t)stream);
   if (r != ncclSuccess) return fail("ncclAllGather (device, in place)", (int)r);
+  return 0;
+}
+API int icicle_snark_rccl_allgather_device(void* comm, void* d_buf, size_t slice_bytes)
+{
+  Comm* c = (Comm*)comm;
+  if (!c) return fail("allgather_device: bad arguments", -1);
+  if (int rc = icicle_snark_rccl_allgather_device_on(comm, d_buf, slice_bytes, c->stream)) return rc;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("sync", -1);
+  return 0;
+}
+
+// One process, n devices: ncclCommInitAll.  comms_out[k] is rank k's communicator (on device devs[k]) for the *_on calls; it
+// owns no stream and no staging buffers.  The devices must be distinct (RCCL refuses duplicates).
+API int icicle_snark_rccl_init_all(int n, const int* devs, void** comms_out)
+{
+  if (n < 1 || n > 64 || !devs || !comms_out) return fail("init_all: bad arguments", -1);
+  ncclComm_t cs[64];
+  ncclResult_t r = ncclCommInitAll(cs, n, devs);
+  if (r != ncclSuccess) return fail("ncclCommInitAll", (int)r);
+  for (int k = 0; k < n; k++) {
+    Comm* c = new Comm();
+    c->comm = cs[k];
+    c->world = n;
+    c->device = devs[k];
+    comms_out[k] = c;
+  }
   return 0;
 }
 

@@ -52,8 +52,9 @@ constexpr int STAGED_LANES = 8;
 hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes = nullptr, int n_lanes = 0, bool own_temp_streams = false);
 // the calling thread's next staged copies read sources inside [base, base + len) from file descriptor fd (fd < 0: off)
 void staged_copy_file_hint(const void* base, size_t len, int fd);
+void staged_copy_file_hint_get(const void** base, size_t* len, int* fd); // the calling thread's hint (to hand it to worker threads)
 // true when hipMemcpyAsync can DMA straight from/to `host_ptr` (pinned / registered memory)
-bool is_pinned_host(const void* host_ptr);
+bool is_pinned_host(const void* host_ptr, int device_id = -1);
 // copies of at least this many bytes from/to pageable memory take the staged path
 constexpr size_t STAGED_MIN_BYTES = 4u << 20;
 

@@ -892,18 +892,31 @@ struct TailRing {
   std::mutex mu;
   TailSlot* slots = nullptr;
   hipEvent_t ev[TAIL_SLOTS] = {};
-  unsigned char state[TAIL_SLOTS] = {}; // 0 never used / known free, 1 acquired (no event yet), 2 event recorded
+  unsigned char state[TAIL_SLOTS] = {}; // 0 never used / known free, 1 acquired (no event yet), 2 event recorded, 3 event lost and stream not drained
   unsigned next = 0;
   bool failed = false;
 };
-inline TailRing& tail_ring()
+// one ring per device: a slot's event is recorded on the stream of the MSM that uses it, and an event only records on a
+// stream of the device it was created on
+constexpr int TAIL_RING_DEVICES = 16;
+inline TailRing& tail_ring(int dev)
 {
-  static TailRing r;
-  return r;
+  static TailRing r[TAIL_RING_DEVICES];
+  return r[dev >= 0 && dev < TAIL_RING_DEVICES ? dev : 0];
+}
+inline TailRing& tail_ring_of(const TailSlot* t)
+{
+  for (int d = 0; d < TAIL_RING_DEVICES; d++) {
+    TailRing& r = tail_ring(d);
+    if (r.slots && t >= r.slots && t < r.slots + TAIL_SLOTS) return r;
+  }
+  return tail_ring(0);
 }
 inline TailSlot* tail_slot_acquire()
 {
-  TailRing& r = tail_ring();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  TailRing& r = tail_ring(dev);
   std::lock_guard<std::mutex> lk(r.mu);
   if (r.failed) return nullptr;
   if (!r.slots) {
@@ -921,7 +934,7 @@ inline TailSlot* tail_slot_acquire()
   }
   for (int k = 0; k < TAIL_SLOTS; k++) {
     const unsigned i = (r.next + k) % TAIL_SLOTS;
-    if (r.state[i] == 1) continue;
+    if (r.state[i] == 1 || r.state[i] == 3) continue;
     if (r.state[i] == 2 && hipEventQuery(r.ev[i]) != hipSuccess) continue; // still in flight
     r.state[i] = 1;
     r.next = i + 1;
@@ -929,13 +942,20 @@ inline TailSlot* tail_slot_acquire()
   }
   return nullptr;
 }
-// all stream work that uses the slot has been enqueued on s
+// all stream work that uses the slot has been enqueued on s.  If the event cannot be recorded the slot's work may still
+// be in flight with nothing to poll: the stream is drained before the slot is handed out again (state 3 = lost until then).
 inline void tail_slot_commit(TailSlot* t, hipStream_t s)
 {
-  TailRing& r = tail_ring();
+  TailRing& r = tail_ring_of(t);
   std::lock_guard<std::mutex> lk(r.mu);
   const size_t i = (size_t)(t - r.slots);
-  r.state[i] = hipEventRecord(r.ev[i], s) == hipSuccess ? 2 : 0;
+  if (hipEventRecord(r.ev[i], s) == hipSuccess) {
+    r.state[i] = 2;
+    return;
+  }
+  (void)hipGetLastError();
+  r.state[i] = 3;
+  if (hipStreamSynchronize(s) == hipSuccess) r.state[i] = 0;
 }
 template <class C>
 void host_tail_callback(void* ud)

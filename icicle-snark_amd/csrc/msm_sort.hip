@@ -23,19 +23,32 @@ using namespace bn254;
 
 namespace isnark {
 
-static MsmProfile g_msm_ring[MSM_PROFILE_RING];
-static uint64_t g_msm_seq = 0;
+// one ring per device: the events are recorded on streams of the device whose thread issues the MSM, and an event only
+// records on a stream of the device it was created on (a process that drives several GPUs has one prover thread per device)
+constexpr int MSM_PROFILE_DEVICES = 16;
+struct MsmProfileRing {
+  MsmProfile slots[MSM_PROFILE_RING];
+  uint64_t seq = 0;
+};
+static MsmProfileRing g_msm_rings[MSM_PROFILE_DEVICES];
 static std::mutex g_msm_prof_mu;
+static MsmProfileRing& msm_ring_of_active_device()
+{
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MSM_PROFILE_DEVICES) d = 0;
+  return g_msm_rings[d];
+}
 
 MsmProfile* msm_profile_next()
 {
   std::lock_guard<std::mutex> lk(g_msm_prof_mu);
-  MsmProfile* p = &g_msm_ring[g_msm_seq % MSM_PROFILE_RING];
+  MsmProfileRing& r = msm_ring_of_active_device();
+  MsmProfile* p = &r.slots[r.seq % MSM_PROFILE_RING];
   if (!p->ev[0])
     for (auto& e : p->ev) (void)hipEventCreate(&e);
   p->valid = false;
   p->has_sort_end = false;
-  g_msm_seq++;
+  r.seq++;
   return p;
 }
 
@@ -1025,8 +1038,10 @@ SortPlan::~SortPlan() { msm_sort_release(this); }
 ISNARK_API eIcicleError icicle_snark_msm_profile(int back, float out_ms[5], uint32_t geom[5])
 {
   using namespace isnark;
-  if (!out_ms || !geom || back < 0 || back >= MSM_PROFILE_RING || (uint64_t)back >= g_msm_seq) return ICICLE_INVALID_ARGUMENT;
-  const MsmProfile& p = g_msm_ring[(g_msm_seq - 1 - back) % MSM_PROFILE_RING];
+  std::lock_guard<std::mutex> lk(g_msm_prof_mu);
+  const MsmProfileRing& r = msm_ring_of_active_device();
+  if (!out_ms || !geom || back < 0 || back >= MSM_PROFILE_RING || (uint64_t)back >= r.seq) return ICICLE_INVALID_ARGUMENT;
+  const MsmProfile& p = r.slots[(r.seq - 1 - back) % MSM_PROFILE_RING];
   if (!p.valid) return ICICLE_INVALID_ARGUMENT;
   if (hipEventElapsedTime(&out_ms[0], p.ev[0], p.ev[1]) != hipSuccess) return ICICLE_UNKNOWN_ERROR;
   (void)hipEventElapsedTime(&out_ms[1], p.ev[1], p.ev[2]);

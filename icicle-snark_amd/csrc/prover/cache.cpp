@@ -1,0 +1,355 @@
+// cache.cpp — CacheManager::compute (src/cache.rs:117-241): zkey sections 4-9 → the device-resident ZKeyCache of one
+// device (or of one shard of a device group).
+#include <algorithm>
+#include <fcntl.h>
+#include <errno.h>
+#include <sys/mman.h>
+#include <sys/random.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "prover_internal.h"
+
+using namespace bn254;
+using namespace isnark;
+using namespace isnark::prover;
+
+namespace isnark {
+namespace prover {
+
+ZKeyCache::~ZKeyCache()
+  {
+    (void)hipSetDevice(device_id);
+    if (s_g1) (void)hipStreamSynchronize(s_g1);
+    if (s_g2) (void)hipStreamSynchronize(s_g2);
+    if (s_g3) (void)hipStreamSynchronize(s_g3);
+    if (s_g4) (void)hipStreamSynchronize(s_g4);
+    if (s_g5) (void)hipStreamSynchronize(s_g5);
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_dist_y, (void*)d_dist_recv1, (void*)d_dist_send2, (void*)d_tw1, (void*)d_partials, (void*)d_bidx, (void*)d_wb})
+      if (p) (void)hipFree(p);
+    if (h_partials) (void)hipHostFree(h_partials);
+    if (s_qap) (void)icicle_destroy_stream(s_qap);
+    if (s_g1) (void)icicle_destroy_stream(s_g1);
+    if (s_g2) (void)icicle_destroy_stream(s_g2);
+    if (s_g3) (void)icicle_destroy_stream(s_g3);
+    if (s_g4) (void)icicle_destroy_stream(s_g4);
+    if (s_g5) (void)icicle_destroy_stream(s_g5);
+    if (ev_witness) (void)hipEventDestroy(ev_witness);
+    if (ev_sort) (void)hipEventDestroy(ev_sort);
+    if (ev_sort_b) (void)hipEventDestroy(ev_sort_b);
+    if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
+    if (ev_g2done) (void)hipEventDestroy(ev_g2done);
+    if (ev_g4done) (void)hipEventDestroy(ev_g4done);
+    if (ev_g5done) (void)hipEventDestroy(ev_g5done);
+    for (auto e : ev)
+      if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_done)
+      if (e) (void)hipEventDestroy(e);
+  }
+
+namespace {
+G1::P g1_from_mont_affine(const uint8_t* p)
+{
+  G1::A a;
+  memcpy(&a, p, 64);
+  if (G1::aff_is_zero(a)) return {Fq::zero(), Fq::one_std(), Fq::zero()};
+  return {Fq::from_mont(a.x), Fq::from_mont(a.y), Fq::one_std()};
+}
+G2::P g2_from_mont_affine(const uint8_t* p)
+{
+  G2::A a;
+  memcpy(&a, p, 128);
+  fe2 one = {Fq::one_std(), Fq::zero()};
+  if (G2::aff_is_zero(a)) return {Fq2Ops::zero(), one, Fq2Ops::zero()};
+  return {Fq2Ops::from_mont(a.x), Fq2Ops::from_mont(a.y), one};
+}
+} // namespace
+
+// ---- cold path: host → device ingest ------------------------------------------------------------
+// The zkey arrives as pageable memory (an mmap of the file, or the caller's buffer).  A pageable hipMemcpy is a
+// single-threaded staging copy; isnark::staged_copy (runtime.cpp) runs up to eight workers that copy 2 MB chunks into
+// their own pair of pinned buffers and enqueue the DMAs on their own streams, so page faults / memcpy of one chunk
+// overlap the DMA of the others.  `lanes`: streams to enqueue the DMAs on (the per-prove witness upload passes the
+// prover's own streams, idle at that point); nullptr: short-lived streams of the call (cold path).
+int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in, int n_lanes)
+{
+  const hipError_t e = staged_copy(device_id, jobs.data(), jobs.size(), true, lanes_in, n_lanes, /*own_temp_streams=*/lanes_in == nullptr);
+  if (e != hipSuccess) return fail((int)ICICLE_COPY_FAILED, "host to device upload: %s", hipGetErrorString(e));
+  return 0;
+}
+
+namespace {
+int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint32_t lo, uint32_t hi, uint64_t& bytes, std::vector<UploadJob>& jobs)
+{
+  if (sec->size != (uint64_t)total * elem) return fail(ERR_FORMAT, "zkey: point section size mismatch");
+  sh.lo = lo;
+  sh.hi = hi;
+  const size_t n = (size_t)sh.len() * elem;
+  P_HIP(hipMalloc(&sh.d_points, n ? n : 256));
+  if (n) jobs.push_back({sh.d_points, sec->p + (size_t)sh.lo * elem, n});
+  bytes += n;
+  return 0;
+}
+} // namespace
+
+// CacheManager::compute — src/cache.rs:117-241
+int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out)
+{
+  if (count < 1 || rank < 0 || rank >= count) return fail(ERR_ARG, "bad shard %d/%d", rank, count);
+  const bool trace = getenv("ICICLE_SNARK_TRACE_COLD") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cold] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  std::vector<Section> s;
+  if (int rc = read_sections(data, len, "zkey", 2, s)) return rc;
+  const Section *s1, *s2, *s4, *s5, *s6, *s7, *s8, *s9;
+  if (int rc = unique_section(s, 1, &s1)) return rc;
+  uint32_t protocol = 0;
+  if (s1->size >= 4) memcpy(&protocol, s1->p, 4);
+  if (protocol != 1) return fail(ERR_FORMAT, "Protocol not supported"); // GROTH16_PROTOCOL_ID, file_wrapper.rs:12,196-207
+  if (int rc = unique_section(s, 2, &s2)) return rc;
+  if (int rc = unique_section(s, 4, &s4)) return rc;
+  if (int rc = unique_section(s, 5, &s5)) return rc;
+  if (int rc = unique_section(s, 6, &s6)) return rc;
+  if (int rc = unique_section(s, 7, &s7)) return rc;
+  if (int rc = unique_section(s, 8, &s8)) return rc;
+  if (int rc = unique_section(s, 9, &s9)) return rc;
+
+  std::unique_ptr<ZKeyCache> z(new ZKeyCache());
+  z->device_id = device_id;
+  z->shard_rank = rank;
+  z->shard_count = count;
+  // read_header_groth16 — src/zkey.rs:47-85
+  const uint8_t* h = s2->p;
+  if (s2->size < 4 + 32 + 4 + 32 + 12 + 3 * 64 + 3 * 128) return fail(ERR_FORMAT, "zkey header too short");
+  memcpy(&z->n8q, h, 4);
+  if (z->n8q != 32) return fail(ERR_FORMAT, "zkey: unsupported base field size");
+  memcpy(z->q.l, h + 4, 32);
+  memcpy(&z->n8r, h + 36, 4);
+  if (z->n8r != 32) return fail(ERR_FORMAT, "zkey: unsupported scalar field size");
+  memcpy(z->r.l, h + 40, 32);
+  memcpy(&z->n_vars, h + 72, 4);
+  memcpy(&z->n_public, h + 76, 4);
+  memcpy(&z->domain_size, h + 80, 4);
+  if (!Fq::eq(z->q, Fq::modulus()) || !Fr::eq(z->r, Fr::modulus())) return fail(ERR_FORMAT, "zkey: not a BN254 key");
+  const uint32_t n = z->domain_size;
+  if (n == 0 || (n & (n - 1))) return fail(ERR_FORMAT, "zkey: domain size %u is not a power of two", n);
+  if (z->n_public + 1 > z->n_vars) return fail(ERR_FORMAT, "zkey: n_public exceeds n_vars");
+  const uint8_t* pp = h + 84;
+  z->vk_alpha_1 = g1_from_mont_affine(pp);
+  z->vk_beta_1 = g1_from_mont_affine(pp + 64);
+  z->vk_beta_2 = g2_from_mont_affine(pp + 128);
+  z->vk_gamma_2 = g2_from_mont_affine(pp + 256);
+  z->vk_delta_1 = g1_from_mont_affine(pp + 384);
+  z->vk_delta_2 = g2_from_mont_affine(pp + 448);
+
+  // coefficients (section 4): {m:u32 c:u32 s:u32 value[32]} — src/cache.rs:126-166 (only byte 0 of m is read, :159)
+  const size_t rec = 12 + 32;
+  if (s4->size < 4 || (s4->size - 4) % rec) return fail(ERR_FORMAT, "zkey: coefficient section size");
+  if ((s4->size - 4) / rec > 0xffffffffull) return fail(ERR_FORMAT, "zkey: too many coefficients");
+  const uint32_t n_coef = (uint32_t)((s4->size - 4) / rec);
+  {
+    const uint64_t nv64 = z->n_vars, np1 = (uint64_t)z->n_public + 1;
+    if (s5->size != nv64 * 64 || s6->size != nv64 * 64 || s7->size != nv64 * 128 || s8->size != (nv64 - np1) * 64 || s9->size != (uint64_t)n * 64)
+      return fail(ERR_FORMAT, "zkey: point section size mismatch");
+  }
+  z->n_coef = n_coef; // from the section length, like src/cache.rs:129 (the declared count in the first 4 bytes is not read)
+  // the container and the header are validated before the device is touched (a malformed key is a format error on any host)
+  IcicleDevice dev;
+  memset(&dev, 0, sizeof dev);
+  strcpy(dev.type, "HIP");
+  dev.id = device_id;
+  P_ICICLE(icicle_set_device(&dev));
+  // device CSR built by kernels from the raw records (prover/csr.hip); the records travel with the points below
+  uint32_t* d_records = nullptr;
+  const size_t rec_bytes = (size_t)n_coef * rec;
+  P_HIP(hipMalloc((void**)&d_records, rec_bytes ? rec_bytes : 4));
+  struct FreeTmp {
+    void* p;
+    ~FreeTmp() { (void)hipFree(p); }
+  } free_records{d_records};
+  P_HIP(hipMalloc((void**)&z->d_rowptr, (2 * (size_t)n + 1) * 4));
+  P_HIP(hipMalloc((void**)&z->d_cols, (size_t)(n_coef ? n_coef : 1) * 4));
+  P_HIP(hipMalloc((void**)&z->d_vals, (size_t)(n_coef ? n_coef : 1) * 32));
+  z->device_bytes += (2 * (size_t)n + 1) * 4 + (size_t)n_coef * 36;
+  std::vector<UploadJob> jobs;
+  if (rec_bytes) jobs.push_back({d_records, s4->p + 4, rec_bytes});
+  lap("header + coefficient buffers");
+
+  // bases (sections 5-9), this process's point range only
+  // A, B1, B2 share the witness range [wlo, whi); C (= witness[n_public+1..]) takes the part of that SAME
+  // witness range it covers, so that one digit sort of witness[wlo:whi] serves all four MSMs.
+  const uint32_t wlo = (uint32_t)((uint64_t)z->n_vars * rank / count), whi = (uint32_t)((uint64_t)z->n_vars * (rank + 1) / count);
+  const uint32_t skip = z->n_public + 1;
+  const uint32_t clo = (wlo > skip ? wlo : skip) - skip, chi = (whi > skip ? whi : skip) - skip;
+  const uint32_t hlo = (uint32_t)((uint64_t)n * rank / count), hhi = (uint32_t)((uint64_t)n * (rank + 1) / count);
+  if (int rc = alloc_shard(z->A, s5, 64, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
+  if (int rc = alloc_shard(z->B1, s6, 64, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
+  if (int rc = alloc_shard(z->B2, s7, 128, z->n_vars, wlo, whi, z->device_bytes, jobs)) return rc;
+  if (int rc = alloc_shard(z->C, s8, 64, z->n_vars - skip, clo, chi, z->device_bytes, jobs)) return rc;
+  // H: a power-of-two shard count takes the residue class k ≡ rank (mod count) instead of a contiguous range — the rank
+  // then needs the coset evaluations only at those k, which the folded forward transform delivers at 1/count of the cost
+  // (qap.h: qap_coset_fold3); the whole section is uploaded once and the class is gathered on the device
+  const bool h_strided = count > 1 && (count & (count - 1)) == 0 && n / (uint32_t)count >= 1024;
+  void* h_full = nullptr;
+  struct FreeFull {
+    void** p;
+    ~FreeFull() { if (*p) (void)hipFree(*p); }
+  } free_full{&h_full};
+  if (h_strided) {
+    if (s9->size != (uint64_t)n * 64) return fail(ERR_FORMAT, "zkey: point section size mismatch");
+    const uint32_t m = n / (uint32_t)count;
+    P_HIP(hipMalloc(&h_full, (size_t)n * 64));
+    P_HIP(hipMalloc(&z->H.d_points, (size_t)m * 64));
+    z->H.lo = 0;
+    z->H.hi = m;
+    z->H.stride = (uint32_t)count;
+    z->H.first = (uint32_t)rank;
+    jobs.push_back({h_full, s9->p, (size_t)n * 64});
+    z->device_bytes += (size_t)m * 64;
+  } else if (int rc = alloc_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes, jobs)) return rc;
+  lap("point buffers (hipMalloc)");
+  if (int rc = staged_upload(device_id, jobs)) return rc;
+  if (h_strided) {
+    P_HIP(qap_gather_strided((const fe*)h_full, (fe*)z->H.d_points, 2, z->H.len(), z->H.stride, z->H.first, nullptr));
+    P_HIP(hipStreamSynchronize(nullptr));
+    P_HIP(hipFree(h_full));
+    h_full = nullptr;
+  }
+  lap("staged upload");
+  {
+    uint32_t first_bad = 0;
+    P_HIP(qap_build_csr(d_records, n_coef, n, z->n_vars, z->d_rowptr, z->d_cols, z->d_vals, &first_bad, nullptr));
+    if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
+  }
+  lap("device CSR build");
+  {
+    // sparse B (see ZKeyCache): keep only the wires of this rank's range whose B1 or B2 base is not the identity.  Opt-in
+    // (ICICLE_SNARK_SPARSE_B=<largest density>): measured on the stand-in circuits it pays at 1.4 M constraints (8.7 → 8.0 ms) and
+    // saves table memory, but costs 0.2–0.8 ms between 0.1 M and 1.0 M — the second digit sort heads the G2 chain, the longest of
+    // a witness-light prove
+    const double max_density = getenv("ICICLE_SNARK_SPARSE_B") ? atof(getenv("ICICLE_SNARK_SPARSE_B")) : 0.0;
+    const uint32_t L = z->B1.len();
+    if (max_density > 0 && L >= 2) {
+      uint8_t* d_flags = nullptr;
+      P_HIP(hipMalloc((void**)&d_flags, L));
+      FreeTmp free_flags{d_flags};
+      P_HIP(qap_points_nonzero(z->B1.d_points, z->B2.d_points, L, d_flags, nullptr));
+      std::vector<uint8_t> flags(L);
+      P_HIP(hipMemcpy(flags.data(), d_flags, L, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> idx;
+      idx.reserve(L);
+      for (uint32_t i = 0; i < L; i++)
+        if (flags[i]) idx.push_back(i);
+      const uint32_t nb = (uint32_t)idx.size();
+      if (nb >= 1 && (double)nb <= max_density * (double)L) {
+        P_HIP(hipMalloc((void**)&z->d_bidx, (size_t)nb * 4));
+        P_HIP(hipMemcpy(z->d_bidx, idx.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+        void *c1 = nullptr, *c2 = nullptr;
+        P_HIP(hipMalloc(&c1, (size_t)nb * 64));
+        FreeTmp free_c1{c1};
+        P_HIP(hipMalloc(&c2, (size_t)nb * 128));
+        FreeTmp free_c2{c2};
+        P_HIP(qap_gather_idx(z->B1.d_points, z->d_bidx, c1, nb, 64, nullptr));
+        P_HIP(qap_gather_idx(z->B2.d_points, z->d_bidx, c2, nb, 128, nullptr));
+        P_HIP(hipStreamSynchronize(nullptr));
+        std::swap(free_c1.p, z->B1.d_points); // the dense arrays are freed at the end of this block
+        std::swap(free_c2.p, z->B2.d_points);
+        z->B1.lo = z->B2.lo = 0;
+        z->B1.hi = z->B2.hi = nb;
+        P_HIP(hipMalloc((void**)&z->d_wb, (size_t)nb * 32));
+        z->device_bytes -= (uint64_t)(L - nb) * (64 + 128);
+        z->device_bytes += (uint64_t)nb * (4 + 32);
+        z->sparse_b = true;
+        z->nb = nb;
+      }
+    }
+  }
+  lap("sparse B detection");
+  // bases: the file's Montgomery form (R = 2^256) → the bucket kernels' internal encoding (R' = 2^261), once.  Table mode
+  // (msm_plan.h; ICICLE_SNARK_TABLES=0 disables it): every base array becomes W rows 2^(c·w)·P so that all digits of a
+  // scalar share one bucket set — 13 instead of 16 mixed additions per scalar at 1.6 M constraints for 13× the base memory.
+  {
+    bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
+    z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
+    z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
+    // the B subset keeps the digit width of the full witness set: fewer buckets would mean longer single-thread chains for the
+    // 0/1-heavy witnesses this path exists for (404 k wires, 219 k with a B base: c = 17 instead of 19 cost 1.2 ms of a 4 ms prove)
+    z->geom_b = z->sparse_b ? msm_geometry(z->nb, 0, tables ? z->geom_w.c : 0) : z->geom_w;
+    if (z->sparse_b && tables && z->geom_b.c != z->geom_w.c) z->geom_b = msm_geometry(z->nb, 0, 1);
+    if (tables) {
+      // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
+      // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
+      size_t free_b = 0, total_b = 0;
+      release_cached_device_memory(); // blocks parked by icicle_free count as free
+      P_HIP(hipMemGetInfo(&free_b, &total_b));
+      const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W, wb = (uint64_t)z->geom_b.W;
+      const uint64_t need = ww * ((uint64_t)z->A.len() * 64 + (uint64_t)z->C.len() * 64) + wb * (uint64_t)z->B1.len() * (64 + 128) + wh * (uint64_t)z->H.len() * 64 +
+                            wb * (uint64_t)z->B2.len() * (192 + 64) + ((uint64_t)n * 128 + (uint64_t)z->n_vars * 32 + (64u << 20));
+      if (need > free_b) {
+        tables = false;
+        z->geom_w = msm_geometry(z->A.len(), 0, 0);
+        z->geom_h = msm_geometry(z->H.len(), 0, 0);
+        z->geom_b = z->sparse_b ? msm_geometry(z->nb, z->geom_w.c, 0) : z->geom_w;
+      }
+    }
+    struct Job { Shard* sh; bool g2; const MsmGeom* g; };
+    const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_b}, {&z->B2, true, &z->geom_b}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
+    for (const Job& j : jobs5) {
+      if (j.g->tab) {
+        void* table = nullptr;
+        P_ICICLE(j.g2 ? msm_g2_build_table(j.sh->d_points, j.sh->len(), 1, *j.g, nullptr, &table) : msm_g1_build_table(j.sh->d_points, j.sh->len(), 1, *j.g, nullptr, &table));
+        P_HIP(hipFree(j.sh->d_points));
+        j.sh->d_points = table;
+        z->device_bytes += (uint64_t)j.sh->len() * (j.g->W - 1) * (j.g2 ? 128 : 64);
+      } else {
+        P_ICICLE(j.g2 ? msm_g2_points_to_internal(j.sh->d_points, j.sh->len(), 1, nullptr) : msm_g1_points_to_internal(j.sh->d_points, j.sh->len(), 1, nullptr));
+      }
+    }
+  }
+  P_HIP(hipStreamSynchronize(nullptr));
+  lap("points to internal form / tables");
+
+  // room for shard_count equal slices (groth16_upload_witness_slice: the in-place all-gather wants equal counts)
+  P_HIP(hipMalloc((void**)&z->d_witness, (size_t)witness_slice_elems(z->n_vars, count) * count * 32));
+  P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
+  if (z->H.stride > 1) P_HIP(hipMalloc((void**)&z->d_fold, (size_t)z->H.len() * 3 * 32));
+  P_HIP(hipMalloc((void**)&z->d_partials, 5 * PARTIALS_STRIDE));
+  P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE));
+  z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
+  // six streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
+  // Stream priorities were tried (QAP chain high, G2 low, …): every variant was 1-2 ms slower than equal priorities.
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_qap)); // QAP front end (its own hardware queue; a higher stream priority made no difference)
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g4));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g5));
+  {
+    // the first host→device copy on a stream sets up its DMA queue (milliseconds, measured 20 ms over six streams): do
+    // it here, not inside the first prove that brings a new witness
+    const hipStream_t all[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
+    for (int rep = 0; rep < 2; rep++)
+      for (hipStream_t st : all) P_HIP(hipMemcpyAsync(z->d_partials, z->h_partials, 4096, hipMemcpyHostToDevice, st));
+    for (hipStream_t st : all) P_HIP(hipStreamSynchronize(st));
+  }
+  P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_sort_b, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_g2done, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_g4done, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_g5done, hipEventDisableTiming));
+  for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
+  for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  lap("work buffers, streams, events");
+  out = std::move(z);
+  return 0;
+}
+
+} // namespace prover
+} // namespace isnark

@@ -1,0 +1,209 @@
+// prover_internal.h — types and helpers shared by the translation units of the prover host
+// (containers.cpp, cache.cpp, prover.cpp, assemble.cpp, multi.cpp).  Nothing here crosses the C ABI.
+//
+//   containers.cpp  snarkjs .zkey / .wtns containers        ← src/file_wrapper.rs:45-208, src/zkey.rs:47-85
+//   cache.cpp       CacheManager::compute (ZKeyCache build) ← src/cache.rs:117-241
+//   prover.cpp      construct_r1cs + groth16_commitments on ONE device, the C API        ← src/proof_helper.rs:31-241, src/lib.rs:33-61
+//   assemble.cpp    blinding, affine conversion, JSON       ← src/proof_helper.rs:274-316, src/conversions.rs:30-56
+//   multi.cpp       the same prove over a GROUP of devices in one process (device string "HIP:0-7"), SURVEY.md §8e
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/groth16_prover.h"
+#include "../common.h"
+#include "../ec.h"
+#include "../msm_plan.h"
+#include "../ntt_fuse.h"
+#include "qap.h"
+
+namespace isnark {
+const bn254::fe* ntt_domain_table(int* log_n); // ntt.hip
+
+namespace prover {
+using namespace bn254;
+
+// ---- errors: one thread-local text per thread (groth16_last_error); worker threads hand theirs to the caller
+int fail(int code, const char* fmt, ...);
+const char* last_error_text();
+void set_error_text(const char* text);
+#define P_HIP(call)                                                                                                              \
+  do {                                                                                                                           \
+    hipError_t e__ = (call);                                                                                                     \
+    if (e__ != hipSuccess) return ::isnark::prover::fail((int)ICICLE_UNKNOWN_ERROR, "%s: %s", #call, hipGetErrorString(e__));    \
+  } while (0)
+#define P_ICICLE(call)                                                                                                           \
+  do {                                                                                                                           \
+    eIcicleError e__ = (call);                                                                                                   \
+    if (e__ != ICICLE_SUCCESS) return ::isnark::prover::fail((int)e__, "%s failed (%d): %s", #call, (int)e__, icicle_snark_last_error()); \
+  } while (0)
+enum { ERR_IO = -1, ERR_FORMAT = -2, ERR_ARG = -3, ERR_NOCACHE = -4 };
+
+inline double ms_since(std::chrono::steady_clock::time_point t0)
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---- containers (containers.cpp)
+struct Section {
+  const uint8_t* p = nullptr;
+  uint64_t size = 0;
+  int count = 0;
+};
+int read_sections(const uint8_t* data, size_t len, const char* type, uint32_t max_version, std::vector<Section>& out);
+int unique_section(const std::vector<Section>& s, size_t id, const Section** sec);
+struct MappedFile {
+  const uint8_t* data = nullptr;
+  size_t len = 0;
+  int fd = -1;
+  ~MappedFile();
+  int open_ro(const char* path);
+};
+struct Wtns {
+  uint32_t n8 = 0, n_witness = 0;
+  fe q;
+  const uint8_t* values = nullptr; // n_witness × 32 B standard form
+};
+int parse_wtns(const uint8_t* data, size_t len, Wtns& w);
+
+// ---- the device-resident cache of one zkey on ONE device (cache.cpp)
+constexpr size_t PARTIALS_STRIDE = 64 * 16 * 256; // ≥ W·bpw·sizeof(XYZZ) for any geometry (W ≤ 64, bpw ≤ 16, G2 256 B)
+
+struct Shard {
+  uint32_t lo = 0, hi = 0; // [lo, hi) of the full base array
+  void* d_points = nullptr; // internal encoding; in table mode W rows of len() points (row w = 2^(c·w)·P, msm_plan.h)
+  uint32_t stride = 1, first = 0; // H of a power-of-two shard count: elements first + k·stride, k < len() (lo = 0, hi = len)
+  uint32_t len() const { return hi - lo; }
+};
+
+struct ZKeyCache {
+  // header — src/zkey.rs:6-21
+  uint32_t n8q = 0, n8r = 0, n_vars = 0, n_public = 0, domain_size = 0, n_coef = 0;
+  fe q, r;
+  G1::P vk_alpha_1, vk_beta_1, vk_delta_1; // standard form projective (host)
+  G2::P vk_beta_2, vk_gamma_2, vk_delta_2;
+  // device
+  int device_id = 0, shard_rank = 0, shard_count = 1;
+  MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM, fixed at cache build
+  // Sparse B: a wire that never occurs on the B side of a constraint has the identity as its B1 and B2 base (snarkjs writes
+  // all-zero bytes).  One thread accumulates one bucket, so an identity base skipped inside the shared witness sort saves
+  // nothing (the other lanes of the wave still add).  Opt-in: with ICICLE_SNARK_SPARSE_B=<d> set and at most the fraction d of
+  // this rank's wires having a B base, B1/B2 hold only those nb bases (d_bidx = their wire numbers relative to A.lo), and the two
+  // B MSMs run on their own digit sort of the gathered scalars d_wb (geometry geom_b: the digit width of the full set).
+  bool sparse_b = false;
+  uint32_t nb = 0;
+  uint32_t* d_bidx = nullptr;
+  fe* d_wb = nullptr;
+  MsmGeom geom_b;
+  uint32_t* d_rowptr = nullptr; // 2n+1
+  uint32_t* d_cols = nullptr;   // n_coef
+  fe* d_vals = nullptr;         // n_coef, Montgomery form
+  Shard A, B1, B2, C, H;
+  fe* d_witness = nullptr; // n_vars
+  fe* d_vec = nullptr;     // 3n
+  fe* d_fold = nullptr;    // 3·n/G: folded rows of a strided H shard (qap_coset_fold3)
+  // distributed front end (groth16_dist_stage1/2; strided H shards only): Y rows of stage 1, what exchange 1 delivers,
+  // what stage 2 sends, the scale table n⁻¹·ω_n^{−r·k2} — 3·m elements each, m = n / shard_count; exchange 2 delivers into d_fold
+  fe *d_dist_y = nullptr, *d_dist_recv1 = nullptr, *d_dist_send2 = nullptr, *d_tw1 = nullptr;
+  // d_fold holds the Z rows of this rank for the witness now resident: the next commitments call WITHOUT a new witness skips
+  // its own inverse transform + fold.  Set only by the caller's confirmation that exchange 2 has delivered
+  // (groth16_dist_exchange_done, or the in-process group prove); cleared by every witness upload and every stage 1.
+  bool dist_ready = false;
+  bool dist_stage2_done = false; // stage 2 has run for the resident witness (what groth16_dist_exchange_done checks)
+  fe* d_skeys = nullptr;   // n: n⁻¹·g^i — 1/n and the coset keys folded into the inverse transform's last pass (ntt_fuse.h); built on first use
+  uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
+  uint8_t* h_partials = nullptr; // pinned mirror
+  hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
+  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_b = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
+             ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_xchg = nullptr; // group prove: "what the peers pull from this shard next is complete" (recorded on s_qap)
+  uint64_t device_bytes = 0;
+  bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
+  bool witness_event_set = false; // ev_witness was already recorded for the resident witness (behind a device-side all-gather)
+  Groth16Timings last_tm = {0, 0, 0, 0}; // phase timings of the most recent prove (groth16_last_timings)
+  uint64_t last_use = 0;                 // CacheManager LRU clock
+
+  ~ZKeyCache();
+};
+
+// elements per rank when the witness is uploaded in shard_count slices
+inline uint64_t witness_slice_elems(uint32_t n_vars, int count) { return ((uint64_t)n_vars + count - 1) / count; }
+
+// CacheManager::compute — src/cache.rs:117-241
+int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out);
+typedef CopyJob UploadJob;
+int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in = nullptr, int n_lanes = 0);
+
+// ---- blinding and proof assembly (assemble.cpp)
+// blinding terms that do not depend on the commitments: δ1·r, δ1·s, δ2·s, δ1·r·s (src/proof_helper.rs:280-283);
+// groth16_prove_mem computes them on a host thread while the GPU works
+struct Blinding {
+  bn254_scalar_t r, s;
+  bn254_projective_t d1r, d1s, d1rs;
+  bn254_g2_projective_t d2s;
+};
+// The two scalar multiplications of the proof's C term that need a commitment — (A + α1 + δ1·r)·s and
+// (B1 + β1 + δ1·s)·r, src/proof_helper.rs:284-287 — only need A and B1, which are complete milliseconds before H:
+// the host threads that finish those two MSMs go on to compute them while the GPU still works (single-GPU prove only;
+// a sharded prove has to sum the commitments of all ranks first).
+struct EarlyTerms {
+  const Blinding* bl = nullptr;
+  std::atomic<bool> bl_ready{false};
+  bn254_projective_t ta, tb;
+  std::atomic<int> done{0};
+};
+int compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_in, Blinding* b);
+int assemble_impl(const ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap,
+                  const EarlyTerms* et = nullptr);
+
+// ---- one device (prover.cpp)
+struct DeviceGroup; // multi.cpp
+} // namespace prover
+} // namespace isnark
+
+// The reference's CacheManager (src/cache.rs:110-115) maps "{zkey_path}_{device}" to a ZKeyCache.  Here an entry is either
+// ONE device's cache or a GROUP of shard caches (one per device of a "HIP:a-b" device string) that prove together.
+struct Groth16CacheManager {
+  std::mutex mu;     // serialises cache builds and proves (one device pipeline per manager)
+  std::mutex map_mu; // guards `cache` / `groups`; entries are shared_ptr so that an evict cannot free a key a prove still uses
+  std::map<std::string, std::shared_ptr<isnark::prover::ZKeyCache>> cache;
+  std::map<std::string, std::shared_ptr<isnark::prover::DeviceGroup>> groups;
+  std::map<int, uint32_t> domain_n; // device → domain_size its NTT domain was last initialised for (get_cache, src/cache.rs:242-256)
+  uint64_t clock = 0;               // LRU clock (last_use of the entries)
+  uint64_t budget_bytes = 0;        // device-memory budget per device for cached keys (0 = none): least recently used keys are evicted
+};
+
+namespace isnark {
+namespace prover {
+std::shared_ptr<ZKeyCache> find(Groth16CacheManager* cm, const char* key);
+std::shared_ptr<DeviceGroup> find_group(Groth16CacheManager* cm, const char* key);
+int set_active_device(int device_id);
+int ensure_domain(Groth16CacheManager* cm, const ZKeyCache* z); // works on the calling thread's active device (= z->device_id)
+void evict_for_budget(Groth16CacheManager* cm, int device, uint64_t need);
+// the shard pipeline of one device; caller holds cm->mu.  wtns == NULL: the witness (and, with z->dist_ready, the Z rows) are resident
+int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, size_t wtns_len, uint8_t* out_points, Groth16Timings* tm, EarlyTerms* et);
+// distributed front end, stages without the host synchronisation of the C API (the exchange is enqueued on z->s_qap)
+int shard_upload_slice(ZKeyCache* z, const Wtns& w);
+int shard_dist_stage1(Groth16CacheManager* cm, ZKeyCache* z);
+int shard_dist_stage2(ZKeyCache* z);
+bool shard_dist_supported(const ZKeyCache* z);
+
+// ---- device groups (multi.cpp)
+// "HIP", "HIP:3", "HIP:0-7", "HIP:0,2,5", "CUDA:0-3" (alias) → device ids (duplicates allowed: several shards on one device);
+// a plain "HIP" / "CUDA" takes ICICLE_SNARK_DEVICES=<list> when set.  Returns 0 or an error code (text in last_error_text).
+int parse_device_string(const char* device, std::vector<int>& ids);
+int group_load(Groth16CacheManager* cm, const char* key, const uint8_t* zkey, size_t len, const std::vector<int>& devs);
+int group_commitments(Groth16CacheManager* cm, DeviceGroup* g, const void* wtns, size_t wtns_len, uint8_t* out_points, Groth16Timings* tm);
+const ZKeyCache* group_lead(const DeviceGroup* g);
+void group_info(const DeviceGroup* g, Groth16CircuitInfo* info);
+} // namespace prover
+} // namespace isnark

@@ -114,15 +114,16 @@ bool is_tracked_device_ptr(const void* p) { return identify(p) >= 0; }
 
 // ---- pageable-memory copy engine (see common.h) ------------------------------------------------------------------
 constexpr size_t STAGED_CHUNK = 2u << 20;
-struct StagedPool { // pinned staging, events and lane streams: allocated once per process / device
-  std::mutex mu;
+struct StagedPool { // pinned staging, events and the lane stream of ONE device (an event only records on a stream of the device
+  std::mutex mu;     // it was created on; one pool and one lock per device also lets the prover threads of several GPUs upload at once)
   uint8_t* pinned = nullptr;
   hipEvent_t events[STAGED_LANES][2] = {};
-  std::map<int, std::vector<hipStream_t>> lanes; // device → persistent lane streams
+  std::vector<hipStream_t> lanes; // persistent lane stream(s)
 };
-static StagedPool g_staged;
+constexpr int STAGED_DEVICES = 16;
+static StagedPool g_staged[STAGED_DEVICES];
 
-bool is_pinned_host(const void* host_ptr)
+bool is_pinned_host(const void* host_ptr, int device_id)
 {
   hipPointerAttribute_t a;
   memset(&a, 0, sizeof a);
@@ -130,7 +131,11 @@ bool is_pinned_host(const void* host_ptr)
     (void)hipGetLastError(); // an unregistered (pageable) pointer is reported as an error: clear it
     return false;
   }
-  return a.type == hipMemoryTypeHost;
+  if (a.type != hipMemoryTypeHost) return false;
+  // device_id ≥ 0: the DMA will be issued by that device — take the direct path only for memory pinned in its context or
+  // pinned portably (hipHostMallocPortable / hipHostRegisterPortable); anything else goes through the staging copy
+  if (device_id >= 0 && a.device != device_id && !(a.allocationFlags & hipHostMallocPortable)) return false;
+  return true;
 }
 
 // A caller whose pageable source is a mapped FILE can say so: the workers then pread() the chunk straight into their pinned
@@ -144,14 +149,21 @@ void staged_copy_file_hint(const void* base, size_t len, int fd)
   t_file_len = len;
   t_file_fd = fd;
 }
+void staged_copy_file_hint_get(const void** base, size_t* len, int* fd)
+{
+  *base = t_file_base;
+  *len = t_file_len;
+  *fd = t_file_fd;
+}
 
 hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes_in, int n_lanes, bool own_temp_streams)
 {
   const uint8_t* const file_base = t_file_base;
   const size_t file_len = t_file_len;
   const int file_fd = t_file_fd;
-  std::lock_guard<std::mutex> lk(g_staged.mu);
-  StagedPool& P = g_staged;
+  if (device_id < 0 || device_id >= STAGED_DEVICES) return hipErrorInvalidDevice;
+  StagedPool& P = g_staged[device_id];
+  std::lock_guard<std::mutex> lk(P.mu);
   hipError_t e0 = hipSetDevice(device_id);
   if (e0 != hipSuccess) return e0;
   if (!P.pinned) {
@@ -195,7 +207,7 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
     // per-call copies of the C ABI: four workers fill their pinned buffers in parallel and enqueue the DMAs on ONE
     // persistent stream of the engine — every extra idle stream takes one of the GPU_MAX_HW_QUEUES hardware queues away
     // from the prover's own streams (with four lane streams alive, two of the prover's six shared a queue)
-    std::vector<hipStream_t>& v = P.lanes[device_id];
+    std::vector<hipStream_t>& v = P.lanes;
     max_lanes = 4;
     if (v.empty()) {
       hipStream_t st;
@@ -281,6 +293,14 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
 }
 
 void release_cached_device_memory(); // below: the allocation cache of icicle_malloc / icicle_free
+void ws_release_idle(int dev, bool lock = true);
+} // namespace isnark
+// stream pool and allocation cache (defined with the C API below), needed by the workspace arena's out-of-memory path
+static std::mutex g_sp_mu;
+static std::map<int, std::vector<hipStream_t>> g_stream_pool;
+static std::mutex g_ac_mu;
+static void alloc_cache_flush(int dev);
+namespace isnark {
 
 // ---- workspace arena (see common.h) -------------------------------------------------------------
 struct WsBlock {
@@ -337,9 +357,11 @@ hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s)
     for (auto it = v.begin(); it != v.end();) {
       if (!it->in_use) { (void)hipFree(it->ptr); it = v.erase(it); } else ++it;
     }
-    for (auto& b : g_ws_orphans[ws_key(s).first]) (void)hipFree(b.ptr);
-    g_ws_orphans[ws_key(s).first].clear();
-    release_cached_device_memory();
+    ws_release_idle(ws_key(s).first, /*lock=*/false); // g_ws_mu is held here
+    {
+      std::lock_guard<std::mutex> la(g_ac_mu);
+      alloc_cache_flush(ws_key(s).first);
+    }
     e = hipMalloc(&q, bytes);
     if (e != hipSuccess) return e;
   }
@@ -361,6 +383,33 @@ hipError_t ws_free(void* p, hipStream_t s)
       }
   }
   return hipErrorInvalidValue;
+}
+
+// Idle workspace of device `dev` back to the driver: the orphan list and the blocks cached for streams parked in the stream
+// pool (a parked stream was synchronised by icicle_destroy_stream and nothing runs on it until it is handed out again).
+// Called when an allocation fails and before the table-mode memory check of a cache build.
+void ws_release_idle(int dev, bool lock)
+{
+  std::vector<hipStream_t> parked;
+  {
+    std::lock_guard<std::mutex> lp(g_sp_mu);
+    auto it = g_stream_pool.find(dev);
+    if (it != g_stream_pool.end()) parked = it->second;
+  }
+  std::unique_lock<std::mutex> lk(g_ws_mu, std::defer_lock);
+  if (lock) lk.lock();
+  for (auto& b : g_ws_orphans[dev]) (void)hipFree(b.ptr);
+  g_ws_orphans[dev].clear();
+  for (hipStream_t st : parked) {
+    auto it = g_ws.find(WsKey(dev, st));
+    if (it == g_ws.end()) continue;
+    for (auto b = it->second.begin(); b != it->second.end();) {
+      if (!b->in_use) {
+        (void)hipFree(b->ptr);
+        b = it->second.erase(b);
+      } else ++b;
+    }
+  }
 }
 
 // The stream goes away (the caller has synchronised it): its idle blocks move to the device's orphan list, from which
@@ -475,7 +524,6 @@ struct AllocCache {
   std::multimap<size_t, void*> blocks; // capacity → block
   size_t bytes = 0;
 };
-static std::mutex g_ac_mu;
 static std::map<int, AllocCache> g_alloc_cache;            // device → cache
 static std::map<uintptr_t, size_t> g_capacity;             // live block → its real (hipMalloc) size
 
@@ -489,10 +537,13 @@ static void alloc_cache_flush(int dev) // caller holds g_ac_mu
 namespace isnark {
 void release_cached_device_memory()
 {
-  std::lock_guard<std::mutex> lk(g_ac_mu);
   int d = 0;
   (void)hipGetDevice(&d);
-  alloc_cache_flush(d);
+  {
+    std::lock_guard<std::mutex> lk(g_ac_mu);
+    alloc_cache_flush(d);
+  }
+  ws_release_idle(d);
 }
 } // namespace isnark
 static hipError_t cached_malloc(void** ptr, size_t size)
@@ -700,8 +751,6 @@ ISNARK_API eIcicleError icicle_copy_to_device_async(void* dst, const void* src, 
 // five streams in every prove (src/proof_helper.rs:32,186-187, src/conversions.rs:14).  A destroyed stream is drained and
 // parked (≤ STREAM_POOL_MAX per device, with the workspace blocks cached for it); the next create takes it back.
 constexpr size_t STREAM_POOL_MAX = 8;
-static std::mutex g_sp_mu;
-static std::map<int, std::vector<hipStream_t>> g_stream_pool;
 ISNARK_API eIcicleError icicle_create_stream(icicleStreamHandle* stream)
 {
   if (!stream) return ICICLE_INVALID_POINTER;

@@ -215,12 +215,14 @@ def sharded_commitments(cm, key: str, wtns, exch, distributed_qap: bool = True, 
             exch.alltoall_rows(send, recv, rows, rb, cb)
             send, recv = cm.dist_stage2(key)
             exch.alltoall_rows(send, recv, rows, rb, cb)
+            cm.dist_exchange_done(key)
         return cm.commitments(key, None)
     if distributed_qap and wtns is not None and exch.world > 1 and cm.dist_supported(key):
         send, recv, rows, rb, cb = cm.dist_stage1(key, wtns)
         exch.alltoall_rows(send, recv, rows, rb, cb)
         send, recv = cm.dist_stage2(key)
         exch.alltoall_rows(send, recv, rows, rb, cb)
+        cm.dist_exchange_done(key)
         return cm.commitments(key, None)
     return cm.commitments(key, wtns)
 

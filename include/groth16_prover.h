@@ -29,9 +29,14 @@ typedef struct Groth16CacheManager Groth16CacheManager;
 Groth16CacheManager* groth16_cache_manager_new(void);
 void groth16_cache_manager_free(Groth16CacheManager* cm);
 
-/* groth16_prove — src/lib.rs:33-61.  `device` is the reference's free-form device string; this
- * library registers "HIP" (and the alias "CUDA"); anything else, including "CPU", is an error — there
- * is no CPU fallback.  Blinding factors r, s are drawn at random (default build of the reference). */
+/* groth16_prove — src/lib.rs:33-61.  `device` is the reference's free-form device string (the reference passes the type
+ * and always uses id 0, src/lib.rs:25-31); this library registers "HIP" (and the alias "CUDA"); anything else, including
+ * "CPU", is an error — there is no CPU fallback.  The string may name the devices to prove on:
+ *     "HIP"  (device 0, or the list in ICICLE_SNARK_DEVICES)   "HIP:2"   "HIP:0-7"   "HIP:0,2,4,6"
+ * More than one device = ONE prove sharded over a device group inside this process: point-range shards of
+ * the A, B1, B2, C bases, residue-class shards of H, the QAP front end distributed, device-side exchanges over xGMI.  A
+ * device may be named several times ("HIP:0,0,0,0": four shards on GPU 0 — how a 1-GPU machine exercises the path).
+ * Blinding factors r, s are drawn at random (default build of the reference). */
 int groth16_prove(const char* witness_path, const char* zkey_path, const char* proof_path, const char* public_path,
                   const char* device, Groth16CacheManager* cm);
 
@@ -45,6 +50,19 @@ int groth16_cache_load(Groth16CacheManager* cm, const char* key, const void* zke
                        int shard_rank, int shard_count);
 int groth16_cache_load_file(Groth16CacheManager* cm, const char* key, const char* zkey_path, int device_id,
                             int shard_rank, int shard_count);
+/* The same key over a GROUP of devices (what groth16_prove builds for "HIP:a-b"): shard k of n_devices lives on
+ * device_ids[k].  Every entry point that takes a key (groth16_commitments, groth16_prove_mem, groth16_prove_resident,
+ * groth16_cache_info, groth16_last_timings, groth16_cache_evict) then works on the group: groth16_commitments returns the
+ * SUM of the shards' commitments. */
+int groth16_cache_load_devices(Groth16CacheManager* cm, const char* key, const void* zkey, size_t zkey_len, const int* device_ids,
+                               int n_devices);
+/* device string → ids ("HIP:0-7" → 0 … 7): returns how many devices it names (`ids` receives the first `cap`), or a
+ * negative error code.  Needs no GPU. */
+int groth16_parse_device(const char* device, int* ids, int cap);
+/* Device-memory budget for the cached keys of ONE device (bytes; 0 = unlimited, the reference's behaviour — its
+ * CacheManager never evicts, src/cache.rs:110-114).  Before a new key is built, the least recently used single-device
+ * keys of that device are evicted until the new entry fits.  ICICLE_SNARK_CACHE_BUDGET_MB sets the initial value. */
+void groth16_cache_set_budget(Groth16CacheManager* cm, uint64_t bytes_per_device);
 int groth16_cache_contains(const Groth16CacheManager* cm, const char* key);
 void groth16_cache_evict(Groth16CacheManager* cm, const char* key);
 
@@ -76,7 +94,8 @@ int groth16_witness_ready(Groth16CacheManager* cm, const char* key);
  * instead of replicating the spmv and the inverse transform on every rank, each rank transforms 1/count of the rows and
  * two all-to-alls move the blocks.  Sequence per prove, on every rank:
  *     groth16_dist_stage1(wtns)  →  all-to-all(send, recv)  →  groth16_dist_stage2()  →  all-to-all(send, recv)
- *     →  groth16_commitments(wtns = NULL)         (finishes with the size-n/count forward transform and the five MSMs)
+ *     →  groth16_dist_exchange_done()  →  groth16_commitments(wtns = NULL)
+ *                                                  (finishes with the size-n/count forward transform and the five MSMs)
  * The buffers are device memory owned by the cache entry: 3 rows of row_bytes; the chunk a rank exchanges with `peer` for
  * row `q` sits at q·row_bytes + peer·chunk_bytes in BOTH the send and the receive buffer.  groth16_dist_supported tells
  * whether the entry can take this path (otherwise groth16_commitments alone does everything, replicated). */
@@ -84,6 +103,10 @@ int groth16_dist_supported(Groth16CacheManager* cm, const char* key);
 int groth16_dist_stage1(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, void** d_send,
                         void** d_recv, uint32_t* rows, uint64_t* row_bytes, uint64_t* chunk_bytes);
 int groth16_dist_stage2(Groth16CacheManager* cm, const char* key, void** d_send, void** d_recv);
+/* The caller confirms that the second all-to-all has DELIVERED into *d_recv of groth16_dist_stage2.  Only after this call
+ * does groth16_commitments(wtns = NULL) finish from those rows; without it (an exchange that failed, a retry) the
+ * commitments call recomputes the whole front end itself, replicated.  A new witness clears the confirmation. */
+int groth16_dist_exchange_done(Groth16CacheManager* cm, const char* key);
 
 /* Element-wise group sum of `count` commitment blocks (gathered from the shards): out = Σ_k blocks[k]. */
 int groth16_sum_commitments(const uint8_t* blocks, int count, uint8_t out_points[GROTH16_COMMITMENTS_BYTES]);
@@ -113,9 +136,12 @@ typedef struct {
   uint64_t device_bytes;
   uint32_t b_bases;  /* bases the two B MSMs of this shard run over: < its wire count when the key's B side is sparse (wires
                       * whose B1/B2 base is the identity are left out), else the wire count */
-  uint32_t reserved;
+  uint32_t shards;   /* device group: number of shards (device_bytes and b_bases are sums over them); else 0 */
 } Groth16CircuitInfo;
 int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16CircuitInfo* info);
+/* the same for a caller that passes sizeof(its Groth16CircuitInfo): fields beyond info_size are not written, so a binary
+ * built against an older, shorter struct keeps working when the struct grows */
+int groth16_cache_info_sized(const Groth16CacheManager* cm, const char* key, void* info, size_t info_size);
 
 /* phase timings (HIP events) of the most recent prove of `key` through ANY entry point — groth16_prove returns none,
  * like the reference's; bench.py reads them here.  ICICLE_SNARK_QUIET=1 suppresses groth16_prove's "proof took: …" line

@@ -154,3 +154,20 @@ def test_golden_zkey_with_corrupt_point_section_is_rejected_before_the_device(K)
             cm.load("cut", bytes(z[:len(z) - 100]))
     finally:
         cm.close()
+
+
+def test_device_strings_of_groth16_prove(K, monkeypatch):
+    """device argument of groth16_prove / `prove --device` (src/lib.rs:25-31, src/main.rs:46-70): a type with an optional
+    device list; more than one device selects the in-process device group.  Parsing needs no GPU."""
+    monkeypatch.delenv("ICICLE_SNARK_DEVICES", raising=False)
+    assert K.parse_device("HIP") == [0] and K.parse_device("CUDA") == [0]
+    assert K.parse_device("HIP:3") == [3]
+    assert K.parse_device("HIP:0-7") == list(range(8))
+    assert K.parse_device("HIP:0,2,4-6") == [0, 2, 4, 5, 6]
+    assert K.parse_device("HIP:0,0,0,0") == [0, 0, 0, 0]          # several shards on one device
+    monkeypatch.setenv("ICICLE_SNARK_DEVICES", "1-2")
+    assert K.parse_device("HIP") == [1, 2] and K.parse_device("HIP:5") == [5]
+    monkeypatch.delenv("ICICLE_SNARK_DEVICES")
+    for bad in ("CPU", "CPU:0", "", "HIP:", "HIP:a", "HIP:3-1", "HIP:0,,1", "HIP:0-", "HIP:-1", "HIP:0-99", "ROCM:0"):
+        with pytest.raises(K.ProverError):
+            K.parse_device(bad)

@@ -47,6 +47,8 @@ def test_distributed_front_end_equals_single_gpu(gpu, O, N, G):
         _exchange(K, [(s[0], s[1]) for s in st], rows, rb, cb)
         st2 = [cm.dist_stage2(k) for k in keys]
         _exchange(K, st2, rows, rb, cb)
+        for k in keys:
+            cm.dist_exchange_done(k)
         blocks = b"".join(cm.commitments(k, None)[0] for k in keys)
         got, _ = cm.assemble("full", wtns, K.sum_commitments(blocks, G), 5, 9)
         assert got == want, (N, G, rep)
@@ -94,6 +96,8 @@ def test_witness_slices_and_all_gather_equal_full_uploads(gpu, O, N, G):
             rows, rb, cb = st[0][2:]
             _exchange(K, [(s[0], s[1]) for s in st], rows, rb, cb)
             _exchange(K, [cm.dist_stage2(k) for k in keys], rows, rb, cb)
+            for k in keys:
+                cm.dist_exchange_done(k)
         blocks = b"".join(cm.commitments(k, None)[0] for k in keys)
         got, _ = cm.assemble("full", wtns, K.sum_commitments(blocks, G), 5, 9)
         assert got == want, (N, G, rep)
