@@ -16,8 +16,13 @@ Workload at N = 1: BASELINE.json configs[1] — benchmark/1600k (squaring chain,
 zkey/witness generated here (no circom/snarkjs offline; icicle-snark_amd/synth.py).  `--workload aadhaar_standin` /
 `keyless_standin` run the scale-sized synthetic stand-ins of configs[3]/[4] (random sparse R1CS, bit-heavy witness;
 keyless: 2 warm-up + 10 timed proves in one process like examples/rust/src/main.rs:3-4,20-36) — labelled as stand-ins.
-With N > 1 the five MSMs are sharded by point range over the ranks (strong scaling); each rank's five partial
-commitments (576 B) are all-gathered with RCCL and summed.
+With N > 1 ONE prove is sharded over the N GPUs (strong scaling): point-range shards of the A, B1, B2, C bases, residue-class
+shards of H, the QAP front end distributed, witness in 1/N slices.  Two hosts drive the same shard pipeline and both are timed:
+  * `value`: the library's own entry — rank 0 calls groth16_prove(witness, zkey, proof, public, device = "HIP:0-(N-1)"), ONE
+    process with one host thread per GPU and device-side exchanges over xGMI (csrc/prover/multi.cpp); the other ranks of
+    the launcher only take part in the barriers;
+  * `config.prove_ms_rank_per_gpu`: one process per GPU (every rank of the launcher), exchanges through RCCL
+    (csrc/comm/rccl_comm.cpp, icicle-snark_amd/parallel.py) — the fallback for `value` if the in-process group fails.
 
 Prints ONE JSON line (rank 0): the driver's contract plus
   roofline          the dominant kernel (G1 bucket accumulation of the H MSM): algorithmic bytes / HIP-event time, and
@@ -247,6 +252,77 @@ def dropin_sequence_ms(zkey, wtns, iters=4):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def inproc_group_bench(args, K, S, dist, rank, world, zkey, wtns, N, tmpdir):
+    """N GPUs through the library's own entry: rank 0 proves with device = "HIP:0-(N-1)" (one process, one host thread per GPU,
+    csrc/prover/multi.cpp); the other ranks only take part in the barriers.  Returns (on every rank) a dict with ms_per_step …
+    or {"error": …}.  ICICLE_SNARK_BENCH_DEVICES overrides the device list (test hook for 1-GPU boxes: "0,0")."""
+    import torch
+    devices = os.environ.get("ICICLE_SNARK_BENCH_DEVICES") or f"0-{world - 1}"
+    device = f"HIP:{devices}"
+    res = {}
+    cm = None
+    try:
+        if rank == 0:
+            zkey_path, wtns_path = os.path.join(tmpdir, "g.zkey"), os.path.join(tmpdir, "g.wtns")
+            proof_path, public_path = os.path.join(tmpdir, "g_proof.json"), os.path.join(tmpdir, "g_public.json")
+            open(zkey_path, "wb").write(zkey)
+            open(wtns_path, "wb").write(wtns)
+            cm = K.CacheManager()
+            t0 = time.time()
+            cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)     # builds the device group (cold) + first prove
+            res["cold_ms"] = (time.time() - t0) * 1e3
+            key = f"{zkey_path}_{device}"
+            info = cm.info(key)
+            res.update(shards=info.shards, device_mb=info.device_bytes / 1e6)
+            log(f"device group {device}: {info.shards} shards, {info.device_bytes / 1e6:.0f} MB of device memory, built + first prove in {res['cold_ms'] / 1e3:.2f} s")
+            for _ in range(max(1, args.warmup)):
+                cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
+    except Exception as e:   # noqa: BLE001 — reported; every rank then agrees on the fallback
+        res = {"error": repr(e)[:400]}
+        log(f"in-process device group failed: {e!r}")
+    ok = torch.tensor([0 if (rank == 0 and "error" in res) else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if cm is not None:
+            cm.close()
+        K.release_domain()
+        return res if rank == 0 else {"error": "rank 0 failed"}
+    dist.barrier()
+    t0 = time.perf_counter()
+    qap = msm = 0.0
+    acc, geom = [], None
+    if rank == 0:
+        for _ in range(args.steps):
+            cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
+            tm = cm.last_timings(key)
+            qap += tm.qap_ms
+            msm += tm.msm_ms
+            prof = K.msm_profile(0)      # shard 0 runs on the calling thread: the H accumulation of its device's ring
+            acc.append(prof[0][1])
+            geom = prof[1]
+        K.check(K.lib().icicle_device_synchronize(), "sync")
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    res["ms_per_step"] = float(dt.item()) * 1e3 / args.steps
+    if rank == 0:
+        proof, public = open(proof_path).read(), open(public_path).read()
+        assert json.loads(proof)["protocol"] == "groth16"
+        res.update(proof=proof, public=public, device=device, qap_ms=qap / args.steps, msm_ms=msm / args.steps,
+                   acc_ms=sum(acc) / len(acc), acc_geom=geom)
+        med = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            cm.prove_mem(key, wtns, resident=True)
+            med.append((time.perf_counter() - t1) * 1e3)
+        res["resident_ms"] = sorted(med)[2]
+        cm.evict(key)
+        cm.close()
+        K.release_domain()
+    dist.barrier()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,9 +415,15 @@ def main():
 
     zkey, wtns, N, what, standin = workload_inputs(K, S, workload)
     keyless_loop = workload == "keyless_standin"
-    if keyless_loop and args.steps == 10 and args.warmup != 2:
-        pass
     tmpdir = tempfile.mkdtemp(prefix="isnark_bench_")
+    # N > 1, first host: the library's own multi-device entry, driven by rank 0 (see the module docstring)
+    group = None
+    if world > 1 and os.environ.get("ICICLE_SNARK_BENCH_INPROC", "1") != "0":
+        group = inproc_group_bench(args, K, S, dist, rank, world, zkey, wtns, N, tmpdir)
+        if rank == 0 and "error" not in group and not standin:
+            assert json.loads(group["public"]) == [str(pow(3, 1 << N, S.R_MOD))]
+        K.set_device("HIP", local_rank)
+    # second host (always run with N > 1; `value` falls back to it if the group failed): one process per GPU, below
     zkey_path, wtns_path = os.path.join(tmpdir, "circuit.zkey"), os.path.join(tmpdir, "witness.wtns")
     proof_path, public_path = os.path.join(tmpdir, "proof.json"), os.path.join(tmpdir, "public.json")
     if world == 1:
@@ -353,6 +435,7 @@ def main():
     t0 = time.time()
     cm.load(key, zkey, device_id=local_rank, shard_rank=rank, shard_count=world)
     cold_ms = (time.time() - t0) * 1e3
+
     info = cm.info(key)
     log(f"cache built in {time.time() - t0:.2f} s: n_vars={info.n_vars} domain={info.domain_size} n_coef={info.n_coef} "
         f"device bytes={info.device_bytes / 1e6:.0f} MB (shard {rank}/{world})")
@@ -476,9 +559,16 @@ def main():
         log("drop-in sequence:", dropin_ms, dropin_detail)
 
     out = None
+    ranks_ms_per_step = ms_per_step
+    use_group = world > 1 and group is not None and "error" not in group
+    if use_group:
+        ms_per_step = group["ms_per_step"]   # `value`: the in-process device group (rank 0's groth16_prove with a device list)
     if rank == 0:
         g = acc_geom[0]
         kern_ms = sum(acc_ms) / len(acc_ms)
+        if use_group:
+            g, kern_ms = group["acc_geom"], group["acc_ms"]
+            phases = dict(qap=group["qap_ms"] * args.steps, msm=group["msm_ms"] * args.steps)
         # algorithmic bytes of one bucket-accumulation launch: per non-zero digit one 4-B
         # sorted index + one 64-B affine base gathered; per bucket 8 B of (offset,count) + a 128-B XYZZ result
         alg_bytes = g["L"] * g["W"] * (4 + 64) + g["nbuckets"] * (8 + 128)
@@ -522,9 +612,17 @@ def main():
             "config": {"workload": f"{what}, domain 2^{info.domain_size.bit_length() - 1}, cached zkey, random r/s",
                        "timed_region": ("the reference's own (src/lib.rs:41-58): groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json) with a warm cache — "
                                         ".wtns file opened and parsed, witness over PCIe, prove, proof.json + public.json written"
-                                        if world == 1 else "host witness buffer -> commitments of this rank's shard -> all-gather -> sum -> blinding + JSON strings"),
+                                        if world == 1 else
+                                        (f"the reference's own, on a device group: rank 0 calls groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json, device = {group['device']!r}) "
+                                         "with a warm cache — one process, one host thread per GPU, device-side exchanges (csrc/prover/multi.cpp)" if use_group else
+                                         "one process per GPU: host witness buffer -> commitments of this rank's shard -> all-gather -> sum -> blinding + JSON strings")),
                        "constraints": N, "msm_sharding": f"point-range x{world}" if world > 1 else "none",
-                       "exchange": type(exch).__name__,
+                       "exchange": ("in-process device group (ICICLE_SNARK_EXCHANGE: pull kernels over peer access | hipMemcpyPeer | rccl)" if use_group else type(exch).__name__),
+                       "host": ("one process, one host thread per GPU" if use_group else ("one process per GPU" if world > 1 else "one process")),
+                       # N > 1: the other host of the same shard pipeline — one process per GPU, exchanges through type(exch)
+                       "prove_ms_rank_per_gpu": ranks_ms_per_step if world > 1 else None,
+                       "rank_per_gpu_exchange": type(exch).__name__ if world > 1 else None,
+                       "device_group": ({k: group.get(k) for k in ("device", "shards", "device_mb", "cold_ms", "resident_ms", "error")} if group else None),
                        "qap_front_end": ("distributed: rows split by residue class, two all-to-alls of 3*(n/N)*32 B per rank" if world > 1 and dist_qap[0]
                                          else ("replicated on every rank" if world > 1 else "single GPU")),
                        "witness_upload": ("1/N of the witness per rank over PCIe + in-place all-gather over the exchange" if world > 1 and shard_w[0]

@@ -32,11 +32,11 @@ sync()
 rep_host = (time.perf_counter() - t) * 1e3 / n
 if cm.dist_supported("s"):
     for _ in range(2):
-        cm.dist_stage1("s", wtns); cm.dist_stage2("s"); cm.commitments("s", None)
+        cm.dist_stage1("s", wtns); cm.dist_stage2("s"); cm.dist_exchange_done("s"); cm.commitments("s", None)
     sync()
     t1 = t2 = t3 = 0.0
     for _ in range(n):
-        a = time.perf_counter(); cm.dist_stage1("s", wtns); b = time.perf_counter(); cm.dist_stage2("s"); c = time.perf_counter()
+        a = time.perf_counter(); cm.dist_stage1("s", wtns); b = time.perf_counter(); cm.dist_stage2("s"); cm.dist_exchange_done("s"); c = time.perf_counter()
         _, tm = cm.commitments("s", None); d = time.perf_counter()
         t1 += b - a; t2 += c - b; t3 += d - c
     print("shard %d/%d distributed front end (host witness each time): stage 1 %.2f ms (upload + spmv + size-n/G inverse transform), stage 2 %.2f ms, "
@@ -46,7 +46,7 @@ if cm.dist_supported("s"):
     t0 = t1 = t2 = t3 = 0.0
     for _ in range(n):
         z = time.perf_counter(); cm.upload_witness_slice("s", wtns); cm.witness_ready("s")
-        a = time.perf_counter(); cm.dist_stage1("s", None); b = time.perf_counter(); cm.dist_stage2("s"); c = time.perf_counter()
+        a = time.perf_counter(); cm.dist_stage1("s", None); b = time.perf_counter(); cm.dist_stage2("s"); cm.dist_exchange_done("s"); c = time.perf_counter()
         _, tm = cm.commitments("s", None); d = time.perf_counter()
         t0 += a - z; t1 += b - a; t2 += c - b; t3 += d - c
     print("shard %d/%d with 1/%d witness upload: slice upload %.2f ms, stage 1 %.2f ms, stage 2 %.2f ms, finish %.2f ms; total %.2f ms + all-gather + two all-to-alls"

@@ -214,7 +214,9 @@ def test_repeated_prove_cache_loop(gpu, O, S):
 
 def test_rccl_exchange_single_rank(gpu):
     """the RCCL data plane with world size 1 (a 1-GPU box cannot host two ranks): unique id, communicator, all-gather
-    and max-reduce through csrc/comm/rccl_comm.cpp on this library's HIP runtime.  Runs in a fresh interpreter
+    and max-reduce through csrc/comm/rccl_comm.cpp on this library's HIP runtime, then the device all-to-all and the in-place
+    device all-gather on buffers of the size one of eight ranks moves, both host-synchronous (one process per GPU) and
+    enqueued on the caller's stream through communicators of ncclCommInitAll (device group in one process).  Runs in a fresh interpreter
     because our librccl must be loaded before torch's bundled one (parallel.preload_rccl)."""
     import subprocess
     code = r'''
@@ -232,6 +234,37 @@ ex = P.RcclExchange(0)
 blk = bytes(range(256)) * 2 + bytes(64)
 assert ex.allgather(blk) == blk
 assert ex.max(3.25) == 3.25
+# the two DEVICE collectives of a sharded prove at the sizes one of eight ranks moves at 1.6 M constraints: the all-to-all of
+# the distributed QAP front end (3 rows of 2^18 elements = 24 MiB) and the in-place witness all-gather (6.4 MB slice)
+import numpy as np
+rng = np.random.default_rng(5)
+rows, row_bytes = 3, (1 << 18) * 32
+payload = rng.integers(0, 256, size=rows * row_bytes, dtype=np.uint8).tobytes()
+d_send, d_recv = K.DeviceVec(rows * row_bytes), K.DeviceVec(rows * row_bytes)
+K.raw_to_device(d_send.ptr, payload)
+ex.alltoall_rows(d_send.ptr, d_recv.ptr, rows, row_bytes, row_bytes)
+assert K.raw_to_host(d_recv.ptr, rows * row_bytes) == payload
+sl = 6_400_032
+wit = rng.integers(0, 256, size=sl, dtype=np.uint8).tobytes()
+d_w = K.DeviceVec(sl)
+K.raw_to_device(d_w.ptr, wit)
+ex.allgather_device(d_w.ptr, sl)
+assert K.raw_to_host(d_w.ptr, sl) == wit
+# the same collectives the way a device group uses them (csrc/prover/multi.cpp): communicators of ncclCommInitAll, enqueued on
+# the CALLER's stream without a host wait, then read back in stream order
+import ctypes as C
+lib = ex.lib
+comms = (C.c_void_p * 1)()
+devs = (C.c_int * 1)(0)
+assert lib.icicle_snark_rccl_init_all(1, devs, comms) == 0, lib.icicle_snark_rccl_last_error()
+st = K.IcicleStream()
+K.raw_to_device(d_recv.ptr, bytes(rows * row_bytes))
+assert lib.icicle_snark_rccl_alltoall_rows_on(C.c_void_p(comms[0]), C.c_void_p(d_send.ptr), C.c_void_p(d_recv.ptr), rows, C.c_size_t(row_bytes), C.c_size_t(row_bytes), C.c_void_p(st.handle)) == 0
+assert lib.icicle_snark_rccl_allgather_device_on(C.c_void_p(comms[0]), C.c_void_p(d_w.ptr), C.c_size_t(sl), C.c_void_p(st.handle)) == 0
+st.synchronize()
+assert K.raw_to_host(d_recv.ptr, rows * row_bytes) == payload and K.raw_to_host(d_w.ptr, sl) == wit
+lib.icicle_snark_rccl_destroy(C.c_void_p(comms[0]))
+st.destroy(); d_send.free(); d_recv.free(); d_w.free()
 ex.barrier(); ex.close()
 dist.destroy_process_group()
 print("RCCL_OK", [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l][:1])
@@ -242,13 +275,14 @@ print("RCCL_OK", [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in
 
 
 def test_bench_two_ranks_on_one_gpu(gpu):
-    """bench.py's N > 1 control flow end to end under torchrun with two ranks pinned to the one GPU of the box and the
-    gloo exchange standing in for RCCL (RCCL refuses two ranks on one device): point-range shards, all-gather of the
-    576-byte blocks, group sum, blinding/JSON, max-over-ranks timing, one JSON line from rank 0."""
+    """bench.py's N > 1 control flow end to end under torchrun with two ranks pinned to the one GPU of the box: rank 0 proves
+    through the in-process device group ("HIP:0,0"), then both ranks run the rank-per-GPU host with the gloo exchange standing
+    in for RCCL (RCCL refuses two ranks on one device): point-range shards, all-gather of the 576-byte blocks, group sum,
+    blinding/JSON, max-over-ranks timing, one JSON line from rank 0."""
     import socket
     import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, ICICLE_SNARK_BENCH_DEVICE="0", ICICLE_SNARK_BENCH_EXCHANGE="gloo")
+    env = dict(os.environ, ICICLE_SNARK_BENCH_DEVICE="0", ICICLE_SNARK_BENCH_EXCHANGE="gloo", ICICLE_SNARK_BENCH_DEVICES="0,0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--constraints", "100000"]
@@ -259,11 +293,16 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["msm_sharding"] == "point-range x2"
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+    # `value` comes from the library's own entry (rank 0: groth16_prove with the device list "HIP:0,0"), the rank-per-GPU host is timed beside it
+    assert d["config"]["device_group"]["shards"] == 2 and d["config"]["device_group"].get("error") is None
+    assert d["config"]["host"].startswith("one process, one host thread per GPU") and d["config"]["prove_ms_rank_per_gpu"] > 0
 
 
 def test_benchmark_3200k_sharded_commitments(gpu, O):
-    """BASELINE config 3 (benchmark/3200k, MSMs sharded by point range) on ONE device: the partial commitments of
-    four shards sum to the unsharded ones, and the assembled proof passes the reference pairing check."""
+    """BASELINE config 3 (benchmark/3200k, MSMs sharded over 8 GPUs) through the entry a caller uses — one key over a device
+    group of EIGHT shards in one process (csrc/prover/multi.cpp; all eight "devices" are GPU 0 on this box): point-range shards
+    of A, B1, B2, C, residue-class shards of H, 1/8 witness slices + device all-gather, the distributed QAP front end with its
+    two all-to-alls.  The proof equals the unsharded prover's and the CPU oracle's and passes the reference pairing check."""
     K = gpu
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
@@ -274,14 +313,13 @@ def test_benchmark_3200k_sharded_commitments(gpu, O):
     cm.load("full", zkey)
     assert cm.info("full").domain_size == 1 << 22
     want, public, _ = cm.prove_mem("full", wtns, 5, 9)
-    blocks = b""
-    for rank in range(4):
-        cm.load(f"s{rank}", zkey, shard_rank=rank, shard_count=4)
-        blk, _ = cm.commitments(f"s{rank}", wtns)
-        blocks += blk
-        cm.evict(f"s{rank}")
-    got, _ = cm.assemble("full", wtns, K.sum_commitments(blocks, 4), 5, 9)
-    assert got == want
+    cm.evict("full")
+    cm.load_devices("g8", zkey, [0] * 8)
+    info = cm.info("g8")
+    assert info.shards == 8 and info.domain_size == 1 << 22
+    for rep in range(2):
+        got, pub, _ = cm.prove_mem("g8", wtns, 5, 9)
+        assert got == want and pub == public, rep
     assert json.loads(public) == [str(pow(3, 1 << N, S.R_MOD))]
     # … and the proof itself equals the CPU oracle's (≈ 15 s of host time at this size)
     O.calibrate_threads()
