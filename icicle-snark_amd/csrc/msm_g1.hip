@@ -9,17 +9,17 @@ thread_local float g_last_msm_ms[4] = {0, 0, 0, 0};
 
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
 {
-  const ReduceShape rs = g2 ? reduce_shape<G2::X>(pl->g, pl->L, pl->reduce_pref) : reduce_shape<G1::X>(pl->g, pl->L, pl->reduce_pref);
-  if (rs.two) {
-    // two-level reduction: four sums [TRI_C, TRI_R, LINE_C, LINE_R]; M = MARK | LO selects the matching host tail
-    if (W) *W = 2;
-    if (M) *M = MSM_TWO_LEVEL_MARK | rs.LO;
-    return 4 * (g2 ? sizeof(G2::X) : sizeof(G1::X));
+  const size_t xs = g2 ? sizeof(G2::X) : sizeof(G1::X);
+  if (M) *M = 1;
+  if (pl->g.tab) {
+    // table mode: [T | S_0 … S_{t−1}] of the bit-plane tree (msm_impl.h); *W = t
+    uint32_t t = 0;
+    while ((1u << t) < pl->nbuckets) t++;
+    if (W) *W = t;
+    return (size_t)(1 + t) * xs;
   }
-  if (W) *W = (uint32_t)pl->g.Wb;
-  if (M) *M = rs.M; // scan reduction with several workgroups per slice: the tail adds M·LL (msm_*_host_tail_tab); else 0
-  // the workgroups' partial sums are folded on the device: one element per window and kind [S | L (table mode) | LL (M > 0)]
-  return (size_t)pl->g.Wb * (g2 ? sizeof(G2::X) : sizeof(G1::X)) * (pl->g.tab ? (rs.M ? 3 : 2) : 1);
+  if (W) *W = (uint32_t)pl->g.Wb; // classic: one folded sum per window
+  return (size_t)pl->g.Wb * xs;
 }
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len, int ticket_slot)
 {
@@ -29,9 +29,9 @@ eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form,
 {
   return build_table_run<G1, FqOps>(d_points, n, from_form, g, s, d_table);
 }
-void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_projective_t* out)
+void msm_g1_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_projective_t* out)
 {
-  G1::P p = msm_host_tail_tab<G1>((const G1::X*)h_partials, Wb, M, NBb);
+  G1::P p = msm_host_tail_tab<G1>((const G1::X*)h_partials, nbits);
   memcpy(out, &p, sizeof p);
 }
 eIcicleError msm_g1_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G1>(d_points, n, from_form, s); }

@@ -1,8 +1,5 @@
 // msm_g2.hip — G2 (Fq2 coordinates) instantiation of the MSM pipeline (see msm_impl.h).
 #define ISNARK_G2_ACC_EXTERN 1
-#ifdef G2_REDUCE_MIN_BLOCKS
-#define REDUCE_MIN_BLOCKS G2_REDUCE_MIN_BLOCKS
-#endif
 #include "msm_impl.h"
 
 namespace isnark {
@@ -14,9 +11,9 @@ eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form,
 {
   return build_table_run<G2, Fq2Ops>(d_points, n, from_form, g, s, d_table);
 }
-void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_g2_projective_t* out)
+void msm_g2_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_g2_projective_t* out)
 {
-  G2::P p = msm_host_tail_tab<G2>((const G2::X*)h_partials, Wb, M, NBb);
+  G2::P p = msm_host_tail_tab<G2>((const G2::X*)h_partials, nbits);
   memcpy(out, &p, sizeof p);
 }
 eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form, hipStream_t s) { return points_to_internal_run<G2>(d_points, n, from_form, s); }

@@ -238,22 +238,6 @@ __global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* 
   }
 }
 
-// two tree sums side by side over n ≤ blockDim entries (n a power of two): the lower half of the workgroup folds sa, the
-// upper half sb (only if `both`) — log₂ n additions on the chain.  Results in sa[0], sb[0]; ends with a barrier.
-template <class C>
-__device__ __forceinline__ void block_dual_tree(typename Lazy<C>::type::X* sa, typename Lazy<C>::type::X* sb, int n, bool both)
-{
-  typedef typename Lazy<C>::type CL;
-  const int half = n >> 1;
-  const bool upper = half && (int)threadIdx.x >= half;
-  typename CL::X* arr = upper ? sb : sa;
-  const int i = upper ? (int)threadIdx.x - half : (int)threadIdx.x;
-  for (int st = half; st > 0; st >>= 1) {
-    if (i < st && (both || !upper)) arr[i] = CL::x_add(arr[i], arr[i + st]);
-    __syncthreads();
-  }
-}
-
 // "last workgroup folds": a workgroup publishes its results, takes a ticket of its window, and the one that draws the
 // last ticket sums the window's gridDim.x results — no separate fold launch, whose waves (392 registers for G2) could only
 // start on a SIMD that the running accumulations had drained completely (G2 fold at 1.6 M constraints: 1.4 ms, nearly
@@ -272,25 +256,23 @@ __device__ __forceinline__ bool last_workgroup_of_window(uint32_t* tickets)
   return true;
 }
 
-// Σ_b (b+1)·B_b per window.  grid = (workgroups per window, W); each thread owns K = 2^k_log buckets.
-// Buckets arrive in the internal encoding; the window sums leave as ec.h XYZZ (Montgomery R = 2^256) for the tails:
-// out = [Σ_b (b+1)·B_b | Σ_b B_b (emit_line: table mode, the windows are slices of ONE bucket set and the tail needs both)].
+// Σ_b (b+1)·B_b per window of the CLASSIC layout.  grid = (workgroups per window, W); each thread owns K = 2^k_log buckets.
+// Buckets arrive in the internal encoding; the window sums leave as ec.h XYZZ (Montgomery R = 2^256) for the tails.
 // raw / tickets: scratch for the per-workgroup results (internal encoding) and one zeroed counter per window, used when
-// gridDim.x > 1.
+// gridDim.x > 1.  (Table mode — the prover's cached keys — reduces its single bucket set with msm_zeta_reduce_kernel.)
 template <class C>
-__global__ __launch_bounds__(256, REDUCE_MIN_BLOCKS) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ out, int emit_line,
-                                                                typename C::X* raw, uint32_t* tickets)
+__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ out, typename C::X* raw, uint32_t* tickets)
 {
   typedef typename Lazy<C>::type CL;
   typedef typename CL::X X;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   X* sh = reinterpret_cast<X*>(smem);
-  X* sb = sh + blockDim.x;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // thread within the window
   const uint32_t base = t << k_log;
   const typename C::X* B = buckets + (size_t)blockIdx.y * NB + base;
+  X tri = CL::x_zero();
   {
-    X line = CL::x_zero(), tri = CL::x_zero();
+    X line = CL::x_zero();
     for (int j = (1 << k_log) - 1; j >= 0; j--) {
       line = CL::x_add(line, CL::x_load_internal(B[j]));
       tri = CL::x_add(tri, line);
@@ -304,33 +286,115 @@ __global__ __launch_bounds__(256, REDUCE_MIN_BLOCKS) void msm_bucket_reduce_kern
       }
       tri = CL::x_add(tri, m);
     }
-    sh[threadIdx.x] = tri;
-    if (emit_line) sb[threadIdx.x] = line;
   }
-  __syncthreads();
-  block_dual_tree<C>(sh, sb, (int)blockDim.x, emit_line != 0);
-  const size_t nw = gridDim.y, bpw = gridDim.x;
+  tri = block_reduce_lazy<C>(tri, sh, (int)blockDim.x);
+  const size_t bpw = gridDim.x;
   if (bpw == 1) {
-    if (threadIdx.x == 0) {
-      out[blockIdx.y] = CL::x_store(sh[0]);
-      if (emit_line) out[nw + blockIdx.y] = CL::x_store(sb[0]);
-    }
+    if (threadIdx.x == 0) out[blockIdx.y] = CL::x_store(tri);
     return;
   }
-  if (threadIdx.x == 0) {
-    raw[(size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(sh[0]);
-    if (emit_line) raw[nw * bpw + (size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(sb[0]);
-  }
+  if (threadIdx.x == 0) raw[(size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(tri);
   if (!last_workgroup_of_window(tickets)) return;
-  if (threadIdx.x < bpw) {
-    sh[threadIdx.x] = CL::x_load_internal(raw[(size_t)blockIdx.y * bpw + threadIdx.x]);
-    if (emit_line) sb[threadIdx.x] = CL::x_load_internal(raw[nw * bpw + (size_t)blockIdx.y * bpw + threadIdx.x]);
+  X v = threadIdx.x < bpw ? CL::x_load_internal(raw[(size_t)blockIdx.y * bpw + threadIdx.x]) : CL::x_zero();
+  int width = 1;
+  while ((size_t)width < bpw) width <<= 1;
+  __syncthreads();
+  v = block_reduce_lazy<C>(v, sh, width);
+  if (threadIdx.x == 0) out[blockIdx.y] = CL::x_store(v);
+}
+
+// ---- bit-plane tree reduction (table mode) ----------------------------------------------------------------------------
+// Table mode has ONE bucket set of NB = 2^t buckets per MSM and needs  Σ_b (b + 1)·B_b = T + Σ_{j<t} 2^j·S_j  with the plain sum
+// T = Σ_b B_b and the bit-plane sums S_j = Σ_{b : bit j of b set} B_b: t + 1 PLAIN sums — no per-thread running-sum pair, no
+// double-and-add by the thread's first index, no suffix scan — and the t doublings of the Horner form are left to the host tail
+// (one core: ≈ 30 µs for G1, 90 µs for G2).  All t + 1 sums come out of one pruned superset-sum ("zeta") transform: a workgroup
+// holds M = 2^m buckets in LDS; stage j (from m − 1 down to 0) adds the upper half of every live group of 2^(j+1) entries into
+// its lower half, and the upper half of group 0 — still holding its values from before the addition — stays behind as the
+// new group of bit j: after stage 0, a[0] = T and a[2^j] = S_j of the block.  (m − j)·2^j additions at stage j: 2M per block,
+// the same 2·NB additions as a running-sum reduction, but a dependent chain of m additions per level instead of 2K + ≈ 25 + 2·8:
+//   level 1  blocks of 256 buckets          → R1[i][block],   i = 0 (total), 1 + j (bit j)                       (chain: 8)
+//   level 2  the same transform over the blocks of every R1[i][·] row                                               (chain: 8)
+//   final    the workgroup that draws the last ticket of level 2 sums the ≤ 8 level-2 blocks:                        (chain: 3)
+//            low bits from row 1 + j's totals, middle bits from row 0's bit sums, high bits from subsets of row 0's totals.
+// The reference halves the bucket count per launch and doubles the window count (cuda_msm.cuh:821-956: log c launches of
+// dependent additions); the three table-mode reductions this replaces (per-thread triangle sums, suffix scans for small
+// sets, row / column sums) had chains of 56, 34 and 26 additions.  Measured on MI355X, G1 / G2 set of 2^19 buckets alone:
+// see DESIGN.md §3.2-5.
+constexpr int ZR_LOG = 8, ZR_M = 1 << ZR_LOG, ZR_T = ZR_M / 2, ZR_OUT = ZR_LOG + 1;
+
+// in: `gridDim.y` rows of n entries (internal encoding; entries ≥ n count as the identity), row r at in + r·n.
+// out[(r·ZR_OUT + i)·gridDim.x + block]: the block's total (i = 0) and bit sums (i = 1 + j), internal encoding.
+// final_out != nullptr (level 2 of `nsets` bucket sets, rows = nsets × ZR_OUT): the last workgroup writes, per set,
+// [T | S_0 … S_{nbits−1}] as ec.h XYZZ (Montgomery R = 2^256) for the host tail.
+template <class C>
+__global__ __launch_bounds__(ZR_T) void msm_zeta_reduce_kernel(const typename C::X* __restrict__ in, uint32_t n, typename C::X* __restrict__ out, uint32_t* ticket, int nbits,
+                                                               typename C::X* __restrict__ final_out)
+{
+  typedef typename Lazy<C>::type CL;
+  typedef typename CL::X X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* a = reinterpret_cast<X*>(smem); // ZR_M entries
+  const uint32_t tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x, row = blockIdx.y;
+  {
+    const uint32_t e0 = blk * ZR_M + tid, e1 = e0 + ZR_T;
+    const typename C::X* src = in + (size_t)row * n;
+    const X x1 = e1 < n ? CL::x_load_internal(src[e1]) : CL::x_zero();
+    const X x0 = e0 < n ? CL::x_load_internal(src[e0]) : CL::x_zero();
+    a[tid] = CL::x_add(x0, x1); // stage m − 1
+    a[tid + ZR_T] = x1;
+  }
+  for (int j = ZR_LOG - 2; j >= 0; j--) {
+    __syncthreads();
+    const uint32_t active = (uint32_t)(ZR_LOG - j) << j;
+    if (tid < active) {
+      const uint32_t gi = tid >> j, y = tid & ((1u << j) - 1);
+      const uint32_t p = (gi ? (1u << (j + gi)) : 0u) + y;
+      a[p] = CL::x_add(a[p], a[p + (1u << j)]);
+    }
   }
   __syncthreads();
-  block_dual_tree<C>(sh, sb, (int)bpw, emit_line != 0);
-  if (threadIdx.x == 0) {
-    out[blockIdx.y] = CL::x_store(sh[0]);
-    if (emit_line) out[nw + blockIdx.y] = CL::x_store(sb[0]);
+  if (tid < ZR_OUT) out[((size_t)row * ZR_OUT + tid) * nblk + blk] = CL::x_store_internal(a[tid ? (1u << (tid - 1)) : 0u]);
+  if (!final_out) return;
+  // ---- last workgroup of level 2: the sums over the ≤ 8 level-2 blocks
+  __shared__ uint32_t s_last;
+  if (tid == 0) {
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const uint32_t nsets = gridDim.y / ZR_OUT, nout = 1u + (uint32_t)nbits;
+  // R2(r1, i2, b2) with r1 = set·ZR_OUT + i1: what level 2 wrote for level-1 row i1 of the set
+  auto R2 = [&](uint32_t set, uint32_t i1, uint32_t i2, uint32_t b2) -> X {
+    if (b2 >= nblk) return CL::x_zero();
+    return CL::x_load_internal(out[((size_t)(set * ZR_OUT + i1) * ZR_OUT + i2) * nblk + b2]);
+  };
+  for (uint32_t set = 0; set < nsets; set++) {
+    // output q: 0 = T, 1 + j = S_j;  four threads per output, each adding two of the ≤ 8 terms, then a two-level tree
+    for (uint32_t q0 = 0; q0 < nout; q0 += ZR_T / 4) {
+      const uint32_t q = q0 + tid / 4, k = tid & 3;
+      X v = CL::x_zero();
+      if (q < nout) {
+        uint32_t i1 = 0, i2 = 0, hb = 0xffffffffu; // hb: only blocks with this bit set (high bits)
+        if (q >= 1) {
+          const uint32_t j = q - 1;
+          if (j < (uint32_t)ZR_LOG) i1 = 1 + j;
+          else if (j < 2u * ZR_LOG) i2 = 1 + (j - ZR_LOG);
+          else hb = j - 2u * ZR_LOG;
+        }
+        const bool t0 = hb == 0xffffffffu || ((k >> hb) & 1), t1 = hb == 0xffffffffu || (((k + 4) >> hb) & 1);
+        const X u0 = t0 ? R2(set, i1, i2, k) : CL::x_zero();
+        const X u1 = t1 ? R2(set, i1, i2, k + 4) : CL::x_zero();
+        v = CL::x_add(u0, u1);
+      }
+      __syncthreads();
+      a[tid] = v;
+      __syncthreads();
+      if (k < 2) a[tid] = v = CL::x_add(v, a[tid + 2]);
+      __syncthreads();
+      if (k == 0 && q < nout) final_out[(size_t)set * nout + q] = CL::x_store(CL::x_add(v, a[tid + 1]));
+    }
   }
 }
 
@@ -515,22 +579,13 @@ struct AccumulateLauncher<G2> {
 };
 #endif
 
-// scalar vectors up to this length leave the GPU far from full (cf. the H stream rule of the prover): the bucket
-// reduction is then a pure latency chain and the suffix-scan kernels shorten it (100 k constraints: 2.70 → 2.43 ms per
-// prove); beyond, their blockDim·log₂ extra additions cost more than the chain saves (1.6 M: 16.85 → 17.2 ms)
-constexpr uint32_t MSM_SCAN_REDUCE_MAX_L = 1u << 19;
+// classic layout: geometry of msm_bucket_reduce_kernel
 struct ReduceShape {
   int k_log;
   uint32_t tpw, rblock, bpw;
-  bool scan;  // small table-mode bucket set: suffix-scan kernels, factor M = rblock << k_log left to the host tail
-  uint32_t M; // 0 unless scan && bpw > 1
-  // large table-mode bucket set: row / column sums, then the scan kernel on the LO + HI sums (msm_reduce_rows_kernel …)
-  bool two;
-  uint32_t LO, HI, gy; // bucket b = h·LO + l;  gy = row groups of the column-sum kernel
 };
-constexpr uint32_t MSM_TWO_LEVEL_MARK = 0x80000000u; // msm_partials_bytes: M = MARK | LO tells the host tail which layout it gets
 template <class X>
-ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu, int pref = 0)
+ReduceShape reduce_shape(const MsmGeom& g)
 {
   ReduceShape r;
   int lnb = 0;
@@ -543,210 +598,15 @@ ReduceShape reduce_shape(const MsmGeom& g, uint32_t L = 0xffffffffu, int pref = 
   if (k < 0) k = 0;
   if (k > 4) k = 4;
   const uint32_t rb_max = sizeof(X) > 128 ? 128 : 256;   // LDS tree buffer ≤ 36 KiB
-  while (k < 4 && (uint64_t)g.Wb * (g.NBb >> k) / rb_max > 128) k++; // ≤ 128 partial sums per kind for the host tail
-  // (8 buckets per thread — twice the threads — was measured for both curves: stand-in circuits 6.1 → 5.9 ms, benchmark/1600k
-  //  16.3 → 16.7 ms: the reductions are latency chains that run beside the accumulations, whose SIMDs they would take)
-  // the prover's LAST MSM (pref == 1: H) reduces on an otherwise idle GPU and its reduction is the tail of the prove: 8 buckets per thread
-  // (a chain of 16 + 16 + 10 instead of 32 + 16 + 8 additions on twice the threads): −0.1 ms at 1.6 M constraints; 4 per thread: none
-  if (pref == 1 && k > 3) k = 3;
+  while (k < 4 && (uint64_t)g.Wb * (g.NBb >> k) / rb_max > 128) k++;
   r.k_log = k < lnb ? k : lnb;
   for (;; r.k_log++) {
-    r.tpw = g.NBb >> r.k_log;                            // reduce threads per (pseudo-)window
+    r.tpw = g.NBb >> r.k_log;                            // reduce threads per window
     r.rblock = r.tpw < rb_max ? r.tpw : rb_max;
     r.bpw = r.tpw / r.rblock;
     if (r.bpw <= r.rblock) break; // the workgroup that finishes a window last folds its bpw results with one thread each
   }
-  static const uint32_t scan_max_l = getenv("ICICLE_SNARK_SCAN_REDUCE_MAX_L") ? (uint32_t)atoll(getenv("ICICLE_SNARK_SCAN_REDUCE_MAX_L")) : MSM_SCAN_REDUCE_MAX_L;
-  r.scan = g.tab && L <= scan_max_l;
-  r.M = r.scan && r.bpw > 1 ? r.rblock << r.k_log : 0;
-  // Opt-in (ICICLE_SNARK_REDUCE_TWO_LEVEL=1): interleaved A/B runs of benchmark/1600k on MI355X put it within ±0.15 ms of
-  // the single kernel (16.2–16.5 ms either way) — it does half the additions on 4–8× the threads, but its four dependent
-  // launches are as long as the single kernel's chain when the GPU is otherwise idle (0.8 vs 0.5 ms at the end of a prove).
-  static const bool two_cfg = getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL") && atoi(getenv("ICICLE_SNARK_REDUCE_TWO_LEVEL")) != 0;
-  const uint32_t nb_all = g.NBb * (uint32_t)g.Wb;
-  int nbits = 0;
-  while ((1u << nbits) < nb_all) nbits++;
-  r.two = two_cfg && pref != 1 && g.tab && !r.scan && nbits >= 14 && nbits <= 20 && (1u << nbits) == nb_all;
-  r.LO = r.HI = r.gy = 0;
-  if (r.two) {
-    r.LO = 1u << ((nbits + 1) / 2);
-    r.HI = nb_all / r.LO;
-    r.gy = r.HI / 32 ? r.HI / 32 : 1; // 4 row groups of ≤ 8 rows per workgroup
-    if (r.gy > 16) r.gy = 16;
-  }
   return r;
-}
-
-// Suffix scan + two concurrent tree sums over one workgroup, shared by the bucket reduction and the fold of its
-// per-workgroup results.  In: sa[i] = t_i, sb[i] = l_i (i < n, n a power of two).  Out (valid in thread 0 after the
-// call): sa[0] = Σ_i t_i,  sb[0] = Σ_{i ≥ 1} i·l_i  (as Σ_{i ≥ 1} suffix_i, suffix_i = Σ_{u ≥ i} l_u — no scalar
-// multiplication), return value = Σ_i l_i.  Chain length: 2·log₂ n point additions (the lower half of the workgroup
-// sums sa while the upper half sums sb).
-template <class C>
-__device__ __forceinline__ typename Lazy<C>::type::X block_weighted_sums(typename Lazy<C>::type::X* sa, typename Lazy<C>::type::X* sb, int n)
-{
-  typedef typename Lazy<C>::type CL;
-  typedef typename CL::X X;
-  const int tid = threadIdx.x;
-  X suf = sb[tid];
-  for (int d = 1; d < n; d <<= 1) {
-    const bool has = tid + d < n;
-    X o = suf;
-    if (has) o = sb[tid + d];
-    __syncthreads();
-    if (has) {
-      suf = CL::x_add(suf, o);
-      sb[tid] = suf;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) sb[0] = CL::x_zero(); // weight 0
-  __syncthreads();
-  const int half = n >> 1;
-  const bool upper = half && tid >= half;
-  X* arr = upper ? sb : sa;
-  const int i = upper ? tid - half : tid;
-  for (int st = half; st > 0; st >>= 1) {
-    if (i < st) arr[i] = CL::x_add(arr[i], arr[i + st]);
-    __syncthreads();
-  }
-  return suf; // thread 0: Σ l_i
-}
-
-// Bucket reduction for SMALL bucket sets in table mode (the GPU is far from full and only the length of the dependent
-// chain counts), grid = (workgroups per window, windows), each thread owns K = 2^k_log consecutive buckets.
-// Workgroup (x, y) covers the M = blockDim·K buckets i of window y behind x·M and emits
-//   TRI = Σ_i (i+1)·B_i  (i local to the workgroup)   and   LINE = Σ_i B_i,
-// so that the window's Σ_b (b+1)·B_b = Σ_x TRI_x + M·Σ_x x·LINE_x — the weights of whole threads / workgroups come
-// from suffix sums (block_weighted_sums), not from a double-and-add per thread: a chain of 2K + 2·log₂(blockDim) + k_log
-// additions instead of 2K + 1.5·log₂(first index) + 2·log₂(blockDim), the factor M is applied by the host tail.  The
-// suffix scan costs blockDim·log₂(blockDim) additions per workgroup, which is why the large (work-bound) bucket sets
-// stay with msm_bucket_reduce_kernel.
-// One workgroup per window: out = [TRI | LINE][window] as ec.h XYZZ (Montgomery R = 2^256) for the tails.  Several: the
-// workgroup that draws the window's last ticket folds the others' results (raw, internal encoding) into [TT | L | LL][window].
-template <class C>
-__global__ __launch_bounds__(256) void msm_bucket_reduce_scan_kernel(const typename C::X* __restrict__ buckets, uint32_t NB, int k_log, typename C::X* __restrict__ out, typename C::X* raw,
-                                                                     uint32_t* tickets)
-{
-  typedef typename Lazy<C>::type CL;
-  typedef typename CL::X X;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  X* sa = reinterpret_cast<X*>(smem);
-  X* sb = sa + blockDim.x;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // thread within the window
-  const typename C::X* B = buckets + (size_t)blockIdx.y * NB + ((size_t)t << k_log);
-  {
-    X line = CL::x_zero(), tri = CL::x_zero();
-    for (int j = (1 << k_log) - 1; j >= 0; j--) {
-      line = CL::x_add(line, CL::x_load_internal(B[j]));
-      tri = CL::x_add(tri, line);
-    }
-    sa[threadIdx.x] = tri;
-    sb[threadIdx.x] = line;
-  }
-  __syncthreads();
-  X total = block_weighted_sums<C>(sa, sb, (int)blockDim.x);
-  const size_t nw = gridDim.y, bpw = gridDim.x;
-  if (threadIdx.x == 0) {
-    X w = sb[0]; // Σ_t t·line_t; thread t's first bucket is t·K
-    for (int j = 0; j < k_log; j++) w = CL::x_dbl(w);
-    const X tri = CL::x_add(sa[0], w);
-    if (bpw == 1) {
-      out[blockIdx.y] = CL::x_store(tri);
-      out[nw + blockIdx.y] = CL::x_store(total);
-    } else {
-      raw[(size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(tri);
-      raw[nw * bpw + (size_t)blockIdx.y * bpw + blockIdx.x] = CL::x_store_internal(total);
-    }
-  }
-  if (bpw == 1 || !last_workgroup_of_window(tickets)) return;
-  // the last workgroup of the window: [TT | L | LL] = Σ_x TRI_x, Σ_x LINE_x, Σ_x x·LINE_x (the host applies M to LL)
-  if (threadIdx.x < bpw) {
-    sa[threadIdx.x] = CL::x_load_internal(raw[(size_t)blockIdx.y * bpw + threadIdx.x]);
-    sb[threadIdx.x] = CL::x_load_internal(raw[nw * bpw + (size_t)blockIdx.y * bpw + threadIdx.x]);
-  }
-  __syncthreads();
-  total = block_weighted_sums<C>(sa, sb, (int)bpw);
-  if (threadIdx.x == 0) {
-    out[blockIdx.y] = CL::x_store(sa[0]);
-    out[nw + blockIdx.y] = CL::x_store(total);
-    out[2 * nw + blockIdx.y] = CL::x_store(sb[0]);
-  }
-}
-
-// ---- two-level bucket reduction (large table-mode sets) ------------------------------------------------------------------
-// Σ_b (b+1)·B_b over ONE bucket set of NB = LO·HI buckets, b = h·LO + l:
-//     Σ_b (b+1)·B_b = Σ_l (l+1)·C_l + LO·Σ_h h·R_h,    C_l = Σ_h B[h][l] (column sums),  R_h = Σ_l B[h][l] (row sums).
-// The 2·NB additions of the row and column sums are plain sums — no per-thread scalar multiplication, chains of ≈ 12
-// additions on 128 K – 256 K threads — and the two weighted sums that remain have LO and HI ≤ 1024 terms: the suffix-scan
-// kernel (msm_bucket_reduce_scan_kernel, one workgroup each) finishes them.  msm_bucket_reduce_kernel gives every thread 16
-// buckets, a running-sum pair AND a double-and-add by its first index (≈ 30 further point operations on the chain): 32 K
-// threads, 0.49 ms for a G1 set of 2^19 buckets and 1.8 ms for G2 — latency-bound kernels whose 392-register G2 waves also
-// kept the accumulation of the next MSM off the SIMDs they sat on.
-// rows: grid = HI workgroups; a workgroup sums the LO consecutive buckets of row h (threads own LO / blockDim consecutive ones)
-template <class C>
-__global__ __launch_bounds__(256) void msm_reduce_rows_kernel(const typename C::X* __restrict__ buckets, uint32_t LO, typename C::X* __restrict__ sums /* [LO + h] */)
-{
-  typedef typename Lazy<C>::type CL;
-  typedef typename CL::X X;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  X* sh = reinterpret_cast<X*>(smem);
-  const uint32_t per = LO / blockDim.x;
-  const typename C::X* B = buckets + (size_t)blockIdx.x * LO + (size_t)threadIdx.x * per;
-  X acc = CL::x_load_internal(B[0]);
-  for (uint32_t j = 1; j < per; j++) acc = CL::x_add(acc, CL::x_load_internal(B[j]));
-  acc = block_reduce_lazy<C>(acc, sh, (int)blockDim.x);
-  if (threadIdx.x == 0) sums[LO + blockIdx.x] = CL::x_store_internal(acc);
-}
-// columns: grid = (LO / 64, gy); a workgroup of 4 waves covers 64 columns × (HI / gy) rows — wave q the rows of its quarter,
-// lane l one column (a row's 64 buckets are one contiguous 8 / 16 KiB read) — and emits 64 partial column sums
-template <class C>
-__global__ __launch_bounds__(256) void msm_reduce_cols_kernel(const typename C::X* __restrict__ buckets, uint32_t LO, uint32_t HI, typename C::X* __restrict__ partial /* [gy][LO] */)
-{
-  typedef typename Lazy<C>::type CL;
-  typedef typename CL::X X;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  X* sh = reinterpret_cast<X*>(smem); // [4][64]
-  const uint32_t lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const uint32_t col = blockIdx.x * 64 + lane;
-  const uint32_t rows_wg = HI / gridDim.y, rows_q = rows_wg / 4 ? rows_wg / 4 : 1;
-  const uint32_t h0 = blockIdx.y * rows_wg + q * rows_q;
-  X acc = CL::x_zero();
-  if (q * rows_q < rows_wg) {
-    acc = CL::x_load_internal(buckets[(size_t)h0 * LO + col]);
-    for (uint32_t j = 1; j < rows_q; j++) acc = CL::x_add(acc, CL::x_load_internal(buckets[(size_t)(h0 + j) * LO + col]));
-  }
-  sh[q * 64 + lane] = acc;
-  __syncthreads();
-  if (q < 2) sh[q * 64 + lane] = acc = CL::x_add(acc, sh[(q + 2) * 64 + lane]);
-  __syncthreads();
-  if (q == 0) partial[(size_t)blockIdx.y * LO + col] = CL::x_store_internal(CL::x_add(acc, sh[64 + lane]));
-}
-// columns, last step: C_l = Σ_y partial[y][l]; workgroup = 16 columns × 16 slots (gy ≤ 16), tree over the slots
-template <class C>
-__global__ __launch_bounds__(256) void msm_reduce_cols_final_kernel(const typename C::X* __restrict__ partial, uint32_t LO, uint32_t gy, typename C::X* __restrict__ sums /* [l] */)
-{
-  typedef typename Lazy<C>::type CL;
-  typedef typename CL::X X;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  X* sh = reinterpret_cast<X*>(smem); // [16 slots][16 columns]
-  const uint32_t c = threadIdx.x & 15, y = threadIdx.x >> 4;
-  const uint32_t col = blockIdx.x * 16 + c;
-  X acc = y < gy ? CL::x_load_internal(partial[(size_t)y * LO + col]) : CL::x_zero();
-  sh[y * 16 + c] = acc;
-  __syncthreads();
-  for (uint32_t st = 8; st > 0; st >>= 1) {
-    if (y < st) sh[y * 16 + c] = acc = CL::x_add(acc, sh[(y + st) * 16 + c]);
-    __syncthreads();
-  }
-  if (y == 0) sums[col] = CL::x_store_internal(acc);
-}
-// zero the padding of the row-sum half when HI < LO (the scan kernel treats both halves as LO-bucket windows)
-template <class C>
-__global__ __launch_bounds__(256) void msm_reduce_pad_kernel(typename C::X* __restrict__ sums, uint32_t first, uint32_t n)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) sums[first + i] = C::x_zero();
 }
 
 // more than 64 KiB of dynamic LDS (two lazy XYZZ per thread) has to be allowed once per kernel
@@ -762,7 +622,6 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
 {
   typedef typename C::X X;
   const MsmGeom& g = pl->g;
-  const ReduceShape rs = reduce_shape<X>(g, pl->L, pl->reduce_pref);
   WsScoped<X> buckets, item_partials;
   HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);
@@ -776,86 +635,65 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lds_l, s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
-  WsScoped<X> raw;
+  typedef typename Lazy<C>::type::X LX;
   WsScoped<uint32_t> own_tickets;
   uint32_t* tickets = nullptr;
-  if (rs.bpw > 1 && !rs.two) {
-    // per-workgroup results + one ticket counter per window: the workgroup that finishes a window last folds it.  The
-    // counters were zeroed with the sort's own (a memset here is one more launch on a latency chain)
-    HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw * 2, s), ICICLE_ALLOCATION_FAILED);
-    if (g.Wb <= 64 && ticket_slot >= 0 && ticket_slot < MSM_TICKET_SLOTS && pl->tickets) tickets = pl->tickets + ticket_slot * 64;
+  const bool plan_tickets = ticket_slot >= 0 && ticket_slot < MSM_TICKET_SLOTS && pl->tickets && g.Wb <= 64;
+  if (g.tab) {
+    // table mode: bit-plane tree over the single bucket set (msm_zeta_reduce_kernel) → [T | S_0 … S_{t−1}] for the host tail
+    const uint32_t n1 = pl->nbuckets, nblk1 = (n1 + ZR_M - 1) / ZR_M, nblk2 = (nblk1 + ZR_M - 1) / ZR_M;
+    int nbits = 0;
+    while ((1u << nbits) < n1) nbits++;
+    if (nblk2 > 8 || (1u << nbits) != n1) {
+      set_last_error("msm: bucket set of %u is outside the table-mode reduction's range", n1);
+      return ICICLE_INVALID_ARGUMENT;
+    }
+    WsScoped<X> r1, r2;
+    HIP_TRY(r1.alloc((size_t)ZR_OUT * nblk1, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(r2.alloc((size_t)ZR_OUT * ZR_OUT * nblk2, s), ICICLE_ALLOCATION_FAILED);
+    if (plan_tickets) tickets = pl->tickets + ticket_slot * 64; // zeroed by the sort (a memset here is one more launch on a latency chain)
+    else {
+      HIP_TRY(own_tickets.alloc(1, s), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(hipMemsetAsync(own_tickets.p, 0, sizeof(uint32_t), s), ICICLE_UNKNOWN_ERROR);
+      tickets = own_tickets.p;
+    }
+    const size_t lds_z = (size_t)ZR_M * sizeof(LX);
+    allow_big_lds(msm_zeta_reduce_kernel<C>, lds_z);
+    hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk1, 1), dim3(ZR_T), lds_z, s, buckets.p, n1, r1.p, (uint32_t*)nullptr, 0, (X*)nullptr);
+    hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk2, ZR_OUT), dim3(ZR_T), lds_z, s, r1.p, nblk1, r2.p, tickets, nbits, d_partials);
+    ICICLE_TRY(check_launch("msm_zeta_reduce"));
+    return ICICLE_SUCCESS;
+  }
+  const ReduceShape rs = reduce_shape<X>(g);
+  WsScoped<X> raw;
+  if (rs.bpw > 1) {
+    // per-workgroup results + one ticket counter per window: the workgroup that finishes a window last folds it
+    HIP_TRY(raw.alloc((size_t)g.Wb * rs.bpw, s), ICICLE_ALLOCATION_FAILED);
+    if (plan_tickets) tickets = pl->tickets + ticket_slot * 64;
     else {
       HIP_TRY(own_tickets.alloc((size_t)g.Wb, s), ICICLE_ALLOCATION_FAILED);
       HIP_TRY(hipMemsetAsync(own_tickets.p, 0, (size_t)g.Wb * sizeof(uint32_t), s), ICICLE_UNKNOWN_ERROR);
       tickets = own_tickets.p;
     }
   }
-  typedef typename Lazy<C>::type::X LX;
-  const size_t lds_r = 2 * (size_t)rs.rblock * sizeof(LX);
-  if (rs.two) {
-    // row sums | column sums → [C_0 … C_{LO−1} | R_0 … R_{HI−1}, 0 …] → the scan kernel on two LO-bucket windows:
-    // out = [Σ(l+1)·C_l, Σ(h+1)·R_h | Σ C_l, Σ R_h]; the host tail forms TRI_C + LO·(TRI_R − LINE_R)
-    WsScoped<X> sums, partial;
-    HIP_TRY(sums.alloc(2 * (size_t)rs.LO, s), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(partial.alloc((size_t)rs.gy * rs.LO, s), ICICLE_ALLOCATION_FAILED);
-    uint32_t rb = sizeof(X) > 128 ? 128 : 256; // LDS tree buffer ≤ 36 KiB
-    if (rb > rs.LO) rb = rs.LO;
-    hipLaunchKernelGGL((msm_reduce_rows_kernel<C>), dim3(rs.HI), dim3(rb), rb * sizeof(LX), s, buckets.p, rs.LO, sums.p);
-    allow_big_lds(msm_reduce_cols_kernel<C>, 256 * sizeof(LX));
-    allow_big_lds(msm_reduce_cols_final_kernel<C>, 256 * sizeof(LX));
-    hipLaunchKernelGGL((msm_reduce_cols_kernel<C>), dim3(rs.LO / 64, rs.gy), dim3(256), 256 * sizeof(LX), s, buckets.p, rs.LO, rs.HI, partial.p);
-    hipLaunchKernelGGL((msm_reduce_cols_final_kernel<C>), dim3(rs.LO / 16), dim3(256), 256 * sizeof(LX), s, partial.p, rs.LO, rs.gy, sums.p);
-    if (rs.HI < rs.LO) hipLaunchKernelGGL((msm_reduce_pad_kernel<C>), dim3((rs.LO - rs.HI + 255) / 256), dim3(256), 0, s, sums.p, rs.LO + rs.HI, rs.LO - rs.HI);
-    const uint32_t sblock = sizeof(X) > 128 ? 128 : 256;
-    int sk = 0;
-    while ((sblock << sk) < rs.LO) sk++;
-    const size_t lds_s = 2 * (size_t)sblock * sizeof(LX);
-    allow_big_lds(msm_bucket_reduce_scan_kernel<C>, lds_s);
-    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(1, 2), dim3(sblock), lds_s, s, sums.p, rs.LO, sk, d_partials, (X*)nullptr, (uint32_t*)nullptr);
-    ICICLE_TRY(check_launch("msm_bucket_reduce (two-level)"));
-    return ICICLE_SUCCESS;
-  }
-  if (rs.scan) {
-    // small table-mode set: [TT | L | LL] (LL only with more than one workgroup per slice; the host applies M)
-    allow_big_lds(msm_bucket_reduce_scan_kernel<C>, lds_r);
-    hipLaunchKernelGGL((msm_bucket_reduce_scan_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, raw.p, tickets);
-  } else {
-    allow_big_lds(msm_bucket_reduce_kernel<C>, lds_r);
-    hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, g.tab, raw.p, tickets);
-  }
+  const size_t lds_r = (size_t)rs.rblock * sizeof(LX);
+  allow_big_lds(msm_bucket_reduce_kernel<C>, lds_r);
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, raw.p, tickets);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
 }
 
-// host tail, table mode: partials = [S | L | LL][slice] for the Wb slices (NBb buckets each) of the single bucket set:
-// S_v the slice's own weighted sum (short by M·LL_v when the scan kernels ran: M = buckets per reduction workgroup, a
-// power of two, else 0 and no LL), L_v = T_v its plain sum;  Σ_b (b+1)·B_b = Σ_v S_v + NBb · Σ_v v·T_v
+// host tail, table mode: part = [T | S_0 … S_{t−1}] of msm_zeta_reduce_kernel;  Σ_b (b+1)·B_b = T + Σ_j 2^j·S_j (Horner from the top bit)
 template <class C>
-typename C::P msm_host_tail_tab(const typename C::X* part, uint32_t Wb, uint32_t M, uint32_t NBb)
+typename C::P msm_host_tail_tab(const typename C::X* part, uint32_t nbits)
 {
   typedef typename C::X X;
-  if (M & MSM_TWO_LEVEL_MARK) {
-    // two-level reduction: part = [Σ(l+1)·C_l, Σ(h+1)·R_h, Σ C_l, Σ R_h];  Σ_b (b+1)·B_b = part[0] + LO·(part[1] − part[3])
-    X U = C::x_add(part[1], C::x_neg(part[3]));
-    for (uint32_t m = M & ~MSM_TWO_LEVEL_MARK; m > 1; m >>= 1) U = C::x_dbl(U);
-    return C::p_from_mont(C::x_to_projective(C::x_add(part[0], U)));
+  X acc = C::x_zero();
+  for (int j = (int)nbits - 1; j >= 0; j--) {
+    acc = C::x_dbl(acc);
+    acc = C::x_add(acc, part[1 + j]);
   }
-  X S = C::x_zero(), run = C::x_zero(), U = C::x_zero(), LL = C::x_zero();
-  for (int v = (int)Wb - 1; v >= 0; v--) {
-    S = C::x_add(S, part[v]);
-    if (M) LL = C::x_add(LL, part[2 * (size_t)Wb + v]);
-    if (v >= 1) {
-      run = C::x_add(run, part[(size_t)Wb + v]); // Σ_{u ≥ v} T_u
-      U = C::x_add(U, run);                       // after the loop: Σ_v v·T_v
-    }
-  }
-  for (uint32_t m = NBb; m > 1; m >>= 1) U = C::x_dbl(U);
-  S = C::x_add(S, U);
-  if (M) {
-    for (uint32_t m = M; m > 1; m >>= 1) LL = C::x_dbl(LL); // one chain for all slices: Σ_v M·LL_v = M·Σ_v LL_v
-    S = C::x_add(S, LL);
-  }
-  return C::p_from_mont(C::x_to_projective(S));
+  return C::p_from_mont(C::x_to_projective(C::x_add(acc, part[0])));
 }
 
 // host tail: Σ partials per window, Horner, standard-form projective (identity → (0,1,0))
@@ -1008,11 +846,9 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     prof->c = pl.g.c;
     prof->W = pl.g.W;
     prof->is_g2 = sizeof(A) > 64;
-    const ReduceShape rs = reduce_shape<X>(pl.g);
     WsScoped<X> partials;
     const int Wt = pl.g.Wb; // windows left for the tail (= W, or ⌈W / f⌉ with precomputed bases)
     HIP_TRY(partials.alloc((size_t)Wt, s), ICICLE_ALLOCATION_FAILED);
-    (void)rs;
     const A* pts = sb.ptr<A>() + (shared ? 0 : (size_t)bi * L * stride);
     ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, 1, s, partials.p, prof)); // the sort entries index the (precomputed) base array directly
     TailSlot* slot = Wt <= 64 ? tail_slot_acquire() : nullptr;

@@ -56,9 +56,6 @@ struct SortPlan {
   uint32_t* order = nullptr;   // [nbuckets] bucket ids by decreasing entry count (wave-uniform trip counts)
   uint32_t* sorted = nullptr;  // [L·W] (index within the scalar vector) | sign << 31, grouped by bucket
   hipStream_t stream = nullptr;
-  // bucket reduction of large table-mode sets: 0 = two-level row / column sums (least work: 4 short kernels), 1 = the single
-  // kernel (one launch, shortest chain when it runs alone) — the prover asks for 1 on the MSM whose reduction ends the prove
-  int reduce_pref = 0;
   SortPlan() = default;
   SortPlan(const SortPlan&) = delete;
   SortPlan& operator=(const SortPlan&) = delete;
@@ -89,10 +86,9 @@ constexpr int MSM_PROFILE_RING = 32;
 MsmProfile* msm_profile_next();
 
 // Bucket stages for one base set on stream s (may differ from the plan's stream; the caller orders them):
-// accumulate (+ large buckets) → per-window reduction.  Writes W·bpw XYZZ partial sums (Montgomery form) to
-// d_partials (device, caller-provided, ≥ msm_partials_bytes(); table mode: per slice of the bucket set the weighted sum,
-// the plain sum and — small sets reduced by the suffix-scan kernels, M > 0 — the workgroup-weighted sum LL the tail still
-// has to scale by M, [S | L | LL][slice]; `d_points` is the table with `points_form` = 2, rows of `row_len` points).  Entries whose scalar index is < skip_below
+// accumulate (+ large buckets) → reduction.  Writes XYZZ partial sums (Montgomery form) to d_partials (device,
+// caller-provided, ≥ msm_partials_bytes(): classic layout one sum per window; table mode the plain sum T and the t bit-plane
+// sums S_j of the single bucket set; `d_points` is then the table with `points_form` = 2, rows of `row_len` points).  Entries whose scalar index is < skip_below
 // are ignored and the base index is (scalar index − skip_below): lets the C MSM (witness[n_public+1..])
 // share the witness sort.
 // `points_form` below: 0 standard form, 1 Montgomery R = 2^256 (as stored in zkey files), 2 the internal encoding of the
@@ -104,8 +100,9 @@ eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form
 // owned by the caller); `g` = msm_geometry(n_scalars, 0, 1) of the scalar vector the table will be used with.
 eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
 eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
-void msm_g1_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_projective_t* out);
-void msm_g2_host_tail_tab(const void* h_partials, uint32_t Wb, uint32_t M, uint32_t NBb, bn254_g2_projective_t* out);
+// table mode: h_partials = [T | S_0 … S_{nbits−1}] (msm_partials_bytes gives nbits as *W)
+void msm_g1_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_projective_t* out);
+void msm_g2_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_g2_projective_t* out);
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M);
 // `ticket_slot` < MSM_TICKET_SLOTS: every run of the bucket stages on one plan needs its own (the runs may overlap in time)
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0);

@@ -492,10 +492,6 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   hipStream_t gh = h_chain ? st3[h_behind] : g3;
   if (h_chain) P_HIP(hipStreamWaitEvent(gh, z->ev_sort_h, 0));
   else if (!h_own) P_HIP(hipStreamWaitEvent(gh, prof[order[h_behind]]->ev[2], 0));
-  // H's reduction is the last kernel of the prove: the single-kernel form (0.49 ms alone) even when the two-level
-  // reduction is switched on for the others
-  static const int h_reduce_pref = getenv("ICICLE_SNARK_H_REDUCE") ? atoi(getenv("ICICLE_SNARK_H_REDUCE")) : 1;
-  plan_h.reduce_pref = h_reduce_pref;
   fill(prof[4], plan_h, 0);
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
   (void)hipEventRecord(prof[4]->ev[3], gh);
@@ -531,7 +527,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[k]);
       const MsmGeom& gg = k == 4 ? gh : k == 1 ? gb : gw;
-      if (gg.tab) msm_g1_host_tail_tab(HP + k * PARTIALS_STRIDE, W, bpw, gg.NBb, (bn254_projective_t*)(out_points + off));
+      if (gg.tab) msm_g1_host_tail_tab(HP + k * PARTIALS_STRIDE, W, (bn254_projective_t*)(out_points + off));
       else msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, 1, c, gg.wide, (bn254_projective_t*)(out_points + off));
       if (et && k < 2) {
         while (!et->bl_ready.load(std::memory_order_acquire)) std::this_thread::yield();
@@ -549,7 +545,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     std::thread t2([&] {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[2]);
-      if (gb.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Wb, bw2, gb.NBb, (bn254_g2_projective_t*)(out_points + 192));
+      if (gb.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Wb, (bn254_g2_projective_t*)(out_points + 192));
       else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Wb, 1, cb, gb.wide, (bn254_g2_projective_t*)(out_points + 192));
     });
     g1tail(4, Wh, bh, ch, 480);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE prove out of a rocprofv3 --kernel-trace run (rocpd sqlite): start/end of every dispatch of
 the last complete prove relative to its first kernel, grouped by stream (queue), plus the busy-union of the GPU.
-usage: timeline_rocpd.py <dir with *_results.db> [prove index, default 4 = inside bench.py's timed loop]"""
+usage: timeline_rocpd.py <dir with *_results.db> [prove index, default 4 = inside bench.py's timed loop] [min dispatch ns to list, default 30000]"""
 import glob
 import sqlite3
 import sys
@@ -37,7 +37,7 @@ def main():
     for name, s, e, q in sel:
         short = name.split("(")[0].split("::")[-1][:60]
         tag = "G2" if "Fq2Ops" in name else ("G1" if "FqOps" in name else "")
-        if (e - s) > 30_000:
+        if (e - s) > (int(sys.argv[3]) if len(sys.argv) > 3 else 30_000):
             print(f"{q:>6} {(s - t0) / 1e6:9.3f} {(e - t0) / 1e6:9.3f} {(e - s) / 1e6:8.3f}  {short} {tag}")
     ev = sorted([(s, 1) for _, s, e, _ in sel] + [(e, -1) for _, s, e, _ in sel])
     busy, depth, last = 0, 0, None
