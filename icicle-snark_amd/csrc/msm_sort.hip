@@ -779,8 +779,7 @@ int ilog2_ceil(uint64_t x)
 // instead of c = 19 / 14.  −1: does not fit.
 static int tab_low_bits(int c, int ib, int W)
 {
-  static const int pb_max = getenv("ICICLE_SNARK_SORT_PARTITION_BITS") ? atoi(getenv("ICICLE_SNARK_SORT_PARTITION_BITS")) : 14;
-  for (int pb = 13; pb <= (pb_max < 13 ? 13 : pb_max > 14 ? 14 : pb_max); pb++) {
+  for (int pb = 13; pb <= 14; pb++) {
     int low = (c - 1) - pb;
     if (low < 0) low = 0;
     if (low > 7) continue;
@@ -842,11 +841,10 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab, int bits, int pf)
     // window leaves half of its buckets empty, so only when the top digit would be 1–3 bits short — then its entries sit in
     // 1/2 … 1/8 of a window's buckets, too few per bucket for the large-bucket path and several times the average
     // (c = 16: a 14-bit top digit); a top digit 4 or more bits short is handled by the large-bucket kernels.
-    static const bool classic_narrow = !getenv("ICICLE_SNARK_CLASSIC_NARROW") || atoi(getenv("ICICLE_SNARK_CLASSIC_NARROW")) != 0;
     const int spare = g.W * c - 254; // ≥ 0: bits the W windows cover beyond the 254 of a scalar
     // (only for full-width scalars — the argument rests on the recoded value being ≤ (r − 1)/2 — and equal windows are what
     //  the shift c·nbms of precomputed bases assumes)
-    if (bits == 254 && g.pf == 1 && c >= 5 && (g.tab || (classic_narrow && spare <= 3))) g.wide = g.W - (spare < g.W ? spare : g.W); // (a 3-bit top window would have no room for offset + carry)
+    if (bits == 254 && g.pf == 1 && c >= 5 && (g.tab || spare <= 3)) g.wide = g.W - (spare < g.W ? spare : g.W); // (a 3-bit top window would have no room for offset + carry)
   }
   uint32_t H[10] = {0};
   for (int w = 0; w < g.W; w++) {
@@ -872,11 +870,10 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   // into the low buckets of the first window: with 10 × / floor 512 the synthetic stand-in circuits spent 2 ms (G1) / 6.5 ms (G2)
   // in 500-addition chains of single threads (prove 11.2 → 6.3 ms at 1.0 M constraints, 14.1 → 8.3 ms at 1.4 M; 1.6 M uniform:
   // unchanged).  The caller's large_bucket_factor (ConfigExtension) is honoured when given.
-  static const int env_factor = getenv("ICICLE_SNARK_LARGE_FACTOR") ? atoi(getenv("ICICLE_SNARK_LARGE_FACTOR")) : 0;
-  static const uint32_t env_floor = getenv("ICICLE_SNARK_LARGE_FLOOR") ? (uint32_t)atoi(getenv("ICICLE_SNARK_LARGE_FLOOR")) : 64u;
+  constexpr uint32_t large_floor = 64u;
   const uint64_t avg = (g.tab ? (uint64_t)L * g.W : (uint64_t)L * g.pf) / g.NB + 1;
-  uint32_t thr = (uint32_t)(avg * (uint64_t)(env_factor > 0 ? env_factor : lbf > 0 ? lbf : 3));
-  if (thr < env_floor) thr = env_floor;
+  uint32_t thr = (uint32_t)(avg * (uint64_t)(lbf > 0 ? lbf : 3));
+  if (thr < large_floor) thr = large_floor;
   if (thr < 8) thr = 8;
   pl->large_thr = thr;
   const uint32_t nblocks = (nb + SCAN_B - 1) / SCAN_B;
@@ -927,13 +924,12 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   }
 
   // LDS-staged path (table mode, ≥ 2^20 entries): partitions of ≈ 25 K entries, ≤ 1024 buckets each
-  static const bool lds_sort_cfg = !(getenv("ICICLE_SNARK_LDS_SORT") && atoi(getenv("ICICLE_SNARK_LDS_SORT")) == 0);
   bool lds_sort = false;
   int s2_pb = 0, s2_low = 0;
   uint32_t s2_ntiles = 0, s2_maxchunks = 0;
   size_t s2_lds_a = 0, s2_lds_b = 0;
   uint32_t s2_hs = 1, s2_rows = 0;
-  if (lds_sort_cfg && g.tab && nentries >= (1u << 20) && g.W <= 16) {
+  if (g.tab && nentries >= (1u << 20) && g.W <= 16) {
     while ((nentries >> s2_pb) > 28000) s2_pb++;
     s2_low = (g.c - 1) - s2_pb;
     if (s2_low > 10) {

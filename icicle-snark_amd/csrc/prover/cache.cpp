@@ -25,7 +25,7 @@ ZKeyCache::~ZKeyCache()
     if (s_g3) (void)hipStreamSynchronize(s_g3);
     if (s_g4) (void)hipStreamSynchronize(s_g4);
     if (s_g5) (void)hipStreamSynchronize(s_g5);
-    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_dist_y, (void*)d_dist_recv1, (void*)d_dist_send2, (void*)d_tw1, (void*)d_partials, (void*)d_bidx, (void*)d_wb})
+    for (void* p : {(void*)d_rowptr, (void*)d_cols, (void*)d_vals, A.d_points, B1.d_points, B2.d_points, C.d_points, H.d_points, (void*)d_witness, (void*)d_vec, (void*)d_fold, (void*)d_skeys, (void*)d_dist_y, (void*)d_dist_recv1, (void*)d_dist_send2, (void*)d_tw1, (void*)d_partials})
       if (p) (void)hipFree(p);
     if (h_partials) (void)hipHostFree(h_partials);
     if (s_qap) (void)icicle_destroy_stream(s_qap);
@@ -36,7 +36,6 @@ ZKeyCache::~ZKeyCache()
     if (s_g5) (void)icicle_destroy_stream(s_g5);
     if (ev_witness) (void)hipEventDestroy(ev_witness);
     if (ev_sort) (void)hipEventDestroy(ev_sort);
-    if (ev_sort_b) (void)hipEventDestroy(ev_sort_b);
     if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
     if (ev_g2done) (void)hipEventDestroy(ev_g2done);
     if (ev_g4done) (void)hipEventDestroy(ev_g4done);
@@ -227,49 +226,6 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
   }
   lap("device CSR build");
-  {
-    // sparse B (see ZKeyCache): keep only the wires of this rank's range whose B1 or B2 base is not the identity.  Opt-in
-    // (ICICLE_SNARK_SPARSE_B=<largest density>): measured on the stand-in circuits it pays at 1.4 M constraints (8.7 → 8.0 ms) and
-    // saves table memory, but costs 0.2–0.8 ms between 0.1 M and 1.0 M — the second digit sort heads the G2 chain, the longest of
-    // a witness-light prove
-    const double max_density = getenv("ICICLE_SNARK_SPARSE_B") ? atof(getenv("ICICLE_SNARK_SPARSE_B")) : 0.0;
-    const uint32_t L = z->B1.len();
-    if (max_density > 0 && L >= 2) {
-      uint8_t* d_flags = nullptr;
-      P_HIP(hipMalloc((void**)&d_flags, L));
-      FreeTmp free_flags{d_flags};
-      P_HIP(qap_points_nonzero(z->B1.d_points, z->B2.d_points, L, d_flags, nullptr));
-      std::vector<uint8_t> flags(L);
-      P_HIP(hipMemcpy(flags.data(), d_flags, L, hipMemcpyDeviceToHost));
-      std::vector<uint32_t> idx;
-      idx.reserve(L);
-      for (uint32_t i = 0; i < L; i++)
-        if (flags[i]) idx.push_back(i);
-      const uint32_t nb = (uint32_t)idx.size();
-      if (nb >= 1 && (double)nb <= max_density * (double)L) {
-        P_HIP(hipMalloc((void**)&z->d_bidx, (size_t)nb * 4));
-        P_HIP(hipMemcpy(z->d_bidx, idx.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
-        void *c1 = nullptr, *c2 = nullptr;
-        P_HIP(hipMalloc(&c1, (size_t)nb * 64));
-        FreeTmp free_c1{c1};
-        P_HIP(hipMalloc(&c2, (size_t)nb * 128));
-        FreeTmp free_c2{c2};
-        P_HIP(qap_gather_idx(z->B1.d_points, z->d_bidx, c1, nb, 64, nullptr));
-        P_HIP(qap_gather_idx(z->B2.d_points, z->d_bidx, c2, nb, 128, nullptr));
-        P_HIP(hipStreamSynchronize(nullptr));
-        std::swap(free_c1.p, z->B1.d_points); // the dense arrays are freed at the end of this block
-        std::swap(free_c2.p, z->B2.d_points);
-        z->B1.lo = z->B2.lo = 0;
-        z->B1.hi = z->B2.hi = nb;
-        P_HIP(hipMalloc((void**)&z->d_wb, (size_t)nb * 32));
-        z->device_bytes -= (uint64_t)(L - nb) * (64 + 128);
-        z->device_bytes += (uint64_t)nb * (4 + 32);
-        z->sparse_b = true;
-        z->nb = nb;
-      }
-    }
-  }
-  lap("sparse B detection");
   // bases: the file's Montgomery form (R = 2^256) → the bucket kernels' internal encoding (R' = 2^261), once.  Table mode
   // (msm_plan.h; ICICLE_SNARK_TABLES=0 disables it): every base array becomes W rows 2^(c·w)·P so that all digits of a
   // scalar share one bucket set — 13 instead of 16 mixed additions per scalar at 1.6 M constraints for 13× the base memory.
@@ -277,28 +233,23 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
     z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
     z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
-    // the B subset keeps the digit width of the full witness set: fewer buckets would mean longer single-thread chains for the
-    // 0/1-heavy witnesses this path exists for (404 k wires, 219 k with a B base: c = 17 instead of 19 cost 1.2 ms of a 4 ms prove)
-    z->geom_b = z->sparse_b ? msm_geometry(z->nb, 0, tables ? z->geom_w.c : 0) : z->geom_w;
-    if (z->sparse_b && tables && z->geom_b.c != z->geom_w.c) z->geom_b = msm_geometry(z->nb, 0, 1);
     if (tables) {
       // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
       // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
       size_t free_b = 0, total_b = 0;
       release_cached_device_memory(); // blocks parked by icicle_free count as free
       P_HIP(hipMemGetInfo(&free_b, &total_b));
-      const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W, wb = (uint64_t)z->geom_b.W;
+      const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W, wb = ww;
       const uint64_t need = ww * ((uint64_t)z->A.len() * 64 + (uint64_t)z->C.len() * 64) + wb * (uint64_t)z->B1.len() * (64 + 128) + wh * (uint64_t)z->H.len() * 64 +
                             wb * (uint64_t)z->B2.len() * (192 + 64) + ((uint64_t)n * 128 + (uint64_t)z->n_vars * 32 + (64u << 20));
       if (need > free_b) {
         tables = false;
         z->geom_w = msm_geometry(z->A.len(), 0, 0);
         z->geom_h = msm_geometry(z->H.len(), 0, 0);
-        z->geom_b = z->sparse_b ? msm_geometry(z->nb, z->geom_w.c, 0) : z->geom_w;
       }
     }
     struct Job { Shard* sh; bool g2; const MsmGeom* g; };
-    const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_b}, {&z->B2, true, &z->geom_b}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
+    const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_w}, {&z->B2, true, &z->geom_w}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
     for (const Job& j : jobs5) {
       if (j.g->tab) {
         void* table = nullptr;
@@ -339,7 +290,6 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   }
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
-  P_HIP(hipEventCreateWithFlags(&z->ev_sort_b, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_g2done, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_g4done, hipEventDisableTiming));

@@ -184,8 +184,7 @@ __attribute__((visibility("default"))) int groth16_cache_load_file(Groth16CacheM
   if (groth16_cache_contains(cm, key)) return 0;
   MappedFile f;
   if (int rc = f.open_ro(zkey_path)) return rc;
-  static const bool file_pread = !(getenv("ICICLE_SNARK_FILE_PREAD") && atoi(getenv("ICICLE_SNARK_FILE_PREAD")) == 0);
-  if (file_pread) staged_copy_file_hint(f.data, f.len, f.fd); // sections 4-9 are pread() into the pinned staging buffers
+  staged_copy_file_hint(f.data, f.len, f.fd); // sections 4-9 are pread() into the pinned staging buffers
   const int rc = groth16_cache_load(cm, key, f.data, f.len, device_id, shard_rank, shard_count);
   staged_copy_file_hint(nullptr, 0, -1);
   return rc;
@@ -283,7 +282,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3;
   double h2d_host_ms = 0;
   bool pinned_src = false;
-  SortPlan plan_w, plan_h, plan_b; // plan_b: the B pair's own sort (sparse B only)
+  SortPlan plan_w, plan_h;
   // Declared after the plans, so it runs before their destructors, and before the first enqueue of this call: on an error
   // return the kernels already enqueued may still read the plans' workspace (which ~SortPlan hands back to the arena) or
   // the caller's pinned witness buffer — drain the six streams first.
@@ -312,8 +311,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     const auto tu = std::chrono::steady_clock::now();
     // three lanes: 51 MB in 1.4 ms, stable; with six, one upload in four stalled for ~15 ms on the GPU box (host threads
     // of this call, the MSM tails and the runtime's own compete for the container's CPU quota)
-    const hipStream_t lanes[6] = {z->s_qap, z->s_g2, z->s_g3, z->s_g1, z->s_g4, z->s_g5};
-    static const int n_lanes = getenv("ICICLE_SNARK_UPLOAD_LANES") ? std::max(1, std::min(6, atoi(getenv("ICICLE_SNARK_UPLOAD_LANES")))) : 3;
+    const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
+    const int n_lanes = 3;
     if (is_pinned_host(w.values, z->device_id)) {
       // the caller's buffer is pinned (hipHostMalloc / hipHostRegister) and mapped for this device: one DMA straight from it on
       // g1, in stream order with everything that waits for ev_witness — no staging copy, no host wait (51 MB: 0.9 instead of 1.35 ms)
@@ -335,8 +334,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   const uint32_t wlo = z->A.lo, wlen = z->A.len(), skip = npub + 1;
   MsmProfile* prof[5]; // A, B1, B2, C, H
   for (auto& p : prof) p = msm_profile_next();
-  // the witness sort is timed with the profile of the G2 MSM that follows it on g2 — of A when B2 runs on the sparse-B sort
-  MsmProfile* psort = z->sparse_b ? prof[0] : prof[2];
+  // the witness sort is timed with the profile of the G2 MSM that follows it on g2
+  MsmProfile* psort = prof[2];
   (void)hipEventRecord(psort->ev[0], g2);
   P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w, z->geom_w.tab));
   if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
@@ -344,18 +343,6 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   psort->has_sort_end = true;
   P_HIP(hipEventRecord(z->ev_sort, g2));
   mark("wsort");
-  if (z->sparse_b) {
-    // sparse B: the scalars of the wires that have a B base, gathered and sorted on B1's stream next to the witness sort
-    hipStream_t gb = z->s_g4;
-    P_HIP(hipStreamWaitEvent(gb, z->ev_witness, 0));
-    P_HIP(qap_gather_idx(z->d_witness + wlo, z->d_bidx, z->d_wb, z->nb, 32, gb));
-    P_ICICLE(msm_sort_run(z->d_wb, z->nb, z->geom_b.tab ? 0 : z->geom_b.c, 0, 0, gb, &plan_b, z->geom_b.tab ? z->geom_b.c : 0));
-    if (plan_b.g.tab != z->geom_b.tab || plan_b.g.c != z->geom_b.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the B sort");
-    P_HIP(hipEventRecord(z->ev_sort_b, gb));
-    P_HIP(hipStreamWaitEvent(g2, z->ev_sort_b, 0));
-    mark("bsort");
-  }
-  const SortPlan& plan_b12 = z->sparse_b ? plan_b : plan_w; // the plan B1 and B2 run on
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
     p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
   };
@@ -364,10 +351,6 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // ---- stream gq: construct_r1cs (src/proof_helper.rs:31-170) on the device
   hipStream_t gq = z->s_qap;
   P_HIP(hipStreamWaitEvent(gq, z->ev_witness, 0));
-  // measurement knob: the QAP chain starts behind the witness sort, so that the sort's event time (roofline.scatter) is its
-  // solo time instead of its time next to the spmv and the first transform pass
-  static const bool sort_solo = getenv("ICICLE_SNARK_SORT_SOLO") && atoi(getenv("ICICLE_SNARK_SORT_SOLO")) != 0;
-  if (sort_solo) P_HIP(hipStreamWaitEvent(gq, z->ev_sort, 0));
   // the distributed stages left this rank's Z rows in d_fold — honoured only for the witness they were computed from (no new
   // witness in this call) and only once the caller has confirmed that exchange 2 delivered (groth16_dist_exchange_done)
   const bool dist_ready = !wtns && z->dist_ready && z->H.stride > 1;
@@ -384,7 +367,6 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   int dom_log = 0;
   const fe* tw = ntt_domain_table(&dom_log);
   const fe* d_hscalars = z->d_vec + n + z->H.lo; // slot 1 of the result, this rank's range
-  static const bool fuse_cfg = !(getenv("ICICLE_SNARK_NTT_FUSE") && atoi(getenv("ICICLE_SNARK_NTT_FUSE")) == 0);
   if (z->H.stride > 1) {
     // strided H shard: coset keys, the fold over the shard count and the twist in one pass, then a size-n/G transform
     const uint32_t m = z->H.len();
@@ -392,7 +374,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       P_ICICLE(bn254_ntt((const bn254_scalar_t*)z->d_vec, (int)n, kInverse, &nc, (bn254_scalar_t*)z->d_vec)); // :116
       P_HIP(qap_coset_fold3(z->d_vec, tw, (1u << dom_log) / (2 * n), n, z->H.stride, z->H.first, z->d_fold, gq));
     }
-    if (fuse_cfg && ntt_fusable(m)) {
+    if (ntt_fusable(m)) {
       NttFuse f;
       f.fused_out = z->d_fold + m;
       P_ICICLE(ntt_fused(z->d_fold, m, 3, false, gq, f));
@@ -401,7 +383,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       P_HIP(qap_final(z->d_fold, m, gq));
     }
     d_hscalars = z->d_fold + m;
-  } else if (fuse_cfg && ntt_fusable(n)) {
+  } else if (ntt_fusable(n)) {
     // inverse transform with 1/n and the coset keys folded into its last pass (:116-141), forward transform with the
     // A·B − C epilogue folded into its last pass (:145-167): no coset sweep, no final sweep, n instead of 3n stores
     if (!z->d_skeys) {
@@ -422,12 +404,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   }
   P_HIP(hipEventRecord(z->ev[2], gq));
   mark("qap");
-  static const int early_cfg = getenv("ICICLE_SNARK_EARLY") ? atoi(getenv("ICICLE_SNARK_EARLY")) : -1;
   // Witness MSMs of small circuits (domain up to 2^19) leave the GPU far from full: they start right
   // after the witness sort instead of waiting for the QAP (200 k constraints: 3.71 → 3.51 ms, 400 k: 6.69 → 6.24 ms; the QAP
   // itself slows down — 1.1 → 3.9 ms at 400 k — which is why the large ones are held back: 800 k: 9.87 → 10.27 ms).
-  // ICICLE_SNARK_EARLY=<max scalars> moves the threshold (0 = never).
-  const uint32_t early_max = early_cfg >= 0 ? (uint32_t)early_cfg : EARLY_MAX_DEFAULT;
+  const uint32_t early_max = EARLY_MAX_DEFAULT;
   const bool early = wlen <= early_max && n <= early_max; // shards of a large circuit keep the full-size inverse transform: neutral there
   if (!early) P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
 
@@ -435,9 +415,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // fills every CU with ~4 ms workgroups, and the NTT passes of the (longer) g1 chain measured 8× slower
   // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
   if (!early) P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
-  fill(prof[2], plan_b12, 1);
-  if (z->sparse_b) (void)hipEventRecord(prof[2]->ev[0], g2);
-  P_ICICLE(msm_g2_partials(&plan_b12, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len(), 3)); // commitment_b — src/proof_helper.rs:206
+  fill(prof[2], plan_w, 1);
+  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len(), 3)); // commitment_b — src/proof_helper.rs:206
   (void)hipEventRecord(prof[2]->ev[3], g2);
   prof[2]->valid = true;
   P_HIP(hipEventRecord(z->ev_g2done, g2));
@@ -462,9 +441,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   hipStream_t st3[3] = {g1, z->s_g4, z->s_g5};
   for (int k = 0; k < 3; k++) {
     MsmProfile* p = prof[order[k]];
-    const SortPlan& pl = k == 1 ? plan_b12 : plan_w;
+    const SortPlan& pl = plan_w;
     fill(p, pl, 0);
-    P_HIP(hipStreamWaitEvent(st3[k], k == 1 && z->sparse_b ? z->ev_sort_b : z->ev_sort, 0));
+    P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
     if (k && !early) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
     if (p != psort) (void)hipEventRecord(p->ev[0], st3[k]);
     P_ICICLE(msm_g1_partials(&pl, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len(), k)); // ticket slots 0-2 of the plan (B2: 3)
@@ -476,22 +455,14 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   mark("abc");
   // H: behind one of the witness MSMs for the large circuits (measured at 1.6 M constraints: five concurrent accumulations
   // are slower than four followed by one, 17.7 vs 17.4 ms) — behind B1, whose accumulation is the first of the three G1
-  // ones to start and to finish (behind A: +0.1 ms, behind C: +0.4 ms; ICICLE_SNARK_H_BEHIND=0/1/2); on g3 right behind its own sort for the small ones and for multi-GPU
-  // shards, where the GPU is far from full and only the length of the chains counts (200 k: 4.3 → 3.9 ms)
-  static const int h_behind_cfg = getenv("ICICLE_SNARK_H_BEHIND") ? atoi(getenv("ICICLE_SNARK_H_BEHIND")) : 1; // 0 = A, 1 = B1, 2 = C
-  const int h_behind = h_behind_cfg < 0 || h_behind_cfg > 2 ? 1 : h_behind_cfg;
-  const bool h_own = z->H.len() <= (1u << 19);
-  // Large circuits: H is queued behind the whole chain of the MSM in front of it.  ICICLE_SNARK_H_AFTER=acc lets it wait
-  // only for that MSM's ACCUMULATION kernel (prof->ev[2]) on its own stream: the timeline shows ≈1 ms between the end of the
-  // four witness accumulations and the start of H's (the other MSM's empty large-bucket kernels and reduction sit in
-  // between), yet filling that gap makes the prove SLOWER — interleaved A/B on MI355X, 1.6 M constraints: 16.35–16.48 ms
-  // against 16.0–16.2 ms: H then overlaps the tails of three other accumulations, and five concurrent accumulations are
-  // less efficient than four followed by one.
-  static const bool h_after_chain = !(getenv("ICICLE_SNARK_H_AFTER") && !strcmp(getenv("ICICLE_SNARK_H_AFTER"), "acc"));
-  const bool h_chain = !h_own && h_after_chain;
+  // ones to start and to finish (behind A: +0.1 ms, behind C: +0.4 ms); on g3 right behind its own sort for the small ones and for
+  // multi-GPU shards, where the GPU is far from full and only the length of the chains counts (200 k: 4.3 → 3.9 ms).  Letting H
+  // wait only for B1's ACCUMULATION kernel instead of B1's whole chain fills a ≈ 1 ms gap in the timeline and still makes the
+  // prove slower (16.35–16.48 against 16.0–16.2 ms; DESIGN.md §4 lists this and the other schedules that were measured).
+  const int h_behind = 1;
+  const bool h_chain = z->H.len() > (1u << 19);
   hipStream_t gh = h_chain ? st3[h_behind] : g3;
   if (h_chain) P_HIP(hipStreamWaitEvent(gh, z->ev_sort_h, 0));
-  else if (!h_own) P_HIP(hipStreamWaitEvent(gh, prof[order[h_behind]]->ev[2], 0));
   fill(prof[4], plan_h, 0);
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
   (void)hipEventRecord(prof[4]->ev[3], gh);
@@ -500,10 +471,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // Each MSM's partial sums go to pinned memory on ITS OWN stream as soon as its reduction is done, and a host
   // thread per MSM waits for that copy and runs the Horner tail — the tails of the early finishers (B2, A, B1, C)
   // overlap the GPU work still in flight; only the last one (H) is exposed.
-  uint32_t Ww = 0, bw1 = 0, Wb = 0, bb1 = 0, bw2 = 0, Wh = 0, bh = 0;
-  const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), byb = msm_partials_bytes(&plan_b12, false, &Wb, &bb1), by2 = msm_partials_bytes(&plan_b12, true, &Wb, &bw2),
-               byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
-  const size_t sizes[5] = {by1, byb, by2, by1, byh};
+  uint32_t Ww = 0, bw1 = 0, Wb = 0, bw2 = 0, Wh = 0, bh = 0;
+  const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Wb, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
+  const size_t sizes[5] = {by1, by1, by2, by1, byh};
   hipStream_t st5[5] = {st3[0], st3[1], g2, st3[2], gh};
   if (h_chain) {
     // the copy of the MSM in front of H must not wait for H (same stream): its partials were complete at its ev[3], copy them on g3 instead
@@ -519,14 +489,14 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   mark("copies");
   {
     const uint8_t* HP = z->h_partials;
-    const int cw = plan_w.g.c, cb = plan_b12.g.c, ch = plan_h.g.c;
+    const int cw = plan_w.g.c, ch = plan_h.g.c;
     hipEvent_t* evd = z->ev_done;
     const int dev = z->device_id;
-    const MsmGeom gw = plan_w.g, gb = plan_b12.g, gh = plan_h.g;
+    const MsmGeom gw = plan_w.g, gh = plan_h.g;
     auto g1tail = [&](int k, uint32_t W, uint32_t bpw, int c, size_t off) {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[k]);
-      const MsmGeom& gg = k == 4 ? gh : k == 1 ? gb : gw;
+      const MsmGeom& gg = k == 4 ? gh : gw;
       if (gg.tab) msm_g1_host_tail_tab(HP + k * PARTIALS_STRIDE, W, (bn254_projective_t*)(out_points + off));
       else msm_g1_host_tail(HP + k * PARTIALS_STRIDE, W, 1, c, gg.wide, (bn254_projective_t*)(out_points + off));
       if (et && k < 2) {
@@ -540,13 +510,13 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       }
     };
     std::thread t0(g1tail, 0, Ww, bw1, cw, (size_t)0);
-    std::thread t1(g1tail, 1, Wb, bb1, cb, (size_t)96);
+    std::thread t1(g1tail, 1, Ww, bw1, cw, (size_t)96);
     std::thread t3(g1tail, 3, Ww, bw1, cw, (size_t)384);
     std::thread t2([&] {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[2]);
-      if (gb.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Wb, (bn254_g2_projective_t*)(out_points + 192));
-      else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Wb, 1, cb, gb.wide, (bn254_g2_projective_t*)(out_points + 192));
+      if (gw.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Wb, (bn254_g2_projective_t*)(out_points + 192));
+      else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Wb, 1, cw, gw.wide, (bn254_g2_projective_t*)(out_points + 192));
     });
     g1tail(4, Wh, bh, ch, 480);
     t0.join(); t1.join(); t2.join(); t3.join();
@@ -559,17 +529,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   P_HIP(hipStreamSynchronize(z->s_g5));
   P_HIP(hipStreamSynchronize(z->s_qap));
   drain.armed = false;
-  if (getenv("ICICLE_SNARK_TRACE_LARGE")) {
-    // debug: large buckets / work items / threshold of the three digit sorts of this prove
-    for (const SortPlan* pl : {(const SortPlan*)&plan_w, (const SortPlan*)&plan_b12, (const SortPlan*)&plan_h}) {
-      uint32_t nl[4] = {0, 0, 0, 0};
-      if (pl->n_large) (void)hipMemcpy(nl, pl->n_large, sizeof nl, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[large] L=%u buckets=%u thr=%u: %u large buckets, %u entries in them, %u work items (cap %u)\n", pl->L, pl->nbuckets, pl->large_thr, nl[0], nl[1], nl[2], pl->item_cap);
-    }
-  }
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
-  if (z->sparse_b) msm_sort_release(&plan_b);
   {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
@@ -852,11 +813,10 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
   }
   // the witness values go from the page cache straight into the upload workers' pinned buffers (pread) instead of being copied
   // out of the mapping, which is then only touched for the header and the public signals: −0.3 ms per prove at 1.6 M
-  // constraints (page faults of a 51 MB mapping); ICICLE_SNARK_FILE_PREAD=0 copies from the mapping
-  static const bool file_pread = !(getenv("ICICLE_SNARK_FILE_PREAD") && atoi(getenv("ICICLE_SNARK_FILE_PREAD")) == 0);
-  if (file_pread) staged_copy_file_hint(wf.data, wf.len, wf.fd);
+  // constraints (page faults of a 51 MB mapping)
+  staged_copy_file_hint(wf.data, wf.len, wf.fd);
   const int prc = groth16_prove_mem(cm, key.c_str(), wf.data, wf.len, nullptr, nullptr, pj.data(), pj.size(), qj.data(), qj.size(), nullptr);
-  if (file_pread) staged_copy_file_hint(nullptr, 0, -1);
+  staged_copy_file_hint(nullptr, 0, -1);
   if (prc) return prc;
   for (int k = 0; k < 2; k++) {
     const char* path = k ? public_path : proof_path;

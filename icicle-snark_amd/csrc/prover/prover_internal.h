@@ -94,16 +94,6 @@ struct ZKeyCache {
   // device
   int device_id = 0, shard_rank = 0, shard_count = 1;
   MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM, fixed at cache build
-  // Sparse B: a wire that never occurs on the B side of a constraint has the identity as its B1 and B2 base (snarkjs writes
-  // all-zero bytes).  One thread accumulates one bucket, so an identity base skipped inside the shared witness sort saves
-  // nothing (the other lanes of the wave still add).  Opt-in: with ICICLE_SNARK_SPARSE_B=<d> set and at most the fraction d of
-  // this rank's wires having a B base, B1/B2 hold only those nb bases (d_bidx = their wire numbers relative to A.lo), and the two
-  // B MSMs run on their own digit sort of the gathered scalars d_wb (geometry geom_b: the digit width of the full set).
-  bool sparse_b = false;
-  uint32_t nb = 0;
-  uint32_t* d_bidx = nullptr;
-  fe* d_wb = nullptr;
-  MsmGeom geom_b;
   uint32_t* d_rowptr = nullptr; // 2n+1
   uint32_t* d_cols = nullptr;   // n_coef
   fe* d_vals = nullptr;         // n_coef, Montgomery form
@@ -123,7 +113,7 @@ struct ZKeyCache {
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
-  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_b = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
+  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
              ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_xchg = nullptr; // group prove: "what the peers pull from this shard next is complete" (recorded on s_qap)
   uint64_t device_bytes = 0;

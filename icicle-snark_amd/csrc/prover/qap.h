@@ -26,11 +26,6 @@ hipError_t qap_coset_fold3(const bn254::fe* d_vec, const bn254::fe* tw, uint32_t
 // dst[k] = src[first + k·stride] for elements of `elem_fe` field elements (strided point-range shard of the H bases)
 hipError_t qap_gather_strided(const bn254::fe* src, bn254::fe* dst, uint32_t elem_fe, uint32_t count, uint32_t stride, uint32_t first, hipStream_t s);
 
-// Sparse B: flags[i] = 1 unless both the G1 base (64 B) and the G2 base (128 B) of wire i are the identity (all-zero bytes, as
-// snarkjs writes them for wires that never occur on the B side); dst[k] = src[idx[k]] for elements of elem_bytes (multiple of 16).
-hipError_t qap_points_nonzero(const void* g1_points, const void* g2_points, uint32_t n, uint8_t* flags, hipStream_t s);
-hipError_t qap_gather_idx(const void* src, const uint32_t* idx, void* dst, uint32_t count, uint32_t elem_bytes, hipStream_t s);
-
 // Distributed front end for G ∈ {2, 4, 8} GPUs (icicle-snark_amd/dist_qap.py has the algebra and its CPU restatement):
 //   stage 1  qap_spmv_strided (rows c ≡ r mod G → [B | A | A∘B] over m = n/G elements) + size-m inverse transform whose
 //            per-element scale is the table of qap_dist_tw1 (n⁻¹·ω_n^{−r·k2}); exchange 1 = all-to-all of blocks of m/G;

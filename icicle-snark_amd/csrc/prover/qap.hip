@@ -97,34 +97,6 @@ __global__ __launch_bounds__(256) void qap_gather_strided_kernel(const fe* __res
 }
 
 
-// ---- sparse B (prover.cpp: build_cache / commitments_impl): wires that never occur on the B side of a constraint have the
-// identity as their B1/B2 base; the B MSMs run over the other wires only
-__global__ __launch_bounds__(256) void qap_points_nonzero_kernel(const uint4* __restrict__ g1, const uint4* __restrict__ g2, uint32_t n, uint8_t* __restrict__ flags)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t acc = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const uint4 v = g1[(size_t)i * 4 + q];
-    acc |= v.x | v.y | v.z | v.w;
-  }
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const uint4 v = g2[(size_t)i * 8 + q];
-    acc |= v.x | v.y | v.z | v.w;
-  }
-  flags[i] = acc != 0;
-}
-// dst[k] = src[idx[k]] for elements of `quads` 16-byte words
-__global__ __launch_bounds__(256) void qap_gather_idx_kernel(const uint4* __restrict__ src, const uint32_t* __restrict__ idx, uint4* __restrict__ dst, uint32_t count, uint32_t quads)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (uint64_t)count * quads) return;
-  const uint64_t k = i / quads, c = i % quads;
-  dst[i] = src[(uint64_t)idx[k] * quads + c];
-}
-
 // ---- distributed front end (power-of-two shard count G, rank r): see qap.h / icicle-snark_amd/dist_qap.py -----------------
 // rows c ≡ r (mod G) of the spmv only: out = [B | A | A∘B] over j2 < m, c = r + G·j2
 __global__ __launch_bounds__(256) void qap_spmv_strided_kernel(const fe* __restrict__ w, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ cols,
@@ -218,19 +190,6 @@ hipError_t qap_gather_strided(const fe* src, fe* dst, uint32_t elem_fe, uint32_t
   return hipGetLastError();
 }
 
-
-hipError_t qap_points_nonzero(const void* g1_points, const void* g2_points, uint32_t n, uint8_t* flags, hipStream_t s)
-{
-  if (n) hipLaunchKernelGGL(qap_points_nonzero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)g1_points, (const uint4*)g2_points, n, flags);
-  return hipGetLastError();
-}
-hipError_t qap_gather_idx(const void* src, const uint32_t* idx, void* dst, uint32_t count, uint32_t elem_bytes, hipStream_t s)
-{
-  const uint32_t quads = elem_bytes / 16;
-  const uint64_t total = (uint64_t)count * quads;
-  if (total) hipLaunchKernelGGL(qap_gather_idx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const uint4*)src, idx, (uint4*)dst, count, quads);
-  return hipGetLastError();
-}
 
 hipError_t qap_spmv_strided(const fe* witness, const uint32_t* rowptr, const uint32_t* cols, const fe* vals, uint32_t n, uint32_t G, uint32_t r, fe* out, hipStream_t s)
 {

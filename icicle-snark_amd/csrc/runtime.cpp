@@ -175,12 +175,7 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
   // chunk size: 2 MB.  Smaller chunks for transfers of a few tens of MB (shorter pipeline fill) were measured on the 51 MB
   // witness of benchmark/1600k and are slower — 1 MB: +0.05 ms, 512 KB: +0.3 ms, 256 KB: +0.8 ms per prove (per-DMA cost);
   // two to five staging lanes make no difference either (17.3–17.5 ms): ≈ 1.3 ms for 51 MB is what this path costs
-  static const size_t small_chunk = getenv("ICICLE_SNARK_STAGE_CHUNK_KB") ? (size_t)atoll(getenv("ICICLE_SNARK_STAGE_CHUNK_KB")) << 10 : STAGED_CHUNK;
-  size_t total_bytes = 0;
-  for (size_t j = 0; j < njobs; j++) total_bytes += jobs[j].n;
-  size_t CH = total_bytes <= ((size_t)128 << 20) ? small_chunk : STAGED_CHUNK;
-  if (CH < (64u << 10)) CH = 64u << 10;
-  if (CH > STAGED_CHUNK) CH = STAGED_CHUNK;
+  const size_t CH = STAGED_CHUNK;
   std::vector<CopyJob> chunks;
   for (size_t j = 0; j < njobs; j++)
     for (size_t off = 0; off < jobs[j].n; off += CH)

@@ -134,8 +134,7 @@ int groth16_prove_resident(Groth16CacheManager* cm, const char* key, const void*
 typedef struct {
   uint32_t n_vars, n_public, domain_size, n_coef;
   uint64_t device_bytes;
-  uint32_t b_bases;  /* bases the two B MSMs of this shard run over: < its wire count when the key's B side is sparse (wires
-                      * whose B1/B2 base is the identity are left out), else the wire count */
+  uint32_t b_bases;  /* bases the two B MSMs run over (= the wires of this shard; kept for layout compatibility) */
   uint32_t shards;   /* device group: number of shards (device_bytes and b_bases are sums over them); else 0 */
 } Groth16CircuitInfo;
 int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16CircuitInfo* info);

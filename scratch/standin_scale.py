@@ -1,5 +1,5 @@
 """resident prove time of the aadhaar-style stand-in circuit at a given scale (fraction of 1.0 M constraints); the knobs of the
-library (ICICLE_SNARK_SPARSE_B …) are read at cache build"""
+library are read at cache build"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -95,15 +95,5 @@ def test_keyless_standin_cache_loop_every_proof_equals_oracle(gpu, O, S, tmp_pat
     # files in / files out through the same cache entry (the reference's entry point), random r, s: valid proof
     cm.prove_files(str(wp), str(zp), str(tmp_path / "proof.json"), str(tmp_path / "public.json"))
     assert K.groth16_verify_json((tmp_path / "proof.json").read_text(), (tmp_path / "public.json").read_text(), S.vk_to_json(vk))
-    # the sparse-B variant of the cache (opt-in: the two B MSMs over the wires that have a B base only) at this scale: same proofs
-    monkeypatch.setenv("ICICLE_SNARK_SPARSE_B", "0.9")
-    cm.load("sparse", zkey)
-    info = cm.info("sparse")
-    assert 0 < info.b_bases < 0.9 * info.n_vars
-    for i in (0, 1):
-        r, s = 1000 + i, 77 + 3 * i
-        pj, qj, _ = cm.prove_mem("sparse", wtns, r, s)
-        proof, public = O.groth16_assemble(cache, w, oc, r, s)
-        assert json.loads(pj) == proof and json.loads(qj) == public, i
     cm.close()
     K.release_domain()

@@ -235,64 +235,39 @@ def test_edge_scalars_in_the_witness(gpu, cm, O, S):
     cm.evict("edge")
 
 
-def test_optional_schedules_and_reductions_give_the_same_proof(gpu, O, S, tmp_path):
-    """the opt-in variants kept for A/B measurements (two-level bucket reduction for every MSM, H released behind the
-    accumulation kernel of the MSM in front of it, unfused NTT) must produce the oracle's proof too — each runs in its own
-    process because the library reads the knobs once"""
+def test_identity_b_bases_and_table_free_layout(gpu, O, S, tmp_path):
+    """Wires without a B-side occurrence have the identity as their B1/B2 base (snarkjs writes all-zero bytes): the bucket
+    kernels skip them.  Same proof as the oracle's with the fixed-base tables (default) and with the classic layout of a
+    memory-constrained host (ICICLE_SNARK_TABLES=0, read at cache build: its own process), and through three point-range shards."""
     import subprocess
     import sys
-    K = gpu
-    N = 70_000                                     # domain 2^17: table mode, bucket sets large enough for the two-level path
-    import importlib
-    bench = importlib.import_module("bench")
-    zkey, wtns = bench.make_inputs(K, S, N)
-    (tmp_path / "c.zkey").write_bytes(zkey)
-    (tmp_path / "w.wtns").write_bytes(wtns)
-    proof, public = O.groth16_prove(zkey, wtns, 9, 4)
-    code = (
-        "import importlib, json, sys; sys.path.insert(0, %r)\n"
-        "K = importlib.import_module('icicle-snark_amd'); K.set_device('HIP', 0)\n"
-        "cm = K.CacheManager(); cm.load('k', open(%r, 'rb').read())\n"
-        "pj, qj, _ = cm.prove_mem('k', open(%r, 'rb').read(), 9, 4); print(json.dumps([json.loads(pj), json.loads(qj)]))\n"
-    ) % (ROOT, str(tmp_path / "c.zkey"), str(tmp_path / "w.wtns"))
-    for env in ({"ICICLE_SNARK_REDUCE_TWO_LEVEL": "1", "ICICLE_SNARK_H_REDUCE": "0", "ICICLE_SNARK_SCAN_REDUCE_MAX_L": "0"},
-                {"ICICLE_SNARK_H_AFTER": "acc", "ICICLE_SNARK_EARLY": "0"}, {"ICICLE_SNARK_NTT_FUSE": "0"}):
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
-        assert out.returncode == 0, out.stderr[-2000:]
-        got = json.loads(out.stdout.strip().splitlines()[-1])
-        assert got == [proof, public], env
-
-
-def test_sparse_b_subset_equals_dense(gpu, O, S, monkeypatch):
-    """Wires without a B-side occurrence have identity B1/B2 bases; the cache then runs the two B MSMs over the other
-    wires only (their own digit sort).  Same proof, byte for byte, as with the subset switched off, equal to the oracle's;
-    the same through three point-range shards (each shard keeps its own subset)."""
     K = gpu
     r1, w = S.random_circuit(3000, 3, 40, bit_fraction=0.7)
     zkey, _ = S.setup(r1, _fbm(K), points_to_mont=lambda a: O.fq_convert_montgomery(a, True))
     wtns = S.write_wtns(w)
     r, s = 0x1234567, 0x7654321
-    out = {}
-    for mode, val in (("dense", "0"), ("sparse", "1.0")):
-        monkeypatch.setenv("ICICLE_SNARK_SPARSE_B", val)
-        c = K.CacheManager()
-        c.load("k", zkey)
-        info = c.info("k")
-        pj, qj, _ = c.prove_mem("k", wtns, r, s)
-        out[mode] = (pj, qj, info.b_bases, info.n_vars)
-        if mode == "sparse":
-            blocks = []
-            for rank in range(3):
-                c.load(f"s{rank}", zkey, shard_rank=rank, shard_count=3)
-                blocks.append(c.commitments(f"s{rank}", wtns)[0])
-            sj, sq = c.assemble("k", wtns, K.sum_commitments(b"".join(blocks), 3), r, s)[:2]
-            assert (sj, sq) == (pj, qj)
-        c.close()
-    assert out["dense"][2] == out["dense"][3]
-    assert 0 < out["sparse"][2] < out["sparse"][3], "the random circuit should leave some wires without a B base"
-    assert out["dense"][:2] == out["sparse"][:2]
     proof, public = O.groth16_prove(zkey, wtns, r, s)
-    assert json.loads(out["sparse"][0]) == proof and json.loads(out["sparse"][1]) == public
+    c = K.CacheManager()
+    c.load("k", zkey)
+    pj, qj, _ = c.prove_mem("k", wtns, r, s)
+    assert json.loads(pj) == proof and json.loads(qj) == public
+    blocks = []
+    for rank in range(3):
+        c.load(f"s{rank}", zkey, shard_rank=rank, shard_count=3)
+        blocks.append(c.commitments(f"s{rank}", wtns)[0])
+    assert c.assemble("k", wtns, K.sum_commitments(b"".join(blocks), 3), r, s)[:2] == (pj, qj)
+    c.close()
+    (tmp_path / "c.zkey").write_bytes(zkey)
+    (tmp_path / "w.wtns").write_bytes(wtns)
+    code = (
+        "import importlib, json, sys; sys.path.insert(0, %r)\n"
+        "K = importlib.import_module('icicle-snark_amd'); K.set_device('HIP', 0)\n"
+        "cm = K.CacheManager(); cm.load('k', open(%r, 'rb').read())\n"
+        "pj, qj, _ = cm.prove_mem('k', open(%r, 'rb').read(), %d, %d); print(json.dumps([json.loads(pj), json.loads(qj)]))\n"
+    ) % (ROOT, str(tmp_path / "c.zkey"), str(tmp_path / "w.wtns"), r, s)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, ICICLE_SNARK_TABLES="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == [proof, public]
 
 
 def test_mutated_witness_files_never_crash(gpu, cm):
