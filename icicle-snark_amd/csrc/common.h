@@ -180,6 +180,16 @@ struct WsScoped {
   operator T*() const { return p; }
 };
 
+// First statement of the short kernels on a prove's critical chains (QAP front end, digit sorts): raise the wave's issue
+// priority.  When the witness MSMs of a small circuit run beside them (prover.cpp: early start), an accumulation wave and a
+// transform wave share a SIMD; without the priority they split its issue slots and the chain H waits for stretches 3×
+// (100 k constraints: last transform pass 0.50 → 0.2 ms).  Neutral for the large circuits, whose QAP runs alone.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ISNARK_CRITICAL_CHAIN_KERNEL() __builtin_amdgcn_s_setprio(3)
+#else
+#define ISNARK_CRITICAL_CHAIN_KERNEL() (void)0
+#endif
+
 // finish an API call: synchronise unless the caller asked for async execution
 inline eIcicleError end_call(hipStream_t s, bool is_async)
 {

@@ -122,6 +122,7 @@ __device__ __forceinline__ uint32_t entry_idx(const MsmGeom& g, int w, uint32_t 
 // zero `n` u32 words (a kernel instead of hipMemsetAsync keeps every dependency on the compute queue)
 __global__ __launch_bounds__(256) void msm_zero_kernel(uint32_t* __restrict__ p, uint32_t n)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
 }
@@ -191,6 +192,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 
 __global__ __launch_bounds__(SCAN_T) void msm_scan_sums_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ bsum)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t sh[SCAN_T];
   const uint32_t base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_E;
   uint32_t s = 0;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(SCAN_T) void msm_scan_sums_kernel(const uint32_t* _
 }
 __global__ __launch_bounds__(SCAN_T) void msm_scan_top_kernel(uint32_t* bsum, uint32_t nblocks)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t sh[SCAN_T];
   uint32_t carry = 0;
   for (uint32_t base = 0; base < nblocks; base += SCAN_T) {
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(SCAN_T) void msm_scan_finish_kernel(const uint32_t*
                                                                   uint32_t* __restrict__ cursor, uint32_t thr, uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list,
                                                                   uint32_t* __restrict__ large_first, uint2* __restrict__ large_items, uint32_t item_cap)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t sh[SCAN_T];
   const uint32_t base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_E;
   uint32_t v[SCAN_E], s = 0;
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(SCAN_T) void msm_scan_finish_kernel(const uint32_t*
 // generic finish of the 3-kernel exclusive scan: out[i] = bsum[block] + local exclusive prefix
 __global__ __launch_bounds__(SCAN_T) void msm_scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t m, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ out)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t sh[SCAN_T];
   const uint32_t base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_E;
   uint32_t v[SCAN_E], s = 0;
@@ -277,6 +282,7 @@ constexpr int ORDER_BINS = 256;
 __device__ __forceinline__ uint32_t order_key(uint32_t cnt) { return (uint32_t)ORDER_BINS - 1 - min(cnt, (uint32_t)ORDER_BINS - 1); } // ascending key = descending size
 __global__ __launch_bounds__(ORDER_BINS) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t nblk, uint32_t* __restrict__ blockhist)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t h[ORDER_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(ORDER_BINS) void msm_order_hist_kernel(const uint32
 }
 __global__ __launch_bounds__(ORDER_BINS) void msm_order_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t m, uint32_t nblk, const uint32_t* __restrict__ scanned, uint32_t* __restrict__ order)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t h[ORDER_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -312,6 +319,7 @@ constexpr int PA_THREADS = 256, PA_PER_THREAD = 16, PA_SCALARS = PA_THREADS * PA
 __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_bits, uint32_t NP, uint32_t nparts,
                                                                     uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ tmp)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[];
   uint32_t* hist = sh;
   uint32_t* cur = sh + nparts;
@@ -364,6 +372,7 @@ __global__ __launch_bounds__(PA_THREADS) void msm_partition_kernel(const fe* __r
 __global__ __launch_bounds__(PA_THREADS) void msm_coarse_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_bits, uint32_t nparts,
                                                                       uint32_t* __restrict__ part_count)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[];
   for (uint32_t p = threadIdx.x; p < nparts; p += PA_THREADS) sh[p] = 0;
   __syncthreads();
@@ -388,6 +397,7 @@ __global__ __launch_bounds__(PA_THREADS) void msm_coarse_hist_kernel(const fe* _
 // exclusive scan of the partition totals, one workgroup (nparts ≤ 8192 = 256 threads × 32)
 __global__ __launch_bounds__(SCAN_T) void msm_part_scan_kernel(const uint32_t* __restrict__ part_count, uint32_t nparts, uint32_t* __restrict__ part_start, uint32_t* __restrict__ part_cursor)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t sh[SCAN_T];
   const uint32_t per = (nparts + SCAN_T - 1) / SCAN_T, lo = threadIdx.x * per;
   uint32_t s = 0;
@@ -406,6 +416,7 @@ __global__ __launch_bounds__(SCAN_T) void msm_part_scan_kernel(const uint32_t* _
 constexpr int PB_SPLIT = 8; // workgroups per partition (a witness-like scalar set puts a third of all entries into ONE partition)
 __global__ __launch_bounds__(256) void msm_fine_count_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, int low_bits, uint32_t* __restrict__ counts)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t hist[128];
   const uint32_t part = blockIdx.x, b0 = part << low_bits, nbk = 1u << low_bits;
   const int fs = 31 - low_bits;
@@ -429,6 +440,7 @@ __global__ __launch_bounds__(256) void msm_fine_place_kernel(const uint32_t* __r
                                                              uint32_t* __restrict__ large_list, uint32_t* __restrict__ large_first, uint2* __restrict__ large_items, uint32_t item_cap,
                                                              uint32_t* __restrict__ sorted)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t offs[128], hist[128], cur[128];
   const uint32_t part = blockIdx.x, b0 = part << low_bits, nbk = 1u << low_bits;
   const int fs = 31 - low_bits;
@@ -540,6 +552,7 @@ __device__ __forceinline__ void s2_wave_scan(const uint32_t* in, uint32_t* out, 
 // pass A, step 1: digits of a tile counted per (window group, partition): cnt[(tile·HS + h)·P + p]
 __global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t HS, uint32_t* __restrict__ cnt)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[]; // [HS][P]
   for (uint32_t p = threadIdx.x; p < HS * P; p += 256) sh[p] = 0;
   __syncthreads();
@@ -562,6 +575,7 @@ __global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restri
 // and chunk numbering), running offsets written back — every load and store coalesced over p
 __global__ __launch_bounds__(256) void sort2_col_sum_kernel(const uint32_t* __restrict__ cnt, uint32_t R, uint32_t P, uint32_t* __restrict__ partial)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const uint32_t rpg = (R + S2_RG - 1) / S2_RG, r0 = blockIdx.y * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
@@ -571,6 +585,7 @@ __global__ __launch_bounds__(256) void sort2_col_sum_kernel(const uint32_t* __re
 }
 __global__ __launch_bounds__(1024) void sort2_col_base_kernel(uint32_t* __restrict__ partial, uint32_t P, uint32_t* __restrict__ part_start, uint32_t* __restrict__ chunk_first)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t ps[4097], cf[4097]; // totals / chunk counts, scanned in place
   for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
     uint32_t run = 0;
@@ -594,6 +609,7 @@ __global__ __launch_bounds__(1024) void sort2_col_base_kernel(uint32_t* __restri
 }
 __global__ __launch_bounds__(256) void sort2_col_apply_kernel(uint32_t* __restrict__ cnt, uint32_t R, uint32_t P, const uint32_t* __restrict__ partial)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const uint32_t rpg = (R + S2_RG - 1) / S2_RG, r0 = blockIdx.y * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
@@ -608,6 +624,7 @@ __global__ __launch_bounds__(256) void sort2_col_apply_kernel(uint32_t* __restri
 __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t HS,
                                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ part_start, uint32_t* __restrict__ tmp)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[];
   uint32_t* base = sh;          // [P + 1] exclusive prefix of the row's partition counts
   uint32_t* cur = sh + P + 1;   // [P] counts / rank counters, then the global position minus the local one
@@ -677,6 +694,7 @@ __device__ __forceinline__ bool s2_chunk_of(uint32_t c, const uint32_t* __restri
 __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_hist_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, int low_b,
                                                                        uint32_t* __restrict__ chunk_hist)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t hist[1024];
   uint32_t p, start, n;
   if (!s2_chunk_of(blockIdx.x, part_start, chunk_first, P, p, start, n)) return;
@@ -694,6 +712,7 @@ __global__ __launch_bounds__(1024) void sort2_bucket_scan_kernel(const uint32_t*
                                                                   uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list, uint32_t* __restrict__ large_first, uint2* __restrict__ large_items,
                                                                   uint32_t item_cap)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   __shared__ uint32_t sc[1024];
   const uint32_t NL = 1u << low_b, p = blockIdx.x, b = threadIdx.x;
   const uint32_t c0 = chunk_first[p], c1 = chunk_first[p + 1];
@@ -730,6 +749,7 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_place_kernel(const uin
                                                                         const uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ offsets,
                                                                         const uint32_t* __restrict__ cnt, uint32_t R, uint32_t HS, MsmGeom g, uint32_t* __restrict__ sorted)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[];
   const uint32_t NL = 1u << low_b;
   uint32_t* lbase = sh;             // [NL + 1]

@@ -370,6 +370,7 @@ __device__ __forceinline__ void ntt_tile_row(const fe* __restrict__ src, fe* __r
 template <bool FUSE>
 __global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ in, fe* __restrict__ out, const fe* __restrict__ tw, PassParams p, fe ninv_mont)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int R = 1 << p.log_r, C = 1 << p.log_c, RC = R * C;
   uint4* lo = reinterpret_cast<uint4*>(smem);

@@ -2,6 +2,7 @@
 //   spmv : reads 36 B per coefficient (value + column) + one gathered 32-B witness element, writes 96 B per row
 //   coset: 3·64 B + 32 B per column;  final: 96 B read, 32 B written per element.
 #include "qap.h"
+#include "../common.h"
 
 using namespace bn254;
 
@@ -26,6 +27,7 @@ __device__ __forceinline__ void st(fe* p, const fe& v)
 __global__ __launch_bounds__(256) void qap_spmv_kernel(const fe* __restrict__ w, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ cols,
                                                         const fe* __restrict__ vals, uint32_t n, fe* __restrict__ d_vec)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   // rows c (A) and n + c (B) advance in lockstep so that the dependent loads (rowptr → column → witness) of the
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(256) void qap_final_kernel(fe* d_vec, uint32_t n)
 __global__ __launch_bounds__(256) void qap_coset_fold3_kernel(const fe* __restrict__ d_vec, const fe* __restrict__ tw, uint32_t tw_scale, uint32_t n, uint32_t G, uint32_t r,
                                                                fe* __restrict__ out)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t m = n / G;
   const uint32_t jp = blockIdx.x * blockDim.x + threadIdx.x;
   if (jp >= m) return;
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256) void qap_gather_strided_kernel(const fe* __res
 __global__ __launch_bounds__(256) void qap_spmv_strided_kernel(const fe* __restrict__ w, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ cols,
                                                                 const fe* __restrict__ vals, uint32_t n, uint32_t G, uint32_t r, fe* __restrict__ out)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t m = n / G;
   const uint32_t j2 = blockIdx.x * blockDim.x + threadIdx.x;
   if (j2 >= m) return;
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(256) void qap_dist_tw1_kernel(const fe* __restrict_
 template <int G>
 __global__ __launch_bounds__(256) void qap_dist_mid_kernel(const fe* __restrict__ recv, fe* __restrict__ send, const fe* __restrict__ tw, uint32_t N, uint32_t n, uint32_t b)
 {
+  ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t m = n / G, mb = m / G;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= mb) return;
