@@ -525,12 +525,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     t0.join(); t1.join(); t2.join(); t3.join();
   }
   mark("tails");
+  // every tail thread has waited for its MSM's ev_done (recorded behind the last operation of that MSM's chain), so all six
+  // streams are drained except for ev[3] on g1, which waits for the five of them: one synchronisation instead of six
   P_HIP(hipStreamSynchronize(g1));
-  P_HIP(hipStreamSynchronize(g2));
-  P_HIP(hipStreamSynchronize(g3));
-  P_HIP(hipStreamSynchronize(z->s_g4));
-  P_HIP(hipStreamSynchronize(z->s_g5));
-  P_HIP(hipStreamSynchronize(z->s_qap));
   drain.armed = false;
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
