@@ -227,7 +227,7 @@ def pmc_traffic(workload, timeout=600):
     return out
 
 
-def dropin_sequence_ms(zkey, wtns, iters=4):
+def dropin_sequence_ms(zkey, wtns, iters=7):
     """the reference's Rust host restated call for call over the C ABI (lib/dropin_host): median warm `proof took`"""
     exe = os.path.join(ROOT, "icicle-snark_amd", "lib", "dropin_host")
     if not os.path.exists(exe):

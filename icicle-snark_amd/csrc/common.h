@@ -58,6 +58,11 @@ bool is_pinned_host(const void* host_ptr, int device_id = -1);
 // copies of at least this many bytes from/to pageable memory take the staged path
 constexpr size_t STAGED_MIN_BYTES = 4u << 20;
 
+// Every entry point that WRITES device memory on behalf of the caller reports the range here (copies, memsets, frees, device
+// results of vec ops / conversions / transforms / MSMs): fixed-base tables built for a base array that overlaps it are dropped
+// (msm_tables in runtime.cpp).  Cheap: a lock and a scan of the handful of live tables.
+void note_device_write(const void* p, size_t bytes);
+
 // Stages a host-resident operand on the device for the lifetime of the object (the reference's
 // wrappers do the same per VecOpsConfig / NTTConfig / MSMConfig flags, e.g.
 // icicle/backend/cuda/src/field/cuda_vec_ops.cu:17-54).  Output operands are copied back by finish().
@@ -101,6 +106,7 @@ public:
     if (!on_device && bytes && is_tracked_device_ptr(p)) on_device = true;
     if (on_device || bytes == 0) {
       dev_ = p;
+      if (bytes) note_device_write(p, bytes);
       return ICICLE_SUCCESS;
     }
     HIP_TRY(hipMalloc(&dev_, bytes), ICICLE_ALLOCATION_FAILED);

@@ -44,7 +44,7 @@ void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, i
 
 ISNARK_API eIcicleError bn254_msm(const bn254_scalar_t* scalars, const bn254_affine_t* bases, int msm_size, const MSMConfig* cfg, bn254_projective_t* results)
 {
-  return msm_impl<G1>(scalars, bases, msm_size, cfg, results);
+  return msm_impl<G1, FqOps>(scalars, bases, msm_size, cfg, results);
 }
 ISNARK_API eIcicleError bn254_msm_precompute_bases(const bn254_affine_t* bases, int nof_bases, const MSMConfig* cfg, bn254_affine_t* out)
 {

@@ -516,8 +516,10 @@ __global__ __launch_bounds__(256) void msm_table_rows_kernel(const typename C::A
       for (int k = 0; k < (w < wide ? c : c - 1); k++) x = CL::x_dbl(x); // row w + 1 sits at the bit where window w ends
   }
 }
+// `async`: temporaries from the stream's workspace arena, nothing synchronised — the table is complete in stream order (the
+// automatic tables of bn254_msm); else plain allocations and a synchronised stream on return (cache build of the prover).
 template <class C, class F>
-eIcicleError build_table_run(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
+eIcicleError build_table_run(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table, bool async = false)
 {
   typedef typename C::A A;
   typedef typename C::P P;
@@ -528,11 +530,26 @@ eIcicleError build_table_run(const void* d_points, uint32_t n, int from_form, co
   if (n) {
     P* rows = nullptr;
     typename F::T* scratch = nullptr;
-    HIP_TRY(hipMalloc((void**)&rows, m * sizeof(P)), ICICLE_ALLOCATION_FAILED);
-    if (hipMalloc((void**)&scratch, m * sizeof(typename F::T)) != hipSuccess) {
-      (void)hipFree(rows);
-      (void)hipFree(table);
-      return ICICLE_ALLOCATION_FAILED;
+    WsScoped<P> ws_rows;
+    WsScoped<typename F::T> ws_scratch;
+    if (async) {
+      if (ws_rows.alloc(m, s) != hipSuccess || ws_scratch.alloc(m, s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(table);
+        return ICICLE_ALLOCATION_FAILED;
+      }
+      rows = ws_rows.p;
+      scratch = ws_scratch.p;
+    } else {
+      if (hipMalloc((void**)&rows, m * sizeof(P)) != hipSuccess) {
+        (void)hipFree(table);
+        return ICICLE_ALLOCATION_FAILED;
+      }
+      if (hipMalloc((void**)&scratch, m * sizeof(typename F::T)) != hipSuccess) {
+        (void)hipFree(rows);
+        (void)hipFree(table);
+        return ICICLE_ALLOCATION_FAILED;
+      }
     }
     hipLaunchKernelGGL((msm_table_rows_kernel<C>), dim3((n + 255) / 256), dim3(256), 0, s, (const A*)d_points, n, from_form, g.c, g.W, g.wide, rows);
     const int chunk = 32;
@@ -540,12 +557,20 @@ eIcicleError build_table_run(const void* d_points, uint32_t n, int from_form, co
     hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, rows, m, chunk, table, scratch);
     hipLaunchKernelGGL((msm_points_to_internal_kernel<C>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, table, (uint32_t)m, 0);
     const eIcicleError e = check_launch("msm_build_table");
-    const hipError_t he = hipStreamSynchronize(s);
-    (void)hipFree(rows);
-    (void)hipFree(scratch);
-    if (e != ICICLE_SUCCESS || he != hipSuccess) {
-      (void)hipFree(table);
-      return e != ICICLE_SUCCESS ? e : ICICLE_SYNCHRONIZATION_FAILED;
+    if (async) {
+      if (e != ICICLE_SUCCESS) {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(table);
+        return e;
+      }
+    } else {
+      const hipError_t he = hipStreamSynchronize(s);
+      (void)hipFree(rows);
+      (void)hipFree(scratch);
+      if (e != ICICLE_SUCCESS || he != hipSuccess) {
+        (void)hipFree(table);
+        return e != ICICLE_SUCCESS ? e : ICICLE_SYNCHRONIZATION_FAILED;
+      }
     }
   }
   *d_table = table;
@@ -720,6 +745,7 @@ struct alignas(64) TailSlot {
   unsigned char result[192];
   void* host_dst; // result requested in host memory: written by the host function itself
   int W, c, wide;
+  int tab_nbits; // > 0: partials = [T | S_0 … S_{tab_nbits−1}] of the table-mode reduction
 };
 // Ring of pinned slots.  A slot is in use from tail_slot_acquire() until the event its user records behind the last
 // stream operation that touches it (tail_slot_commit) has completed: a caller that keeps more than TAIL_SLOTS
@@ -799,7 +825,8 @@ template <class C>
 void host_tail_callback(void* ud)
 {
   TailSlot* t = (TailSlot*)ud;
-  typename C::P p = msm_host_tail<C>((const typename C::X*)t->partials, (uint32_t)t->W, 1, t->c, t->wide);
+  typename C::P p = t->tab_nbits > 0 ? msm_host_tail_tab<C>((const typename C::X*)t->partials, (uint32_t)t->tab_nbits)
+                                     : msm_host_tail<C>((const typename C::X*)t->partials, (uint32_t)t->W, 1, t->c, t->wide);
   memcpy(t->result, &p, sizeof p);
   if (t->host_dst) memcpy(t->host_dst, &p, sizeof p);
 }
@@ -810,7 +837,8 @@ void host_tail_callback(void* ud)
 // caller's stream.  precompute_factor f > 1: `bases` came from msm_precompute_bases and holds f points per original
 // base, [f·i] being the base itself; this backend reads only those (stride f) — the extra multiples trade memory for a
 // cheaper bucket reduction in the reference's backends, which is not where the time goes here.
-template <class C, class AT, class PT>
+constexpr uint32_t MSM_AUTO_TABLE_MIN_L = 1u << 15; // smaller MSMs are launch-bound either way
+template <class C, class F, class AT, class PT>
 eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_size, const MSMConfig* cfg, PT* results)
 {
   typedef typename C::A A;
@@ -833,12 +861,38 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
 
   int lbf = 0; // 0 = this library's default (msm_sort_run)
   ext_get_int(cfg->ext, "large_bucket_factor", &lbf);
+  // automatic fixed-base table (msm_plan.h): one MSM of full-width scalars over a device-resident base array this runtime tracks
+  BaseTableRef tref;
+  bool use_table = false;
+  if (batch == 1 && stride == 1 && cfg->c <= 0 && (cfg->bitsize == 0 || cfg->bitsize == 254) && cfg->are_points_on_device && L >= MSM_AUTO_TABLE_MIN_L &&
+      is_tracked_device_ptr(bases)) {
+    const MsmGeom gt = msm_geometry(L, 0, 1);
+    if (gt.tab) {
+      const size_t table_bytes = (size_t)L * gt.W * sizeof(A);
+      const int form = cfg->are_points_montgomery_form ? 1 : 0;
+      const BaseTableState st = base_table_lookup(bases, (size_t)L * sizeof(A), L, sizeof(A) > 64, form, table_bytes, &tref);
+      if (st == BASE_TABLE_BUILD) {
+        void* table = nullptr;
+        if (build_table_run<C, F>(bases, L, form, gt, s, &table, /*async=*/true) == ICICLE_SUCCESS) {
+          base_table_publish(bases, L, sizeof(A) > 64, form, table, table_bytes, gt, s);
+          tref.table = table;
+          tref.g = gt;
+          tref.built = nullptr; // built on this very stream
+          use_table = true;
+        } else (void)hipGetLastError(); // no memory for the table: the classic layout still works
+      } else if (st == BASE_TABLE_HIT) {
+        use_table = true;
+        if (tref.built) HIP_TRY(hipStreamWaitEvent(s, tref.built, 0), ICICLE_UNKNOWN_ERROR); // built on another stream, perhaps
+      }
+    }
+  }
   MsmProfile* prof = nullptr;
   for (uint32_t bi = 0; bi < batch; bi++) {
     prof = msm_profile_next();
     SortPlan pl;
     (void)hipEventRecord(prof->ev[0], s);
-    ICICLE_TRY(msm_sort_run(ss.ptr<fe>() + (size_t)bi * L, L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl, 0, cfg->bitsize, (int)stride));
+    ICICLE_TRY(msm_sort_run(ss.ptr<fe>() + (size_t)bi * L, L, cfg->c, lbf, cfg->are_scalars_montgomery_form, s, &pl, use_table ? 1 : 0, cfg->bitsize, (int)stride));
+    if (use_table && (pl.g.tab != tref.g.tab || pl.g.c != tref.g.c || pl.g.W != tref.g.W)) return ICICLE_UNKNOWN_ERROR; // (same L, same rule: cannot differ)
     (void)hipEventRecord(prof->ev[4], s);
     prof->has_sort_end = true;
     prof->L = L;
@@ -847,21 +901,36 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
     prof->W = pl.g.W;
     prof->is_g2 = sizeof(A) > 64;
     WsScoped<X> partials;
-    const int Wt = pl.g.Wb; // windows left for the tail (= W, or ⌈W / f⌉ with precomputed bases)
+    uint32_t tail_w = 0;
+    const size_t part_bytes = msm_partials_bytes(&pl, sizeof(A) > 64, &tail_w, nullptr);
+    const int Wt = (int)(part_bytes / sizeof(X)); // sums left for the tail: one per window (= W, or ⌈W / f⌉ with precomputed bases), or 1 + t in table mode
     HIP_TRY(partials.alloc((size_t)Wt, s), ICICLE_ALLOCATION_FAILED);
-    const A* pts = sb.ptr<A>() + (shared ? 0 : (size_t)bi * L * stride);
-    ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, 1, s, partials.p, prof)); // the sort entries index the (precomputed) base array directly
+    if (use_table) {
+      ICICLE_TRY(msm_buckets_run<C>(&pl, (const A*)tref.table, 2, 0, L, s, partials.p, prof));
+    } else {
+      const A* pts = sb.ptr<A>() + (shared ? 0 : (size_t)bi * L * stride);
+      ICICLE_TRY(msm_buckets_run<C>(&pl, pts, cfg->are_points_montgomery_form, 0, 1, s, partials.p, prof)); // the sort entries index the (precomputed) base array directly
+    }
+    if (cfg->are_results_on_device) note_device_write(results + bi, sizeof(P));
     TailSlot* slot = Wt <= 64 ? tail_slot_acquire() : nullptr;
     if (slot) {
       slot->W = Wt;
       slot->c = pl.g.c;
       slot->wide = pl.g.wide < Wt ? pl.g.wide : Wt;
+      slot->tab_nbits = use_table ? (int)tail_w : 0;
       slot->host_dst = cfg->are_results_on_device ? nullptr : (void*)(results + bi);
       hipError_t he = hipMemcpyAsync(slot->partials, partials.p, (size_t)Wt * sizeof(X), hipMemcpyDeviceToHost, s);
       if (he == hipSuccess) he = hipLaunchHostFunc(s, host_tail_callback<C>, slot);
       if (he == hipSuccess && cfg->are_results_on_device) he = hipMemcpyAsync(results + bi, slot->result, sizeof(P), hipMemcpyHostToDevice, s);
       tail_slot_commit(slot, s); // on every path: the slot is free again once what was enqueued has run
       HIP_TRY(he, ICICLE_COPY_FAILED);
+    } else if (use_table) {
+      // no pinned slot (more than TAIL_SLOTS asynchronous MSMs in flight): wait for the sums and finish here
+      std::vector<X> hp((size_t)Wt);
+      HIP_TRY(hipMemcpyAsync(hp.data(), partials.p, (size_t)Wt * sizeof(X), hipMemcpyDeviceToHost, s), ICICLE_COPY_FAILED);
+      HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
+      const P p = msm_host_tail_tab<C>(hp.data(), tail_w);
+      HIP_TRY(hipMemcpy(results + bi, &p, sizeof(P), cfg->are_results_on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost), ICICLE_COPY_FAILED);
     } else {
       // no pinned slot: single-lane Horner on the device (2.5 ms G1 / 9 ms G2)
       WsScoped<P> dres;

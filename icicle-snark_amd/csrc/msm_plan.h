@@ -114,6 +114,26 @@ void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, i
 // G2 bucket accumulation, compiled with inlined Fq2 arithmetic (msm_g2_acc.hip)
 void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, uint32_t stride, hipStream_t s, void* buckets);
 
+// ---- automatic fixed-base tables behind bn254_msm / bn254_g2_msm (runtime.cpp) -------------------------------------------------
+// A caller that runs MSM after MSM over the SAME device-resident base array (the reference's host keeps its zkey points on the
+// device, src/cache.rs:58-72) gets the prover's table mode without asking: the second MSM over (pointer, length, form) builds the
+// table — W rows 2^(c·w)·P_i in the internal encoding — on the caller's stream, later ones use it (13 instead of 16 digits per
+// scalar at 1.6 M points, one bucket set, no Horner pass).  Validity is tracked by the runtime, not guessed: every entry point
+// that writes device memory (note_device_write) drops the tables of the ranges it touches, so no stream synchronisation and no
+// content check sits in the call.  The contract this rests on: device buffers handed to this library are modified only THROUGH
+// this library (true of the reference's host); ICICLE_SNARK_MSM_TABLES=0 switches the tables off, ICICLE_SNARK_MSM_TABLE_MB
+// (default 16384) bounds their memory per device (least recently used tables go first).
+struct BaseTableRef {
+  const void* table = nullptr;
+  MsmGeom g;
+  hipEvent_t built = nullptr; // recorded behind the build on the building stream
+};
+enum BaseTableState { BASE_TABLE_NONE = 0, BASE_TABLE_BUILD = 1, BASE_TABLE_HIT = 2 };
+// NONE: run the classic layout (first sighting, not eligible, no memory); BUILD: the caller builds a table of geometry ref->g and
+// hands it to base_table_publish; HIT: *ref is valid
+BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bool g2, int form, size_t table_bytes, BaseTableRef* ref);
+void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, hipStream_t s);
+
 bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
 bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);
 

@@ -169,6 +169,7 @@ struct DeviceGroup {
   std::vector<std::shared_ptr<ZKeyCache>> shards;
   std::unique_ptr<Team> team;
   bool dist = false; // every shard can run the distributed front end
+  bool peer_ok = false; // every device of the group maps every other one's memory (or they are one device)
   int mode = XCHG_PULL;
   RcclApi rccl;
   std::vector<void*> comms;
@@ -378,28 +379,36 @@ static int exchange_self_test(DeviceGroup* g)
   return 0;
 }
 
+// peer mappings for the pull kernels; called BEFORE the shard caches are allocated, so that every buffer a peer will read
+// is created with the mapping in place (and the self-test below exercises the same kind of allocation)
+static bool enable_peer_access(const std::vector<int>& devs)
+{
+  const int G = (int)devs.size();
+  for (int i = 0; i < G; i++) {
+    if (hipSetDevice(devs[i]) != hipSuccess) return false;
+    for (int j = 0; j < G; j++) {
+      if (devs[i] == devs[j]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devs[i], devs[j]) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        return false;
+      }
+      const hipError_t e = hipDeviceEnablePeerAccess(devs[j], 0);
+      (void)hipGetLastError();
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return false;
+    }
+  }
+  return true;
+}
+
 static int setup_exchange(DeviceGroup* g)
 {
   const int G = (int)g->devs.size();
-  bool distinct = true, peer_ok = true;
+  bool distinct = true;
+  const bool peer_ok = g->peer_ok;
   for (int i = 0; i < G; i++)
     for (int j = 0; j < i; j++)
       if (g->devs[i] == g->devs[j]) distinct = false;
-  // peer mappings for the pull kernels
-  for (int i = 0; i < G && peer_ok; i++) {
-    if (hipSetDevice(g->devs[i]) != hipSuccess) peer_ok = false;
-    for (int j = 0; j < G && peer_ok; j++) {
-      if (g->devs[i] == g->devs[j]) continue;
-      int can = 0;
-      if (hipDeviceCanAccessPeer(&can, g->devs[i], g->devs[j]) != hipSuccess || !can) {
-        peer_ok = false;
-        break;
-      }
-      const hipError_t e = hipDeviceEnablePeerAccess(g->devs[j], 0);
-      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peer_ok = false;
-      (void)hipGetLastError();
-    }
-  }
   std::vector<int> order;
   const char* forced = getenv("ICICLE_SNARK_EXCHANGE");
   if (forced && *forced) {
@@ -454,6 +463,7 @@ int group_load(Groth16CacheManager* cm, const char* key, const uint8_t* zkey, si
   std::shared_ptr<DeviceGroup> g(new DeviceGroup());
   g->devs = devs;
   g->shards.resize(G);
+  g->peer_ok = enable_peer_access(devs);
   // one builder thread per distinct device; the shards of one device are built one after the other (they share its null
   // stream, staging pool and memory)
   std::vector<int> distinct;

@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include "common.h"
+#include "msm_plan.h"
 
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share
 // a queue serialise.  The prover overlaps five streams; with four queues two of them collide and a
@@ -430,6 +431,117 @@ void ws_release_stream(hipStream_t s)
   }
 }
 
+// ---- fixed-base tables of caller-owned base arrays (msm_plan.h) -------------------------------------------------------------------
+struct BaseTable {
+  int dev;
+  uintptr_t ptr;
+  size_t bytes;
+  uint32_t n;
+  bool g2;
+  int form;
+  uint32_t sightings;
+  void* table; // nullptr: seen, not built
+  size_t table_bytes;
+  MsmGeom g;
+  hipEvent_t built;
+  uint64_t last_use;
+};
+static std::mutex g_bt_mu;
+static std::vector<BaseTable> g_bt;
+static uint64_t g_bt_clock = 0;
+static bool base_tables_enabled()
+{
+  static const bool on = !(getenv("ICICLE_SNARK_MSM_TABLES") && atoi(getenv("ICICLE_SNARK_MSM_TABLES")) == 0);
+  return on;
+}
+static size_t base_tables_budget()
+{
+  static const size_t v = getenv("ICICLE_SNARK_MSM_TABLE_MB") ? (size_t)atoll(getenv("ICICLE_SNARK_MSM_TABLE_MB")) << 20 : (size_t)16 << 30;
+  return v;
+}
+static void base_table_drop(BaseTable& t) // caller holds g_bt_mu; hipFree waits for whatever still reads the table
+{
+  if (t.table) {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != t.dev) (void)hipSetDevice(t.dev);
+    (void)hipFree(t.table);
+    if (t.built) (void)hipEventDestroy(t.built);
+    if (cur != t.dev) (void)hipSetDevice(cur);
+  }
+}
+void note_device_write(const void* p, size_t bytes)
+{
+  if (!p || !bytes) return;
+  std::lock_guard<std::mutex> lk(g_bt_mu);
+  if (g_bt.empty()) return;
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  for (size_t i = 0; i < g_bt.size();) {
+    if (g_bt[i].ptr < hi && lo < g_bt[i].ptr + g_bt[i].bytes) {
+      base_table_drop(g_bt[i]);
+      g_bt.erase(g_bt.begin() + i);
+    } else i++;
+  }
+}
+BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bool g2, int form, size_t table_bytes, BaseTableRef* ref)
+{
+  if (!base_tables_enabled()) return BASE_TABLE_NONE;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_bt_mu);
+  for (BaseTable& t : g_bt) {
+    if (t.dev != dev || t.ptr != (uintptr_t)bases || t.n != n || t.g2 != g2 || t.form != form) continue;
+    t.last_use = ++g_bt_clock;
+    if (t.table) {
+      ref->table = t.table;
+      ref->g = t.g;
+      ref->built = t.built;
+      return BASE_TABLE_HIT;
+    }
+    t.sightings++;
+    if (t.sightings < 2) return BASE_TABLE_NONE;
+    // second MSM over this array: worth a table if it fits the budget (least recently used tables make room)
+    if (table_bytes > base_tables_budget()) return BASE_TABLE_NONE;
+    for (;;) {
+      size_t used = 0;
+      size_t lru = (size_t)-1;
+      for (size_t i = 0; i < g_bt.size(); i++) {
+        if (g_bt[i].dev != dev || !g_bt[i].table) continue;
+        used += g_bt[i].table_bytes;
+        if (lru == (size_t)-1 || g_bt[i].last_use < g_bt[lru].last_use) lru = i;
+      }
+      if (used + table_bytes <= base_tables_budget() || lru == (size_t)-1) break;
+      base_table_drop(g_bt[lru]);
+      g_bt[lru].table = nullptr;
+      g_bt[lru].built = nullptr;
+      g_bt[lru].sightings = 0;
+    }
+    return BASE_TABLE_BUILD;
+  }
+  g_bt.push_back({dev, (uintptr_t)bases, bytes, n, g2, form, 1u, nullptr, 0, MsmGeom(), nullptr, ++g_bt_clock});
+  return BASE_TABLE_NONE;
+}
+void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, hipStream_t s)
+{
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(ev, s);
+  std::lock_guard<std::mutex> lk(g_bt_mu);
+  for (BaseTable& t : g_bt) {
+    if (t.dev != dev || t.ptr != (uintptr_t)bases || t.n != n || t.g2 != g2 || t.form != form || t.table) continue;
+    t.table = table;
+    t.table_bytes = table_bytes;
+    t.g = g;
+    t.built = ev;
+    return;
+  }
+  // the entry went away between lookup and publish (a write to the bases): the table is of no use
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(table);
+  if (ev) (void)hipEventDestroy(ev);
+}
+
 } // namespace isnark
 
 using namespace isnark;
@@ -620,9 +732,27 @@ ISNARK_API eIcicleError icicle_malloc_async(void** ptr, size_t size, icicleStrea
   return ICICLE_SUCCESS;
 }
 
+// the whole tracked block that contains p is about to go away / be rewritten
+static void note_block_write(const void* p)
+{
+  size_t size = 0;
+  uintptr_t base = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_allocs.upper_bound((uintptr_t)p);
+    if (it == g_allocs.begin()) return;
+    --it;
+    if ((uintptr_t)p >= it->first + it->second.first) return;
+    base = it->first;
+    size = it->second.first;
+  }
+  note_device_write((const void*)base, size);
+}
+
 ISNARK_API eIcicleError icicle_free(void* ptr)
 {
   if (!ptr) return ICICLE_SUCCESS;
+  note_block_write(ptr);
   // memory of a non-active device: switch, release, switch back (runtime.cpp:66-93)
   int owner = identify(ptr);
   if (owner < 0) return ICICLE_INVALID_POINTER;
@@ -641,6 +771,7 @@ ISNARK_API eIcicleError icicle_free(void* ptr)
 ISNARK_API eIcicleError icicle_free_async(void* ptr, icicleStreamHandle stream)
 {
   if (!ptr) return ICICLE_SUCCESS;
+  note_block_write(ptr);
   const int owner = identify(ptr);
   if (!untrack(ptr)) return ICICLE_INVALID_POINTER;
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream), ICICLE_SYNCHRONIZATION_FAILED);
@@ -663,6 +794,7 @@ ISNARK_API eIcicleError icicle_get_available_memory(size_t* total, size_t* free_
 ISNARK_API eIcicleError icicle_memset(void* ptr, int value, size_t size)
 {
   if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
+  note_device_write(ptr, size);
   HIP_TRY(hipMemset(ptr, value, size), ICICLE_UNKNOWN_ERROR);
   return ICICLE_SUCCESS;
 }
@@ -670,6 +802,7 @@ ISNARK_API eIcicleError icicle_memset(void* ptr, int value, size_t size)
 ISNARK_API eIcicleError icicle_memset_async(void* ptr, int value, size_t size, icicleStreamHandle stream)
 {
   if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
+  note_device_write(ptr, size);
   HIP_TRY(hipMemsetAsync(ptr, value, size, (hipStream_t)stream), ICICLE_UNKNOWN_ERROR);
   return ICICLE_SUCCESS;
 }
@@ -686,12 +819,14 @@ static hipMemcpyKind direction(void* dst, const void* src)
 ISNARK_API eIcicleError icicle_copy(void* dst, const void* src, size_t size)
 {
   ICICLE_TRY(require_device());
+  if (identify(dst) >= 0) note_device_write(dst, size);
   HIP_TRY(hipMemcpy(dst, src, size, direction(dst, src)), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
 ISNARK_API eIcicleError icicle_copy_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
 {
   ICICLE_TRY(require_device());
+  if (identify(dst) >= 0) note_device_write(dst, size);
   HIP_TRY(hipMemcpyAsync(dst, src, size, direction(dst, src), (hipStream_t)stream), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
@@ -728,6 +863,7 @@ ISNARK_API eIcicleError icicle_copy_to_host_async(void* dst, const void* src, si
 ISNARK_API eIcicleError icicle_copy_to_device(void* dst, const void* src, size_t size)
 {
   ICICLE_TRY(require_device());
+  note_device_write(dst, size);
   bool done;
   ICICLE_TRY(big_pageable_copy(dst, src, size, true, nullptr, &done));
   if (!done) HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
@@ -736,6 +872,7 @@ ISNARK_API eIcicleError icicle_copy_to_device(void* dst, const void* src, size_t
 ISNARK_API eIcicleError icicle_copy_to_device_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
 {
   ICICLE_TRY(require_device());
+  note_device_write(dst, size);
   bool done;
   ICICLE_TRY(big_pageable_copy(dst, src, size, true, (hipStream_t)stream, &done));
   if (!done) HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t)stream), ICICLE_COPY_FAILED);

@@ -282,3 +282,50 @@ def test_many_async_msms_in_flight_do_not_share_tail_slots(gpu, O):
     for d in outs + d_s + [d_b]:
         d.free()
     st.destroy()
+
+
+@pytest.mark.parametrize("grp,n", [("g1", 40_000), ("g2", 33_000)])
+def test_msm_automatic_fixed_base_tables(gpu, O, grp, n):
+    """bn254_msm / bn254_g2_msm over the SAME device-resident base array: the first call runs the classic layout, the second
+    builds a fixed-base table on the caller's stream, later ones use it (csrc/msm_plan.h: base_table_lookup).  Every result
+    equals the oracle's, with fresh scalars each time, standard and Montgomery scalars, two streams; a write to the bases
+    THROUGH the API (copy, in-place Montgomery conversion, free + reallocation at the same address) retires the table, and the
+    results follow the new contents — icicle/src/msm.cpp:12-32 semantics are unchanged."""
+    K = gpu
+    rng = np.random.default_rng(2024 + n)
+    bases = _bases(O, grp, rng, n)
+    bases[3] = 0
+    st, st2 = K.IcicleStream(), K.IcicleStream()
+    d_b = K.DeviceVec.from_host(bases, st)
+    st.synchronize()
+
+    def check(points, points_mont=False, stream=None, rounds=1):
+        for k in range(rounds):
+            sc = rand_fr(O, rng, n)
+            if k % 2:
+                sc[: n // 2] = 0
+                sc[5, 0] = 1
+            want = O.ec_to_affine(grp, O.msm(grp, sc, points))
+            d_s = K.DeviceVec.from_host(sc, stream)
+            if k == 2:
+                K.scalar_convert_montgomery(d_s, True, stream=stream)
+            got = K.msm(grp, d_s, d_b, stream=stream, scalars_mont=(k == 2), points_mont=points_mont)
+            assert np.array_equal(K.ec(grp, "to_affine", got), want), (k, points_mont)
+            d_s.free()
+
+    check(bases, rounds=4, stream=st)                      # classic, build, hit, hit (Montgomery scalars on the third)
+    check(bases, rounds=2, stream=st2)                     # the table built on `st` serves another stream
+    # the bases change behind the same pointer: copy from the host …
+    bases2 = _bases(O, grp, rng, n)
+    d_b.copy_from_host(bases2, st)
+    st.synchronize()
+    check(bases2, rounds=3, stream=st)
+    # … converted in place to Montgomery form (the reference's cache does the opposite conversion on its points, src/cache.rs:228)
+    K.affine_convert_montgomery(grp, d_b, True)
+    check(bases2, points_mont=True, rounds=3)
+    # … freed, and a new array of the same size (the allocation cache hands the block out again)
+    d_b.free()
+    bases3 = _bases(O, grp, rng, n)
+    d_b = K.DeviceVec.from_host(bases3)
+    check(bases3, rounds=3)
+    st.destroy(); st2.destroy(); d_b.free()
