@@ -803,8 +803,11 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
       if (int rc = groth16_cache_load_devices(cm, key.c_str(), zf.data, zf.len, devs.data(), (int)devs.size())) return rc;
     }
   }
+  static const bool trace_host = getenv("ICICLE_SNARK_TRACE_HOST") != nullptr;
+  if (trace_host) fprintf(stderr, "[host] prove: cache key found        %8.1f us\n", ms_since(t0) * 1e3);
   MappedFile wf;
   if (int rc = wf.open_ro(witness_path)) return rc;
+  if (trace_host) fprintf(stderr, "[host] prove: witness mapped         %8.1f us\n", ms_since(t0) * 1e3);
   std::vector<char> pj(4096), qj(256);
   {
     Groth16CircuitInfo info;
@@ -818,6 +821,7 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
   const int prc = groth16_prove_mem(cm, key.c_str(), wf.data, wf.len, nullptr, nullptr, pj.data(), pj.size(), qj.data(), qj.size(), nullptr);
   staged_copy_file_hint(nullptr, 0, -1);
   if (prc) return prc;
+  if (trace_host) fprintf(stderr, "[host] prove: proof assembled        %8.1f us\n", ms_since(t0) * 1e3);
   for (int k = 0; k < 2; k++) {
     const char* path = k ? public_path : proof_path;
     FILE* f = fopen(path, "wb");
@@ -825,6 +829,7 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
     fputs(k ? qj.data() : pj.data(), f);
     fclose(f);
   }
+  if (trace_host) fprintf(stderr, "[host] prove: files written          %8.1f us\n", ms_since(t0) * 1e3);
   static const bool quiet = getenv("ICICLE_SNARK_QUIET") && atoi(getenv("ICICLE_SNARK_QUIET")) != 0;
   if (!quiet) {
     printf("proof took: %.3fms\n", ms_since(t0)); // src/lib.rs:58
