@@ -518,6 +518,14 @@ BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bo
     }
     return BASE_TABLE_BUILD;
   }
+  // first sighting: remember the array (bounded: the oldest table-less entry makes room)
+  if (g_bt.size() >= 64) {
+    size_t old = (size_t)-1;
+    for (size_t i = 0; i < g_bt.size(); i++)
+      if (!g_bt[i].table && (old == (size_t)-1 || g_bt[i].last_use < g_bt[old].last_use)) old = i;
+    if (old == (size_t)-1) return BASE_TABLE_NONE;
+    g_bt.erase(g_bt.begin() + old);
+  }
   g_bt.push_back({dev, (uintptr_t)bases, bytes, n, g2, form, 1u, nullptr, 0, MsmGeom(), nullptr, ++g_bt_clock});
   return BASE_TABLE_NONE;
 }
