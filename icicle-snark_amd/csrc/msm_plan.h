@@ -70,7 +70,10 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab = 0, int bits = 0, int pf = 
 // recode → histogram → scan → scatter on stream s.  Workspace comes from the arena of stream s and is
 // returned by msm_sort_release (which only marks it reusable by later work on that stream; idempotent, also
 // run by ~SortPlan).
-eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl, int tab = 0, int bits = 0, int pf = 1);
+// `entries_hint` > 0: the number of non-zero digits the caller expects (a witness-light key adapted to its witnesses, prover.cpp):
+// the large-bucket threshold is then 3 × that average instead of 3 × the dense one.
+eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl, int tab = 0, int bits = 0, int pf = 1,
+                          uint64_t entries_hint = 0);
 void msm_sort_release(SortPlan* pl);
 
 // ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,

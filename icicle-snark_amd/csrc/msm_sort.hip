@@ -875,7 +875,7 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab, int bits, int pf)
   return g;
 }
 
-eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl, int tab, int bits, int pf)
+eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl, int tab, int bits, int pf, uint64_t entries_hint)
 {
   pl->g = msm_geometry(L, c_cfg, tab, bits, pf);
   const MsmGeom& g = pl->g;
@@ -891,7 +891,7 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   // in 500-addition chains of single threads (prove 11.2 → 6.3 ms at 1.0 M constraints, 14.1 → 8.3 ms at 1.4 M; 1.6 M uniform:
   // unchanged).  The caller's large_bucket_factor (ConfigExtension) is honoured when given.
   constexpr uint32_t large_floor = 64u;
-  const uint64_t avg = (g.tab ? (uint64_t)L * g.W : (uint64_t)L * g.pf) / g.NB + 1;
+  const uint64_t avg = (entries_hint ? entries_hint : g.tab ? (uint64_t)L * g.W : (uint64_t)L * g.pf) / g.NB + 1;
   uint32_t thr = (uint32_t)(avg * (uint64_t)(lbf > 0 ? lbf : 3));
   if (thr < large_floor) thr = large_floor;
   if (thr < 8) thr = 8;

@@ -270,7 +270,10 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipMalloc((void**)&z->d_vec, (size_t)n * 3 * 32));
   if (z->H.stride > 1) P_HIP(hipMalloc((void**)&z->d_fold, (size_t)z->H.len() * 3 * 32));
   P_HIP(hipMalloc((void**)&z->d_partials, 5 * PARTIALS_STRIDE));
-  P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE));
+  P_HIP(hipHostMalloc((void**)&z->h_partials, 5 * PARTIALS_STRIDE + 64)); // + the sort statistics read back per prove (h_stats)
+  z->h_stats = reinterpret_cast<uint32_t*>(z->h_partials + 5 * PARTIALS_STRIDE);
+  z->h_stats[0] = z->h_stats[1] = 0;
+  z->geom_w_default_c = z->geom_w.c;
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
   // six streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
   // Stream priorities were tried (QAP chain high, G2 low, …): every variant was 1-2 ms slower than equal priorities.
@@ -298,6 +301,53 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   lap("work buffers, streams, events");
   out = std::move(z);
+  return 0;
+}
+
+// ---- digit width of the witness MSMs adapted to the witnesses a key really sees ------------------------------------------------
+// The tables fix the digit width c at cache build for DENSE scalars: c = 20 at a million wires, 2^19 buckets per MSM, whose
+// reduction is 1 M point additions per MSM whatever the witness.  Witnesses of real circuits are mostly 0/1 wires and small values:
+// a tenth to a fifth of the non-zero digits of a dense witness, so the four witness MSMs (A, B1, B2, C) spend more in reducing
+// empty-ish buckets than in filling them — the G2 reduction heads the critical chain.  After a prove the
+// entry count of the witness digit sort is known; if it calls for a digit at least two bits narrower (target ≈ 32 entries per
+// bucket), the four tables are rebuilt from their own row 0 with that width — once, ≈ 0.1–0.3 s, like a cache build — and the
+// next proves sort with it and size the large-bucket threshold from the observed count.  Measured on the stand-in keys of
+// BASELINE configs 4 / 5: c = 20 → 18, prove 5.5 → 4.7 ms (1.0 M constraints) and 8.15 → 7.3 ms (1.4 M); c ≤ 16 is slower again
+// (one thread per bucket: chains of hundreds).  A later, denser witness moves the key back the same way.  H stays dense.
+int witness_digit_target(const ZKeyCache* z, uint64_t entries)
+{
+  if (!entries) return z->geom_w.c;
+  int lg = 0;
+  while (((uint64_t)1 << lg) * 32 < entries) lg++; // 2^lg ≥ entries / 32 buckets
+  int c = lg + 1;
+  if (c > z->geom_w_default_c) c = z->geom_w_default_c;
+  if (c < 13) c = 13;
+  return c;
+}
+int rebuild_witness_tables(ZKeyCache* z, int c_new)
+{
+  if (!z->geom_w.tab || c_new == z->geom_w.c) return 0;
+  static std::mutex rebuild_mu; // the shards of a device group may share a device (and its null stream)
+  std::lock_guard<std::mutex> lk(rebuild_mu);
+  const MsmGeom g = c_new == z->geom_w_default_c ? msm_geometry(z->A.len(), 0, 1) : msm_geometry(z->A.len(), 0, c_new);
+  if (!g.tab || (c_new != z->geom_w_default_c && g.c != c_new)) return 0; // the entry encoding does not fit this width: keep what there is
+  // room for the largest new table next to the old ones (they go one by one)
+  size_t free_b = 0, total_b = 0;
+  release_cached_device_memory();
+  P_HIP(hipMemGetInfo(&free_b, &total_b));
+  const uint64_t biggest = (uint64_t)z->B2.len() * g.W * 128 + (uint64_t)z->B2.len() * g.W * (192 + 64) + (64u << 20);
+  if (biggest > free_b) return 0;
+  struct Job { Shard* sh; bool g2; };
+  const Job jobs[4] = {{&z->A, false}, {&z->B1, false}, {&z->B2, true}, {&z->C, false}};
+  for (const Job& j : jobs) {
+    void* table = nullptr;
+    // row 0 of the old table = the bases themselves, in the internal encoding (form 2)
+    P_ICICLE(j.g2 ? msm_g2_build_table(j.sh->d_points, j.sh->len(), 2, g, nullptr, &table) : msm_g1_build_table(j.sh->d_points, j.sh->len(), 2, g, nullptr, &table));
+    P_HIP(hipFree(j.sh->d_points));
+    j.sh->d_points = table;
+    z->device_bytes += (int64_t)j.sh->len() * ((int64_t)g.W - (int64_t)z->geom_w.W) * (j.g2 ? 128 : 64);
+  }
+  z->geom_w = g;
   return 0;
 }
 

@@ -276,6 +276,15 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   const auto t0 = std::chrono::steady_clock::now();
   if (int rc = set_active_device(z->device_id)) return rc;
   if (int rc = ensure_domain(cm, z)) return rc;
+  // the key follows its witnesses: a digit width at least two bits off the one the last witness called for → rebuild the four
+  // witness tables now (nothing of this prove is enqueued yet; the streams are idle), at most once every eight proves
+  if (z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1) {
+    const int c_t = witness_digit_target(z, z->witness_entries);
+    if ((c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (z->geom_w.c == z->geom_w_default_c || z->proves_since_rebuild >= 8)) {
+      if (int rc = rebuild_witness_tables(z, c_t)) return rc;
+      z->proves_since_rebuild = 0;
+    }
+  }
   static const bool trace_host = getenv("ICICLE_SNARK_TRACE_HOST") != nullptr;
   auto mark = [&](const char* what) {
     if (trace_host) fprintf(stderr, "[host] %-12s %8.1f us\n", what, ms_since(t0) * 1e3);
@@ -340,11 +349,19 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // the witness sort is timed with the profile of the G2 MSM that follows it on g2
   MsmProfile* psort = prof[2];
   (void)hipEventRecord(psort->ev[0], g2);
-  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w, z->geom_w.tab));
+  // (tab > 1 = table mode with exactly this digit width: a key adapted to its witnesses, cache.cpp)
+  const bool adapted_w = z->geom_w.tab && z->geom_w.c != z->geom_w_default_c;
+  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w, adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, adapted_w ? z->witness_entries : 0));
   if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
   (void)hipEventRecord(psort->ev[4], g2); // end of the witness digit sort (roofline.scatter)
   psort->has_sort_end = true;
   P_HIP(hipEventRecord(z->ev_sort, g2));
+  // entry count of this sort (offset + count of the last bucket), read at the end of the prove: it steers the digit width of
+  // the key's witness tables (cache.cpp: rebuild_witness_tables)
+  if (plan_w.nbuckets) {
+    P_HIP(hipMemcpyAsync(&z->h_stats[0], plan_w.offsets + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, g2));
+    P_HIP(hipMemcpyAsync(&z->h_stats[1], plan_w.counts + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, g2));
+  }
   mark("wsort");
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
     p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
@@ -529,6 +546,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // streams are drained except for ev[3] on g1, which waits for the five of them: one synchronisation instead of six
   P_HIP(hipStreamSynchronize(g1));
   drain.armed = false;
+  z->witness_entries = (uint64_t)z->h_stats[0] + z->h_stats[1]; // the copies on g2 completed before B2's ev_done
+  z->proves_since_rebuild++;
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
   {

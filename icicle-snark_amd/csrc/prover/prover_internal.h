@@ -93,7 +93,11 @@ struct ZKeyCache {
   G2::P vk_beta_2, vk_gamma_2, vk_delta_2;
   // device
   int device_id = 0, shard_rank = 0, shard_count = 1;
-  MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM, fixed at cache build
+  MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM; geom_w follows the witnesses (cache.cpp)
+  int geom_w_default_c = 0;        // digit width of the dense geometry chosen at cache build
+  uint32_t* h_stats = nullptr;     // pinned: offset and count of the last bucket of the witness sort = its entry count
+  uint64_t witness_entries = 0;    // non-zero digits of the witness range in the most recent prove
+  uint32_t proves_since_rebuild = 0;
   uint32_t* d_rowptr = nullptr; // 2n+1
   uint32_t* d_cols = nullptr;   // n_coef
   fe* d_vals = nullptr;         // n_coef, Montgomery form
@@ -127,6 +131,10 @@ struct ZKeyCache {
 
 // elements per rank when the witness is uploaded in shard_count slices
 inline uint64_t witness_slice_elems(uint32_t n_vars, int count) { return ((uint64_t)n_vars + count - 1) / count; }
+
+// digit width of the witness MSMs adapted to the witnesses seen (cache.cpp)
+int witness_digit_target(const ZKeyCache* z, uint64_t entries);
+int rebuild_witness_tables(ZKeyCache* z, int c_new);
 
 // CacheManager::compute — src/cache.rs:117-241
 int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out);
