@@ -26,7 +26,7 @@ hipError_t qap_coset_fold3(const bn254::fe* d_vec, const bn254::fe* tw, uint32_t
 // dst[k] = src[first + k·stride] for elements of `elem_fe` field elements (strided point-range shard of the H bases)
 hipError_t qap_gather_strided(const bn254::fe* src, bn254::fe* dst, uint32_t elem_fe, uint32_t count, uint32_t stride, uint32_t first, hipStream_t s);
 
-// Distributed front end for G ∈ {2, 4, 8} GPUs (icicle-snark_amd/dist_qap.py has the algebra and its CPU restatement):
+// Distributed front end for G ∈ {2, 4, 8} GPUs (tests/dist_qap_model.py has the algebra and its CPU restatement):
 //   stage 1  qap_spmv_strided (rows c ≡ r mod G → [B | A | A∘B] over m = n/G elements) + size-m inverse transform whose
 //            per-element scale is the table of qap_dist_tw1 (n⁻¹·ω_n^{−r·k2}); exchange 1 = all-to-all of blocks of m/G;
 //   stage 2  qap_dist_mid: size-G inverse DFT over the sources, coset key g^k, size-G forward DFT, twist ω_n^{k2·i1};

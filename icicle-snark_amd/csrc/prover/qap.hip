@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void qap_gather_strided_kernel(const fe* __res
 }
 
 
-// ---- distributed front end (power-of-two shard count G, rank r): see qap.h / icicle-snark_amd/dist_qap.py -----------------
+// ---- distributed front end (power-of-two shard count G, rank r): see qap.h / tests/dist_qap_model.py -----------------
 // rows c ≡ r (mod G) of the spmv only: out = [B | A | A∘B] over j2 < m, c = r + G·j2
 __global__ __launch_bounds__(256) void qap_spmv_strided_kernel(const fe* __restrict__ w, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ cols,
                                                                 const fe* __restrict__ vals, uint32_t n, uint32_t G, uint32_t r, fe* __restrict__ out)

@@ -199,7 +199,7 @@ class RcclExchange:
 
 def sharded_commitments(cm, key: str, wtns, exch, distributed_qap: bool = True, shard_witness: bool | None = None):
     """this rank's five partial commitments.  With 2, 4 or 8 ranks (H sharded by residue class) the QAP front end is
-    distributed too: every rank transforms 1/world of the rows and two all-to-alls move the blocks (dist_qap.py); otherwise
+    distributed too: every rank transforms 1/world of the rows and two all-to-alls move the blocks (tests/dist_qap_model.py has the algebra); otherwise
     (or with distributed_qap=False, or when the witness is already resident: wtns=None) it is replicated, communication-free.
     shard_witness (default: on with more than one rank; ICICLE_SNARK_SHARD_WITNESS=0 turns it off): every rank uploads
     1/world of the witness over PCIe and an in-place all-gather over the exchange completes it on every device."""

@@ -1,5 +1,5 @@
-"""Distributed QAP front end for a power-of-two number of GPUs — the index algebra, shared by the HIP path
-(csrc/prover/qap.hip: qap_dist_*; csrc/prover/prover.cpp: groth16_dist_stage*) and its CPU restatement below.
+"""Distributed QAP front end for a power-of-two number of GPUs — the index algebra of the HIP path (csrc/prover/qap.hip:
+qap_dist_*; csrc/prover/prover.cpp: shard_dist_stage1/2) restated on the CPU.  Test infrastructure (tests/test_dist_qap.py).
 
 n = G·m.  The inverse transform of construct_r1cs (src/proof_helper.rs:116), the coset multiplication (:121-141) and the
 forward transform (:145) are computed WITHOUT any rank holding a full row:

@@ -1,4 +1,4 @@
-"""Distributed QAP front end (icicle-snark_amd/dist_qap.py): the three-stage decomposition with two all-to-alls equals the
+"""Distributed QAP front end (tests/dist_qap_model.py): the three-stage decomposition with two all-to-alls equals the
 oracle's construct_r1cs, (a) simulated in one process for G = 2, 4, 8 and (b) run by two gloo processes that really exchange
 their blocks.  CPU only — the HIP kernels of the same stages are compared with the single-GPU prover in tests/test_gpu_dist.py."""
 import importlib
@@ -13,7 +13,7 @@ import pytest
 
 from conftest import ROOT
 
-D = importlib.import_module("icicle-snark_amd.dist_qap")
+import dist_qap_model as D
 
 
 def _reference_h(O, rows, logn):
@@ -58,7 +58,7 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"
 import torch, torch.distributed as dist
 import oracle as O
 from test_dist_qap import _reference_h, _ntt_fns
-D = importlib.import_module("icicle-snark_amd.dist_qap")
+import dist_qap_model as D
 dist.init_process_group("gloo")
 r, G = dist.get_rank(), dist.get_world_size()
 logn = 6; n, m, mb = 1 << logn, (1 << logn) // G, (1 << logn) // (G * G)
