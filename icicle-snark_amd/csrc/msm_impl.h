@@ -1031,6 +1031,7 @@ eIcicleError generator_mul_impl(const bn254_scalar_t* sc, uint64_t n, hipStream_
   if (!sc || !out) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(require_device());
   if (n == 0) return ICICLE_SUCCESS;
+  note_device_write(out, (size_t)n * sizeof(A));
   WsScoped<X> table;
   WsScoped<P> proj;
   WsScoped<typename F::T> scratch;
