@@ -379,3 +379,32 @@ def test_pinned_witness_buffer_takes_the_direct_dma_path(gpu, cm):
         hip.hipHostFree(p)
     assert json.loads(want[0]) == c["proof"]
     cm.evict("pin")
+
+
+def test_cache_budget_evicts_least_recently_used_keys(gpu, O, S):
+    """groth16_cache_set_budget (the reference's CacheManager never evicts, src/cache.rs:110-114; the fixed-base tables make an entry
+    ≈ 10× its size): with a budget that holds two of three keys, loading the third evicts the least recently USED one; proofs
+    of the surviving keys are unchanged, and the evicted key simply builds again."""
+    K = gpu
+    keys = {}
+    for name, n in (("a", 2500), ("b", 2600), ("c", 2700)):
+        r1, w = S.squaring_chain(n)
+        zkey, _ = S.setup(r1, _fbm(K), points_to_mont=lambda a: O.fq_convert_montgomery(a, True))
+        keys[name] = (zkey, S.write_wtns(w))
+    c = K.CacheManager()
+    c.load("a", keys["a"][0])
+    c.load("b", keys["b"][0])
+    pa = c.prove_mem("a", keys["a"][1], 3, 4)[0]
+    pb = c.prove_mem("b", keys["b"][1], 3, 4)[0]
+    size_a, size_b = c.info("a").device_bytes, c.info("b").device_bytes
+    need_c = 11 * len(keys["c"][0])                           # the size estimate of a new entry: 11 × its zkey
+    c.set_budget(max(size_a, size_b) + need_c + (1 << 20))    # room for "c" next to ONE of the two
+    assert size_a + size_b + need_c > max(size_a, size_b) + need_c + (1 << 20)
+    c.prove_mem("a", keys["a"][1], 3, 4)                      # "a" is now more recently used than "b"
+    c.load("c", keys["c"][0])
+    assert c.contains("a") and c.contains("c") and not c.contains("b")
+    assert c.prove_mem("a", keys["a"][1], 3, 4)[0] == pa
+    c.set_budget(0)
+    c.load("b", keys["b"][0])
+    assert c.prove_mem("b", keys["b"][1], 3, 4)[0] == pb
+    c.close()
