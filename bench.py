@@ -261,31 +261,48 @@ def inproc_group_bench(args, K, S, dist, rank, world, zkey, wtns, N, tmpdir):
     device = f"HIP:{devices}"
     res = {}
     cm = None
-    try:
-        if rank == 0:
-            zkey_path, wtns_path = os.path.join(tmpdir, "g.zkey"), os.path.join(tmpdir, "g.wtns")
-            proof_path, public_path = os.path.join(tmpdir, "g_proof.json"), os.path.join(tmpdir, "g_public.json")
-            open(zkey_path, "wb").write(zkey)
-            open(wtns_path, "wb").write(wtns)
-            cm = K.CacheManager()
-            t0 = time.time()
-            cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)     # builds the device group (cold) + first prove
-            res["cold_ms"] = (time.time() - t0) * 1e3
-            key = f"{zkey_path}_{device}"
-            info = cm.info(key)
-            res.update(shards=info.shards, device_mb=info.device_bytes / 1e6)
-            log(f"device group {device}: {info.shards} shards, {info.device_bytes / 1e6:.0f} MB of device memory, built + first prove in {res['cold_ms'] / 1e3:.2f} s")
-            for _ in range(max(1, args.warmup)):
-                cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
-    except Exception as e:   # noqa: BLE001 — reported; every rank then agrees on the fallback
-        res = {"error": repr(e)[:400]}
-        log(f"in-process device group failed: {e!r}")
+    hung = False
+    if rank == 0:
+        zkey_path, wtns_path = os.path.join(tmpdir, "g.zkey"), os.path.join(tmpdir, "g.wtns")
+        proof_path, public_path = os.path.join(tmpdir, "g_proof.json"), os.path.join(tmpdir, "g_public.json")
+        key = f"{zkey_path}_{device}"
+
+        def bring_up():
+            # builds the device group (cold) + first prove + warm-up; on a helper thread with a deadline: peer access, peer copies
+            # and RCCL have never run across two GPUs, and a bring-up that never returns must not hang the launcher's other ranks
+            nonlocal cm
+            try:
+                open(zkey_path, "wb").write(zkey)
+                open(wtns_path, "wb").write(wtns)
+                c = K.CacheManager()
+                t0 = time.time()
+                c.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
+                res["cold_ms"] = (time.time() - t0) * 1e3
+                info = c.info(key)
+                res.update(shards=info.shards, device_mb=info.device_bytes / 1e6)
+                log(f"device group {device}: {info.shards} shards, {info.device_bytes / 1e6:.0f} MB of device memory, built + first prove in {res['cold_ms'] / 1e3:.2f} s")
+                for _ in range(max(1, args.warmup)):
+                    c.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
+                cm = c
+            except Exception as e:   # noqa: BLE001 — reported; every rank then agrees on the fallback
+                res["error"] = repr(e)[:400]
+                log(f"in-process device group failed: {e!r}")
+        import threading
+        th = threading.Thread(target=bring_up, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("ICICLE_SNARK_GROUP_TIMEOUT", "600")))
+        if th.is_alive():
+            hung = True
+            res["error"] = "device group bring-up did not finish in time"
+            log("in-process device group: bring-up did not finish in time; falling back to the rank-per-GPU host")
     ok = torch.tensor([0 if (rank == 0 and "error" in res) else 1], dtype=torch.int32)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
         if cm is not None:
             cm.close()
-        K.release_domain()
+        if not hung:
+            K.release_domain()
+        res["hung"] = hung
         return res if rank == 0 else {"error": "rank 0 failed"}
     dist.barrier()
     t0 = time.perf_counter()
@@ -650,9 +667,9 @@ def main():
     shutil.rmtree(tmpdir, ignore_errors=True)
     if world > 1:
         dist.destroy_process_group()
-        if rccl_hung:
+        if rccl_hung or (group or {}).get("hung"):
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)   # a thread is still inside the RCCL bootstrap
+            os._exit(0)   # a thread is still inside the RCCL bootstrap / the device group's bring-up
 
 
 if __name__ == "__main__":
