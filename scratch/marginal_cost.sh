@@ -1,0 +1,19 @@
+#!/bin/bash
+# Marginal cost of the stages of one prove, by duplication (work-bound overlapped schedule: a stage's solo duration says little
+# about what it costs the prove).  icicle-snark_amd/lib_b must be a build with -DISNARK_EXPERIMENT_DUP: ISNARK_DUP bit 0 runs the
+# first reduction level of every G1 set twice, bit 1 the same for G2, bit 2 the G1 accumulations twice, bit 3 the G2 accumulation
+# twice (all idempotent).  lib_c (optional): another variant, run interleaved.
+L=icicle-snark_amd/lib/libicicle_snark_hip.so
+cp $L /tmp/lib_a.so; cp icicle-snark_amd/lib_b/libicicle_snark_hip.so /tmp/lib_b.so
+[ -f icicle-snark_amd/lib_c/libicicle_snark_hip.so ] && cp icicle-snark_amd/lib_c/libicicle_snark_hip.so /tmp/lib_c.so
+trap 'cp /tmp/lib_a.so $L' EXIT
+for n in ${@:-1600000}; do
+export LOOP_CONSTRAINTS=$n
+run() { python scratch/prove_loop.py 40 2>/dev/null | tail -1; }
+for r in 1 2; do
+  cp /tmp/lib_a.so $L; echo "-- $n shipped : $(run)"
+  cp /tmp/lib_b.so $L
+  for m in 0 1 2 4 8; do echo "-- $n dup=$m  : $(ISNARK_DUP=$m run)"; done
+  if [ -f /tmp/lib_c.so ]; then cp /tmp/lib_c.so $L; echo "-- $n lib_c   : $(run)"; fi
+done
+done

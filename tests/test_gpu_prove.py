@@ -408,3 +408,23 @@ def test_cache_budget_evicts_least_recently_used_keys(gpu, O, S):
     c.load("b", keys["b"][0])
     assert c.prove_mem("b", keys["b"][1], 3, 4)[0] == pb
     c.close()
+
+
+def test_cache_info_sized_respects_the_callers_struct_size(gpu, cm):
+    """groth16_cache_info_sized writes no more than the caller's sizeof(Groth16CircuitInfo): a binary built against an older,
+    shorter struct is not overrun when the struct grows (round-2 advisor finding)."""
+    import ctypes as C
+    K = gpu
+    if not cm.contains("g"):
+        cm.load("g", base64.b64decode(load_golden("groth16.json")["zkey"]))
+    full = cm.info("g")
+    buf = (C.c_uint8 * 64)(*([0xAB] * 64))
+    lib = K.lib()
+    assert lib.groth16_cache_info_sized(cm._h, b"g", buf, C.c_size_t(24)) == 0
+    raw = bytes(buf)
+    assert raw[24:] == b"\xab" * 40                                     # nothing beyond the 24 bytes the caller has
+    assert int.from_bytes(raw[0:4], "little") == full.n_vars and int.from_bytes(raw[16:24], "little") == full.device_bytes
+    assert lib.groth16_cache_info_sized(cm._h, b"g", buf, C.c_size_t(64)) == 0
+    assert int.from_bytes(bytes(buf)[24:28], "little") == full.b_bases
+    assert lib.groth16_cache_info_sized(cm._h, b"nokey", buf, C.c_size_t(64)) != 0
+    assert bytes(buf)[28:32] == (0).to_bytes(4, "little")                # one shard: not a device group
