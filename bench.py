@@ -18,9 +18,10 @@ zkey/witness generated here (no circom/snarkjs offline; icicle-snark_amd/synth.p
 keyless: 2 warm-up + 10 timed proves in one process like examples/rust/src/main.rs:3-4,20-36) — labelled as stand-ins.
 With N > 1 ONE prove is sharded over the N GPUs (strong scaling): point-range shards of the A, B1, B2, C bases, residue-class
 shards of H, the QAP front end distributed, witness in 1/N slices.  Two hosts drive the same shard pipeline and both are timed:
-  * `value`: the library's own entry — rank 0 calls groth16_prove(witness, zkey, proof, public, device = "HIP:0-(N-1)"), ONE
-    process with one host thread per GPU and device-side exchanges over xGMI (csrc/prover/multi.cpp); the other ranks of
-    the launcher only take part in the barriers;
+  * `value`: the library's own entry — groth16_prove(witness, zkey, proof, public, device = "HIP:0-(N-1)"), ONE process with
+    one host thread per GPU and device-side exchanges over xGMI (csrc/prover/multi.cpp).  That process is a child of rank 0
+    (`--group-child`, released and awaited between the two barriers that bracket the K proves): a crash or a hang of a
+    path that has never run across two real GPUs then costs this leg only; the launcher's ranks take part in the barriers;
   * `config.prove_ms_rank_per_gpu`: one process per GPU (every rank of the launcher), exchanges through RCCL
     (csrc/comm/rccl_comm.cpp, icicle-snark_amd/parallel.py) — the fallback for `value` if the in-process group fails.
 
@@ -252,91 +253,169 @@ def dropin_sequence_ms(zkey, wtns, iters=7):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def inproc_group_bench(args, K, S, dist, rank, world, zkey, wtns, N, tmpdir):
-    """N GPUs through the library's own entry: rank 0 proves with device = "HIP:0-(N-1)" (one process, one host thread per GPU,
-    csrc/prover/multi.cpp); the other ranks only take part in the barriers.  Returns (on every rank) a dict with ms_per_step …
-    or {"error": …}.  ICICLE_SNARK_BENCH_DEVICES overrides the device list (test hook for 1-GPU boxes: "0,0")."""
-    import torch
-    devices = os.environ.get("ICICLE_SNARK_BENCH_DEVICES") or f"0-{world - 1}"
-    device = f"HIP:{devices}"
-    res = {}
-    cm = None
-    hung = False
-    if rank == 0:
-        zkey_path, wtns_path = os.path.join(tmpdir, "g.zkey"), os.path.join(tmpdir, "g.wtns")
-        proof_path, public_path = os.path.join(tmpdir, "g_proof.json"), os.path.join(tmpdir, "g_public.json")
-        key = f"{zkey_path}_{device}"
+def group_child(workload_unused=None):
+    """`bench.py --group-child`: the device-group leg of rank 0, in a process of its own.  Protocol on stdin / stdout (one JSON
+    object per line): build the group + first prove + warm-up → {"ready": …}; wait for the line "go"; K timed proves →
+    {"done": …}; exit.  A crash or a hang of the never-yet-run multi-GPU path then costs this leg, not the launcher's ranks."""
+    cfg = json.loads(sys.stdin.readline())
+    os.environ["ICICLE_SNARK_QUIET"] = "1"
+    out = os.fdopen(os.dup(1), "w")          # the protocol's channel; anything the library prints to fd 1 goes to stderr instead
+    os.dup2(2, 1)
 
-        def bring_up():
-            # builds the device group (cold) + first prove + warm-up; on a helper thread with a deadline: peer access, peer copies
-            # and RCCL have never run across two GPUs, and a bring-up that never returns must not hang the launcher's other ranks
-            nonlocal cm
-            try:
-                open(zkey_path, "wb").write(zkey)
-                open(wtns_path, "wb").write(wtns)
-                c = K.CacheManager()
-                t0 = time.time()
-                c.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
-                res["cold_ms"] = (time.time() - t0) * 1e3
-                info = c.info(key)
-                res.update(shards=info.shards, device_mb=info.device_bytes / 1e6)
-                log(f"device group {device}: {info.shards} shards, {info.device_bytes / 1e6:.0f} MB of device memory, built + first prove in {res['cold_ms'] / 1e3:.2f} s")
-                for _ in range(max(1, args.warmup)):
-                    c.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
-                cm = c
-            except Exception as e:   # noqa: BLE001 — reported; every rank then agrees on the fallback
-                res["error"] = repr(e)[:400]
-                log(f"in-process device group failed: {e!r}")
-        import threading
-        th = threading.Thread(target=bring_up, daemon=True)
-        th.start()
-        th.join(float(os.environ.get("ICICLE_SNARK_GROUP_TIMEOUT", "600")))
-        if th.is_alive():
-            hung = True
-            res["error"] = "device group bring-up did not finish in time"
-            log("in-process device group: bring-up did not finish in time; falling back to the rank-per-GPU host")
-    ok = torch.tensor([0 if (rank == 0 and "error" in res) else 1], dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
-        if cm is not None:
-            cm.close()
-        if not hung:
-            K.release_domain()
-        res["hung"] = hung
-        return res if rank == 0 else {"error": "rank 0 failed"}
-    dist.barrier()
-    t0 = time.perf_counter()
-    qap = msm = 0.0
-    acc, geom = [], None
-    if rank == 0:
-        for _ in range(args.steps):
+    def say(obj):
+        out.write(json.dumps(obj) + "\n")
+        out.flush()
+    try:
+        fault = os.environ.get("ICICLE_SNARK_BENCH_GROUP_FAULT")   # test hook (tests/test_gpu_fullsize.py): what the parent does when this process dies or hangs
+        if fault == "abort":
+            os.abort()
+        if fault == "hang":
+            time.sleep(3600)
+        K = importlib.import_module("icicle-snark_amd")
+        device, steps, warmup = cfg["device"], cfg["steps"], cfg["warmup"]
+        zkey_path, wtns_path, proof_path, public_path = cfg["zkey"], cfg["wtns"], cfg["proof"], cfg["public"]
+        key = f"{zkey_path}_{device}"
+        cm = K.CacheManager()
+        t0 = time.time()
+        cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
+        cold_ms = (time.time() - t0) * 1e3
+        info = cm.info(key)
+        log(f"device group {device}: {info.shards} shards, {info.device_bytes / 1e6:.0f} MB of device memory, built + first prove in {cold_ms / 1e3:.2f} s")
+        for _ in range(max(1, warmup)):
+            cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
+        K.check(K.lib().icicle_device_synchronize(), "sync")
+        say({"ready": True, "cold_ms": cold_ms, "shards": info.shards, "device_mb": info.device_bytes / 1e6})
+        if sys.stdin.readline().strip() != "go":
+            return 1
+        qap = msm = 0.0
+        acc, geom = [], None
+        t0 = time.perf_counter()
+        for _ in range(steps):
             cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
             tm = cm.last_timings(key)
             qap += tm.qap_ms
             msm += tm.msm_ms
-            prof = K.msm_profile(0)      # shard 0 runs on the calling thread: the H accumulation of its device's ring
+            prof = K.msm_profile(0)          # shard 0 runs on the calling thread: the H accumulation of its device's ring
             acc.append(prof[0][1])
             geom = prof[1]
         K.check(K.lib().icicle_device_synchronize(), "sync")
-    dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    res["ms_per_step"] = float(dt.item()) * 1e3 / args.steps
-    if rank == 0:
-        proof, public = open(proof_path).read(), open(public_path).read()
-        assert json.loads(proof)["protocol"] == "groth16"
-        res.update(proof=proof, public=public, device=device, qap_ms=qap / args.steps, msm_ms=msm / args.steps,
-                   acc_ms=sum(acc) / len(acc), acc_geom=geom)
+        child_ms = (time.perf_counter() - t0) * 1e3 / steps
+        say({"done": True, "child_ms_per_step": child_ms, "qap_ms": qap / steps, "msm_ms": msm / steps, "acc_ms": sum(acc) / len(acc), "acc_geom": geom})
+        wtns = open(wtns_path, "rb").read()
         med = []
         for _ in range(5):
             t1 = time.perf_counter()
             cm.prove_mem(key, wtns, resident=True)
             med.append((time.perf_counter() - t1) * 1e3)
-        res["resident_ms"] = sorted(med)[2]
+        say({"resident_ms": sorted(med)[2], "proof": open(proof_path).read(), "public": open(public_path).read()})
         cm.evict(key)
         cm.close()
         K.release_domain()
+        return 0
+    except Exception as e:   # noqa: BLE001 — reported to the parent, which falls back
+        say({"error": repr(e)[:400]})
+        return 1
+
+
+class _ChildLines:
+    """line reader with a deadline over a child's stdout (a reader thread feeding a queue)"""
+
+    def __init__(self, proc):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.proc = proc
+
+        def pump():
+            for line in proc.stdout:
+                self.q.put(line)
+            self.q.put(None)
+        threading.Thread(target=pump, daemon=True).start()
+
+    def get(self, timeout):
+        import queue
+        try:
+            line = self.q.get(timeout=timeout)
+        except queue.Empty:
+            return {"error": f"no answer from the device-group process within {timeout:.0f} s", "hung": True}
+        if line is None:
+            return {"error": f"the device-group process ended (exit code {self.proc.wait()})"}
+        try:
+            return json.loads(line)
+        except ValueError:
+            return {"error": f"unexpected output of the device-group process: {line[:200]!r}"}
+
+
+def inproc_group_bench(args, dist, rank, world, zkey, wtns, tmpdir):
+    """N GPUs through the library's own entry: groth16_prove with device = "HIP:0-(N-1)" — one process, one host thread per GPU
+    (csrc/prover/multi.cpp).  That process is a CHILD of rank 0 (`bench.py --group-child`): peer access, peer copies and RCCL
+    inside one process have never run across two real GPUs, and a crash or a hang there must cost this leg only — the
+    launcher's ranks then report the one-process-per-GPU host.  The ranks take part in the barriers that bracket the K timed
+    proves; rank 0 releases the child after the first barrier and waits for its answer before the second.  Returns (on every rank)
+    a dict with ms_per_step … or {"error": …}.  ICICLE_SNARK_BENCH_DEVICES overrides the device list (test hook for 1-GPU boxes: "0,0")."""
+    import torch
+    devices = os.environ.get("ICICLE_SNARK_BENCH_DEVICES") or f"0-{world - 1}"
+    device = f"HIP:{devices}"
+    res = {"device": device}
+    proc = lines = None
+    if rank == 0:
+        import subprocess
+        zkey_path, wtns_path = os.path.join(tmpdir, "g.zkey"), os.path.join(tmpdir, "g.wtns")
+        open(zkey_path, "wb").write(zkey)
+        open(wtns_path, "wb").write(wtns)
+        cfg = dict(device=device, steps=args.steps, warmup=args.warmup, zkey=zkey_path, wtns=wtns_path,
+                   proof=os.path.join(tmpdir, "g_proof.json"), public=os.path.join(tmpdir, "g_public.json"))
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+        try:
+            proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--group-child"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                    text=True, env=env, cwd=ROOT)
+            proc.stdin.write(json.dumps(cfg) + "\n")
+            proc.stdin.flush()
+            lines = _ChildLines(proc)
+            ans = lines.get(float(os.environ.get("ICICLE_SNARK_GROUP_TIMEOUT", "420")))   # cold: 8 shards built + tables + first prove
+            res.update(ans)
+        except Exception as e:   # noqa: BLE001 — reported; every rank then agrees on the fallback
+            res["error"] = repr(e)[:400]
+        if "error" in res:
+            log(f"device-group process failed: {res['error']}; falling back to the rank-per-GPU host")
+
+    def stop_child():
+        if proc is not None and proc.poll() is None:
+            proc.kill()          # this exact child
+            proc.wait()
+    ok = torch.tensor([0 if (rank == 0 and "error" in res) else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        stop_child()
+        return res if rank == 0 else {"error": "rank 0 failed"}
     dist.barrier()
+    t0 = time.perf_counter()
+    if rank == 0:
+        try:
+            proc.stdin.write("go\n")
+            proc.stdin.flush()
+            res.update(lines.get(60.0 + 2.0 * args.steps))
+        except Exception as e:   # noqa: BLE001
+            res["error"] = repr(e)[:400]
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    res["ms_per_step"] = float(dt.item()) * 1e3 / args.steps
+    if rank == 0 and "error" not in res:
+        res.update(lines.get(60.0))
+        if "error" not in res:
+            assert json.loads(res["proof"])["protocol"] == "groth16"
+            try:
+                proc.wait(timeout=60)
+            except Exception:   # noqa: BLE001 — the numbers are in; a child that does not leave is ended below
+                pass
+    ok = torch.tensor([0 if (rank == 0 and "error" in res) else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    stop_child()
+    if int(ok.item()) == 0:
+        if rank == 0:
+            log(f"device-group process failed in the timed region: {res.get('error')}; falling back to the rank-per-GPU host")
+        return res if rank == 0 else {"error": "rank 0 failed"}
     return res
 
 
@@ -351,7 +430,10 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--group-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.group_child:
+        return group_child()
     workload = args.workload or (str(args.constraints) if args.constraints else "1600k")
     if args.pmc_child:
         return pmc_child(workload)
@@ -436,10 +518,9 @@ def main():
     # N > 1, first host: the library's own multi-device entry, driven by rank 0 (see the module docstring)
     group = None
     if world > 1 and os.environ.get("ICICLE_SNARK_BENCH_INPROC", "1") != "0":
-        group = inproc_group_bench(args, K, S, dist, rank, world, zkey, wtns, N, tmpdir)
+        group = inproc_group_bench(args, dist, rank, world, zkey, wtns, tmpdir)
         if rank == 0 and "error" not in group and not standin:
             assert json.loads(group["public"]) == [str(pow(3, 1 << N, S.R_MOD))]
-        K.set_device("HIP", local_rank)
     # second host (always run with N > 1; `value` falls back to it if the group failed): one process per GPU, below
     zkey_path, wtns_path = os.path.join(tmpdir, "circuit.zkey"), os.path.join(tmpdir, "witness.wtns")
     proof_path, public_path = os.path.join(tmpdir, "proof.json"), os.path.join(tmpdir, "public.json")
@@ -667,10 +748,10 @@ def main():
     shutil.rmtree(tmpdir, ignore_errors=True)
     if world > 1:
         dist.destroy_process_group()
-        if rccl_hung or (group or {}).get("hung"):
+        if rccl_hung:
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)   # a thread is still inside the RCCL bootstrap / the device group's bring-up
+            os._exit(0)   # a thread is still inside the RCCL bootstrap
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

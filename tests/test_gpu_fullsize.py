@@ -298,6 +298,32 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert d["config"]["host"].startswith("one process, one host thread per GPU") and d["config"]["prove_ms_rank_per_gpu"] > 0
 
 
+@pytest.mark.parametrize("fault", ["abort", "hang", "no_such_device"])
+def test_bench_survives_a_failing_device_group(gpu, fault):
+    """The device-group leg of bench.py runs in a child process of rank 0: when that process aborts, hangs (ended after
+    ICICLE_SNARK_GROUP_TIMEOUT) or fails (a device that does not exist), the launcher's ranks agree on the fallback and the one
+    JSON line carries the one-process-per-GPU host's numbers with the error recorded."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ICICLE_SNARK_BENCH_DEVICE="0", ICICLE_SNARK_BENCH_EXCHANGE="gloo", ICICLE_SNARK_BENCH_DEVICES="0,0", ICICLE_SNARK_GROUP_TIMEOUT="20")
+    if fault == "no_such_device":
+        env["ICICLE_SNARK_BENCH_DEVICES"] = "0,97"
+    else:
+        env["ICICLE_SNARK_BENCH_GROUP_FAULT"] = fault
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--constraints", "100000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["device_group"]["error"] and d["config"]["host"] == "one process per GPU"
+    assert abs(d["ms_per_step"] - d["config"]["prove_ms_rank_per_gpu"]) < 1e-9
+
+
 def test_benchmark_3200k_sharded_commitments(gpu, O):
     """BASELINE config 3 (benchmark/3200k, MSMs sharded over 8 GPUs) through the entry a caller uses — one key over a device
     group of EIGHT shards in one process (csrc/prover/multi.cpp; all eight "devices" are GPU 0 on this box): point-range shards
