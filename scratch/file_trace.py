@@ -16,3 +16,8 @@ for i in range(8):
     t = time.perf_counter()
     cm.prove_files(wp, zp, d + "/p.json", d + "/q.json")
     print(f"call {i}: {1e3 * (time.perf_counter() - t):.3f} ms", file=sys.stderr, flush=True)
+print("---- host-witness (prove_mem) ----", file=sys.stderr, flush=True)
+for i in range(4):
+    t = time.perf_counter()
+    cm.prove_mem(zp + "_HIP", wtns)
+    print(f"mem call {i}: {1e3 * (time.perf_counter() - t):.3f} ms", file=sys.stderr, flush=True)
