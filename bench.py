@@ -284,7 +284,18 @@ def group_child(workload_unused=None):
         for _ in range(max(1, warmup)):
             cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
         K.check(K.lib().icicle_device_synchronize(), "sync")
-        say({"ready": True, "cold_ms": cold_ms, "shards": info.shards, "device_mb": info.device_bytes / 1e6})
+        # the group's proof for fixed blinding scalars must be the one a single GPU computes (untimed; the exchanges have never
+        # crossed two real GPUs before the run this guards)
+        wtns = open(wtns_path, "rb").read()
+        want_key = "single_device_check"
+        cm.load(want_key, open(zkey_path, "rb").read(), device_id=K.parse_device(device)[0])
+        want = cm.prove_mem(want_key, wtns, 5, 9)[0]
+        cm.evict(want_key)
+        for rep in range(2):
+            if cm.prove_mem(key, wtns, 5, 9)[0] != want:
+                raise RuntimeError(f"the device group's proof differs from the single-device proof for the same (r, s) (repeat {rep})")
+        K.set_device("HIP", K.parse_device(device)[0])
+        say({"ready": True, "cold_ms": cold_ms, "shards": info.shards, "device_mb": info.device_bytes / 1e6, "equals_single_device_proof": True})
         if sys.stdin.readline().strip() != "go":
             return 1
         qap = msm = 0.0
@@ -301,7 +312,6 @@ def group_child(workload_unused=None):
         K.check(K.lib().icicle_device_synchronize(), "sync")
         child_ms = (time.perf_counter() - t0) * 1e3 / steps
         say({"done": True, "child_ms_per_step": child_ms, "qap_ms": qap / steps, "msm_ms": msm / steps, "acc_ms": sum(acc) / len(acc), "acc_geom": geom})
-        wtns = open(wtns_path, "rb").read()
         med = []
         for _ in range(5):
             t1 = time.perf_counter()
@@ -720,7 +730,7 @@ def main():
                        # N > 1: the other host of the same shard pipeline — one process per GPU, exchanges through type(exch)
                        "prove_ms_rank_per_gpu": ranks_ms_per_step if world > 1 else None,
                        "rank_per_gpu_exchange": type(exch).__name__ if world > 1 else None,
-                       "device_group": ({k: group.get(k) for k in ("device", "shards", "device_mb", "cold_ms", "resident_ms", "error")} if group else None),
+                       "device_group": ({k: group.get(k) for k in ("device", "shards", "device_mb", "cold_ms", "resident_ms", "equals_single_device_proof", "error")} if group else None),
                        "qap_front_end": ("distributed: rows split by residue class, two all-to-alls of 3*(n/N)*32 B per rank" if world > 1 and dist_qap[0]
                                          else ("replicated on every rank" if world > 1 else "single GPU")),
                        "witness_upload": ("1/N of the witness per rank over PCIe + in-place all-gather over the exchange" if world > 1 and shard_w[0]

@@ -16,4 +16,7 @@ hipError_t xchg_allgather_pull(const PeerPtrs& bufs, uint32_t G, uint32_t me, si
 // all-to-all of [row][peer][chunk] buffers: recv[q][p] = sends.p[p][q][me]
 hipError_t xchg_alltoall_pull(const PeerPtrs& sends, void* recv, uint32_t G, uint32_t me, uint32_t rows, size_t row_bytes, size_t chunk_bytes, hipStream_t s);
 
+// a single-lane kernel that occupies stream `s` for about `ms` milliseconds (exchange self-test: makes the producers late)
+hipError_t xchg_delay(double ms, hipStream_t s);
+
 } // namespace isnark

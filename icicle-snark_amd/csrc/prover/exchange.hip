@@ -31,7 +31,27 @@ __global__ __launch_bounds__(256) void xchg_alltoall_pull_kernel(PeerPtrs send, 
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunk_u4; i += (uint64_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+// one lane spins for `ticks` of the constant-rate wall clock (self-test of the exchanges' ordering)
+__global__ void xchg_delay_kernel(uint64_t ticks)
+{
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 } // namespace
+
+hipError_t xchg_delay(double ms, hipStream_t s)
+{
+  int dev = 0, khz = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+    (void)hipGetLastError();
+    khz = 100000; // 100 MHz on CDNA3/4
+  }
+  hipLaunchKernelGGL(xchg_delay_kernel, dim3(1), dim3(1), 0, s, (uint64_t)(ms * (double)khz));
+  return hipGetLastError();
+}
 
 hipError_t xchg_allgather_pull(const PeerPtrs& bufs, uint32_t G, uint32_t me, size_t slice_bytes, hipStream_t s)
 {

@@ -235,12 +235,15 @@ struct RunState {
   }
 };
 
-// one pattern all-gather + all-to-all through the group's transport, verified on the host
+// one pattern all-gather + all-to-all through the group's transport, verified on the host.  The producers are made LATE on
+// purpose — a delay kernel sits in front of the copies that put the patterns in place, and nothing synchronises the host
+// before the peers enqueue their side — so a transport whose cross-device ordering does not hold (an event of one device
+// that fails to hold back a stream of another) reads the zeroed buffers and is rejected here, not in a proof.
 static int exchange_self_test(DeviceGroup* g)
 {
   const int G = (int)g->devs.size();
   const size_t slice = 4096, chunk = 1024, rows = 3, row_bytes = chunk * G;
-  std::vector<uint8_t*> ag(G, nullptr), snd(G, nullptr), rcv(G, nullptr);
+  std::vector<uint8_t*> ag(G, nullptr), snd(G, nullptr), rcv(G, nullptr), stage(G, nullptr);
   std::vector<void*> agv(G), sndv(G);
   RunState st;
   std::vector<int> bad(G, 0);
@@ -248,28 +251,42 @@ static int exchange_self_test(DeviceGroup* g)
     int rc = set_active_device(g->devs[r]);
     ZKeyCache* z = g->shards[r].get();
     hipStream_t s = z->s_qap;
-    auto step = [&]() -> int {
+    // patterns into a staging buffer, exchange buffers zeroed — all complete before anybody goes on
+    auto prepare = [&]() -> int {
       P_HIP(hipMalloc((void**)&ag[r], slice * G));
       P_HIP(hipMalloc((void**)&snd[r], rows * row_bytes));
       P_HIP(hipMalloc((void**)&rcv[r], rows * row_bytes));
-      std::vector<uint8_t> h(std::max(slice * G, rows * row_bytes), 0);
-      for (size_t i = 0; i < slice; i++) h[(size_t)r * slice + i] = (uint8_t)(r * 31 + i * 7 + 1);
-      P_HIP(hipMemcpyAsync(ag[r], h.data(), slice * G, hipMemcpyHostToDevice, s));
-      P_HIP(hipStreamSynchronize(s));
+      P_HIP(hipMalloc((void**)&stage[r], slice + rows * row_bytes));
+      std::vector<uint8_t> h(slice + rows * row_bytes, 0);
+      for (size_t i = 0; i < slice; i++) h[i] = (uint8_t)(r * 31 + i * 7 + 1);
       for (size_t q = 0; q < rows; q++)
         for (int p = 0; p < G; p++)
-          for (size_t i = 0; i < chunk; i++) h[q * row_bytes + (size_t)p * chunk + i] = (uint8_t)(r * 17 + p * 5 + q * 3 + i);
-      P_HIP(hipMemcpyAsync(snd[r], h.data(), rows * row_bytes, hipMemcpyHostToDevice, s));
+          for (size_t i = 0; i < chunk; i++) h[slice + q * row_bytes + (size_t)p * chunk + i] = (uint8_t)(r * 17 + p * 5 + q * 3 + i);
+      P_HIP(hipMemcpyAsync(stage[r], h.data(), h.size(), hipMemcpyHostToDevice, s));
+      P_HIP(hipMemsetAsync(ag[r], 0, slice * G, s));
+      P_HIP(hipMemsetAsync(snd[r], 0, rows * row_bytes, s));
       P_HIP(hipMemsetAsync(rcv[r], 0, rows * row_bytes, s));
-      P_HIP(hipEventRecord(g->ev_slice[r], s));
       P_HIP(hipStreamSynchronize(s));
       return 0;
     };
-    if (!rc) rc = step();
+    // the late producer: delay, then the patterns move into the buffers the peers read; the event is all the peers get
+    auto produce = [&]() -> int {
+      P_HIP(xchg_delay(3.0, s));
+      P_HIP(hipMemcpyAsync(ag[r] + (size_t)r * slice, stage[r], slice, hipMemcpyDeviceToDevice, s));
+      P_HIP(hipMemcpyAsync(snd[r], stage[r] + slice, rows * row_bytes, hipMemcpyDeviceToDevice, s));
+      P_HIP(hipEventRecord(g->ev_slice[r], s));
+      return 0;
+    };
+    if (!rc) rc = prepare();
+    st.note(rc);
+    g->team->barrier(); // every buffer exists and is zero
+    if (!st.failed) {
+      rc = produce();
+      st.note(rc);
+    }
     agv[r] = ag[r];
     sndv[r] = snd[r];
-    st.note(rc);
-    g->team->barrier();
+    g->team->barrier(); // every ev_slice is recorded (enqueued, not complete)
     if (!st.failed) {
       rc = xchg_allgather(g, r, agv.data(), slice, g->ev_slice.data(), s);
       if (!rc) rc = xchg_alltoall(g, r, sndv.data(), rcv[r], (uint32_t)rows, row_bytes, chunk, g->ev_slice.data(), s);
@@ -295,7 +312,7 @@ static int exchange_self_test(DeviceGroup* g)
             }
     }
     g->team->barrier(); // nobody frees a buffer a peer may still be reading
-    for (uint8_t* p : {ag[r], snd[r], rcv[r]})
+    for (uint8_t* p : {ag[r], snd[r], rcv[r], stage[r]})
       if (p) (void)hipFree(p);
   });
   if (int rc = st.finish()) return rc;
