@@ -236,8 +236,8 @@ struct RunState {
 };
 
 // one pattern all-gather + all-to-all through the group's transport, verified on the host.  The producers are made LATE on
-// purpose — a delay kernel sits in front of the copies that put the patterns in place, and nothing synchronises the host
-// before the peers enqueue their side — so a transport whose cross-device ordering does not hold (an event of one device
+// purpose — a delay kernel (longer on every next rank) sits in front of the copies that put the patterns in place, and nothing
+// synchronises the host before the peers enqueue their side — so a transport whose cross-device ordering does not hold (an event of one device
 // that fails to hold back a stream of another) reads the zeroed buffers and is rejected here, not in a proof.
 static int exchange_self_test(DeviceGroup* g)
 {
@@ -269,9 +269,11 @@ static int exchange_self_test(DeviceGroup* g)
       P_HIP(hipStreamSynchronize(s));
       return 0;
     };
-    // the late producer: delay, then the patterns move into the buffers the peers read; the event is all the peers get
+    // the late producer: delay, then the patterns move into the buffers the peers read; the event is all the peers get.
+    // The delays differ by rank (this rank's own exchange sits behind its own delay on the same stream): rank 0 is through
+    // after 2 ms and would read rank 1's still-zero buffers 2 ms too early, rank 1 rank 2's, …
     auto produce = [&]() -> int {
-      P_HIP(xchg_delay(3.0, s));
+      P_HIP(xchg_delay(2.0 * (r + 1), s));
       P_HIP(hipMemcpyAsync(ag[r] + (size_t)r * slice, stage[r], slice, hipMemcpyDeviceToDevice, s));
       P_HIP(hipMemcpyAsync(snd[r], stage[r] + slice, rows * row_bytes, hipMemcpyDeviceToDevice, s));
       P_HIP(hipEventRecord(g->ev_slice[r], s));
