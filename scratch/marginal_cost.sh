@@ -13,7 +13,7 @@ run() { python scratch/prove_loop.py 40 2>/dev/null | tail -1; }
 for r in 1 2; do
   cp /tmp/lib_a.so $L; echo "-- $n shipped : $(run)"
   cp /tmp/lib_b.so $L
-  for m in 0 1 2 4 8; do echo "-- $n dup=$m  : $(ISNARK_DUP=$m run)"; done
+  for m in ${DUP_MASKS:-0 1 2 4 8}; do echo "-- $n dup=$m  : $(ISNARK_DUP=$m run)"; done
   if [ -f /tmp/lib_c.so ]; then cp /tmp/lib_c.so $L; echo "-- $n lib_c   : $(run)"; fi
 done
 done
