@@ -19,7 +19,12 @@ namespace prover {
 
 ZKeyCache::~ZKeyCache()
   {
+    // (an eviction must not leave the caller's thread on another device)
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
     (void)hipSetDevice(device_id);
+    if (s_qap) (void)hipStreamSynchronize(s_qap);
     if (s_g1) (void)hipStreamSynchronize(s_g1);
     if (s_g2) (void)hipStreamSynchronize(s_g2);
     if (s_g3) (void)hipStreamSynchronize(s_g3);

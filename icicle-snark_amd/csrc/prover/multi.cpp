@@ -101,6 +101,9 @@ struct DeviceGroup {
   std::vector<hipEvent_t> ev_slice, ev_s1, ev_s2; // per shard, recorded on its s_qap: slice resident / stage 1 done / stage 2 done
   ~DeviceGroup()
   {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
     team.reset();
     for (size_t r = 0; r < comms.size(); r++)
       if (comms[r] && rccl.destroy) (void)rccl.destroy(comms[r]);

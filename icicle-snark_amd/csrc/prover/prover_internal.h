@@ -119,7 +119,6 @@ struct ZKeyCache {
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
   hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
              ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_xchg = nullptr; // group prove: "what the peers pull from this shard next is complete" (recorded on s_qap)
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
   bool witness_event_set = false; // ev_witness was already recorded for the resident witness (behind a device-side all-gather)
