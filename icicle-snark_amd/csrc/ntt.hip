@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "ff.h"
+#include "fr29.h"
 #include "ntt_fuse.h"
 
 using namespace bn254;
@@ -46,6 +47,7 @@ const uint32_t ROU28[8] = {0x725b19f0, 0x9bd61b6e, 0x41112ed4, 0x402d111e, 0x8ef
 
 struct Domain {
   fe* tw = nullptr; // tw[i] = root^i, Montgomery form, i in [0, N)
+  fe* tw29 = nullptr; // the same roots as root^i·2^261 (packed canonical): twiddles of the radix-2^29 passes (fr29.h)
   int log_n = -1;
   fe root_std;
   int device = -1;
@@ -399,6 +401,258 @@ __global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ 
   }
 }
 
+// ---- the same pass on the lazy radix-2^29 field (fr29.h) --------------------------------------------------------------------------
+// Full 2048-element tiles only, at most 8 bits per pass.  Differences from ntt_pass_kernel:
+//  * the tile holds NINE words per element — two uint4 planes + one word plane (72 KiB) — and the stage twiddles stay packed
+//    (32 B, Montgomery-261, unpacked at use), so two workgroups still share a CU's LDS;
+//  * a butterfly is  s = norm(a + b),  d = (a + K·r − b)·w :  nine-instruction add / sub, a 27-instruction carry pass, and a
+//    product of 153 multiply-adds (the 8×32-bit form: ≈ 40 + 40 + 300).  Values are NOT reduced after additions: the bound of
+//    level l's inputs (in multiples of r) is tracked on the host (Plan29), which hands the kernel the borrow-proof constant
+//    K_l·r of every level and says whether the tile needs one `shrink` before its last round;
+//  * everything that leaves a pass has gone through a product (inter-pass twiddle, 1/n, per-element scale) and is < 4·r, which
+//    fits the packed 32-byte form; the LAST pass of a transform stores canonical values.
+struct Plan29 {
+  uint32_t kc[8][9];   // level l: K_l·r, borrow-proof (fr29::kr_borrow_proof)
+  int shrink_last;     // apply fr29::shrink to the operands of the last round
+};
+struct Lds29 {
+  uint4 *lo, *hi;
+  uint32_t* top;
+};
+__device__ __forceinline__ fe9 lds_get9(const Lds29& t, int idx)
+{
+  const uint4 a = t.lo[idx], b = t.hi[idx];
+  fe9 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = t.top[idx];
+  return r;
+}
+__device__ __forceinline__ void lds_put9(const Lds29& t, int idx, const fe9& v)
+{
+  t.lo[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  t.hi[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  t.top[idx] = v.l[8];
+}
+// a + K·r − b with the level's constant from the kernel arguments (scalar registers)
+__device__ __forceinline__ fe9 sub_k(const fe9& a, const fe9& b, const uint32_t (&kc)[9])
+{
+  fe9 o;
+#pragma unroll
+  for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + (kc[i] - b.l[i]);
+  return o;
+}
+#define NTT_BF9(a, b, e, L)                                                                                    \
+  {                                                                                                            \
+    const fe9 s_ = fr29::norm(fr29::add(x[a], x[b]));                                                          \
+    const fe9 d_ = sub_k(x[a], x[b], pl.kc[L]);                                                                \
+    x[a] = s_;                                                                                                 \
+    x[b] = fr29::mul(d_, fr29::unpack(lds_get(twlo, twhi, (e))));                                              \
+  }
+#define NTT_BF9_1(a, b, L)                                                                                     \
+  {                                                                                                            \
+    const fe9 s_ = fr29::norm(fr29::add(x[a], x[b]));                                                          \
+    x[b] = fr29::norm(sub_k(x[a], x[b], pl.kc[L]));                                                            \
+    x[a] = s_;                                                                                                 \
+  }
+template <int Q>
+__device__ __forceinline__ void dif_butterfly9(fe9 (&x)[1 << Q], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl);
+template <>
+__device__ __forceinline__ void dif_butterfly9<3>(fe9 (&x)[8], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+{
+  const int g = 1 << (log_m - 3);
+  const int s0 = log_r - log_m, s1 = s0 + 1, s2 = s0 + 2;
+  NTT_BF9(0, 4, j << s0, s0) NTT_BF9(1, 5, (j + g) << s0, s0) NTT_BF9(2, 6, (j + 2 * g) << s0, s0) NTT_BF9(3, 7, (j + 3 * g) << s0, s0)
+  NTT_BF9(0, 2, j << s1, s1) NTT_BF9(1, 3, (j + g) << s1, s1) NTT_BF9(4, 6, j << s1, s1) NTT_BF9(5, 7, (j + g) << s1, s1)
+  NTT_BF9(0, 1, j << s2, s2) NTT_BF9(2, 3, j << s2, s2) NTT_BF9(4, 5, j << s2, s2) NTT_BF9(6, 7, j << s2, s2)
+}
+template <int Q>
+__device__ __forceinline__ void dif_butterfly9_last(fe9 (&x)[1 << Q], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl);
+template <>
+__device__ __forceinline__ void dif_butterfly9_last<3>(fe9 (&x)[8], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+{
+  const int s0 = log_r - 3, s1 = s0 + 1, s2 = s0 + 2;
+  NTT_BF9_1(0, 4, s0) NTT_BF9(1, 5, 1 << s0, s0) NTT_BF9(2, 6, 2 << s0, s0) NTT_BF9(3, 7, 3 << s0, s0)
+  NTT_BF9_1(0, 2, s1) NTT_BF9(1, 3, 1 << s1, s1) NTT_BF9_1(4, 6, s1) NTT_BF9(5, 7, 1 << s1, s1)
+  NTT_BF9_1(0, 1, s2) NTT_BF9_1(2, 3, s2) NTT_BF9_1(4, 5, s2) NTT_BF9_1(6, 7, s2)
+}
+template <>
+__device__ __forceinline__ void dif_butterfly9_last<2>(fe9 (&x)[4], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+{
+  const int s0 = log_r - 2, s1 = s0 + 1;
+  NTT_BF9_1(0, 2, s0) NTT_BF9(1, 3, 1 << s0, s0)
+  NTT_BF9_1(0, 1, s1) NTT_BF9_1(2, 3, s1)
+}
+template <>
+__device__ __forceinline__ void dif_butterfly9_last<1>(fe9 (&x)[2], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+{
+  NTT_BF9_1(0, 1, log_r - 1)
+}
+#undef NTT_BF9_1
+#undef NTT_BF9
+
+template <int Q, bool LAST>
+__device__ __forceinline__ void dif_round9(const Lds29& t, const uint4* twlo, const uint4* twhi, int log_m, int log_r, int log_c, int tid, const Plan29& pl)
+{
+  const int C = 1 << log_c;
+  const int log_g = log_m - Q;
+#pragma unroll
+  for (int u = 0; u < (8 >> Q); u++) {
+    const int gi = tid * (8 >> Q) + u;
+    const int c = gi & (C - 1);
+    const int rest = gi >> log_c;
+    const int j = rest & ((1 << log_g) - 1);
+    const int blk = rest >> log_g;
+    const int base_row = (blk << log_m) + j;
+    fe9 x[1 << Q];
+#pragma unroll
+    for (int k = 0; k < (1 << Q); k++) x[k] = lds_get9(t, ((base_row + (k << log_g)) << log_c) + c);
+    if constexpr (LAST) {
+      if (pl.shrink_last) {
+#pragma unroll
+        for (int k = 0; k < (1 << Q); k++) x[k] = fr29::shrink(x[k]);
+      }
+      dif_butterfly9_last<Q>(x, log_r, twlo, twhi, pl);
+    } else dif_butterfly9<Q>(x, j, log_m, log_r, twlo, twhi, pl);
+#pragma unroll
+    for (int k = 0; k < (1 << Q); k++) lds_put9(t, ((base_row + (k << log_g)) << log_c) + c, x[k]);
+  }
+}
+
+// x·2^5 of an N value below 4 (→ N, below 128): the factor a Montgomery-256 operand leaves behind in a 2^261 product
+__device__ __forceinline__ fe9 shl5(const fe9& a)
+{
+  fe9 o;
+  o.l[0] = (a.l[0] & 0xffffffu) << 5;
+#pragma unroll
+  for (int i = 1; i < 8; i++) o.l[i] = ((a.l[i] & 0xffffffu) << 5) | (a.l[i - 1] >> 24);
+  o.l[8] = (a.l[8] << 5) | (a.l[7] >> 24);
+  return o;
+}
+
+// MODE as in ntt_tile_row
+template <int MODE>
+__device__ __forceinline__ void ntt_tile_row9(const fe* __restrict__ src, fe* __restrict__ dst, const fe* __restrict__ tw29, const PassParams& p, const Plan29& pl, const fe& ninv261, const Lds29& t,
+                                              const uint4* twlo, const uint4* twhi, uint32_t b_lo, uint64_t out_off, int tid)
+{
+  const int R = 1 << p.log_r, C = 1 << p.log_c;
+  {
+    fe v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = tid + u * NT;
+      int r, c;
+      if (p.load_rows_fastest) { r = e & (R - 1); c = e >> p.log_r; }
+      else { c = e & (C - 1); r = e >> p.log_c; }
+      v[u] = g_get(src + (uint64_t)r * p.in_row + (uint64_t)c * p.in_col);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = tid + u * NT;
+      int r, c;
+      if (p.load_rows_fastest) { r = e & (R - 1); c = e >> p.log_r; }
+      else { c = e & (C - 1); r = e >> p.log_c; }
+      lds_put9(t, (r << p.log_c) + c, fr29::unpack(v[u]));
+    }
+  }
+  __syncthreads();
+  {
+    int log_m = p.log_r;
+    while (log_m > 3) {
+      dif_round9<3, false>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
+      __syncthreads();
+      log_m -= 3;
+    }
+    if (log_m == 3) dif_round9<3, true>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
+    else if (log_m == 2) dif_round9<2, true>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
+    else dif_round9<1, true>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
+    __syncthreads();
+  }
+  if (MODE != 0) {
+    // fused epilogue (see ntt_tile_row): B̂ canonical → dst;  Â·B̂ (standard form, < 2·r) → dst;  Â·B̂ − Ĉ' canonical → dst
+#pragma unroll 1
+    for (int u0 = 0; u0 < 8; u0 += 4) {
+      fe y[4];
+      fe* q[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = tid + (u0 + u) * NT;
+        const int c = e & (C - 1);
+        const uint32_t kk = __brev((uint32_t)(e >> p.log_c)) >> (32 - p.log_r);
+        q[u] = dst + (uint64_t)kk * p.out_row + (uint64_t)c * p.out_col;
+        if (MODE != 1) y[u] = g_get(q[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const fe9 x = lds_get9(t, tid + (u0 + u) * NT);
+        if (MODE == 1) g_put(q[u], fr29::pack(fr29::canon(x)));
+        else if (MODE == 2) g_put(q[u], fr29::pack(fr29::mul(fr29::mul(x, fr29::unpack(y[u])), fr29::r2())));
+        else g_put(q[u], fr29::pack(fr29::canon(fr29::norm(fr29::sub<600>(fr29::unpack(y[u]), x)))));
+      }
+    }
+    return;
+  }
+  for (int e0 = tid; e0 < NT * 8; e0 += NT * 4) {
+    fe w[4];
+    uint32_t kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * NT;
+      const int c = e & (C - 1);
+      kk[u] = __brev((uint32_t)(e >> p.log_c)) >> (32 - p.log_r);
+      if (p.tw_mul) w[u] = g_get(tw29 + tw_index(kk[u] * ((b_lo << p.log_c) + c) * p.tw_mul, p.n_mask, p.inverse)); // (index 0: the Montgomery one)
+      else if (p.scale_tab) w[u] = g_get(p.scale_tab + (out_off + (uint64_t)kk[u] * p.out_row + (uint64_t)c * p.out_col) * p.scale_stride);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * NT;
+      const int c = e & (C - 1);
+      fe9 x = lds_get9(t, e);
+      if (p.tw_mul) x = fr29::mul(x, fr29::unpack(w[u]));                               // < 4 (fits 32 bytes); not the last pass
+      else if (p.scale_tab) x = fr29::canon(shl5(fr29::mul(x, fr29::unpack(w[u]))));     // the caller's table is Montgomery-256: ·2^5 afterwards
+      else if (p.scale) x = fr29::canon4(fr29::mul(x, fr29::unpack(ninv261)));
+      else x = fr29::canon(x);
+      g_put(dst + (uint64_t)kk[u] * p.out_row + (uint64_t)c * p.out_col, fr29::pack(x));
+    }
+  }
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(NT, 2) void ntt_pass29_kernel(const fe* __restrict__ in, fe* __restrict__ out, const fe* __restrict__ tw29, PassParams p, Plan29 pl, fe ninv261)
+{
+  ISNARK_CRITICAL_CHAIN_KERNEL();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int R = 1 << p.log_r, RC = NT * 8;
+  Lds29 t;
+  t.lo = reinterpret_cast<uint4*>(smem);
+  t.hi = t.lo + RC;
+  uint4* twlo = t.hi + RC; // R/2 packed twiddles
+  uint4* twhi = twlo + (R >> 1);
+  t.top = reinterpret_cast<uint32_t*>(twhi + (R >> 1));
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t b_hi = b >> p.tiles_per_group_log, b_lo = b & ((1u << p.tiles_per_group_log) - 1);
+  const uint64_t in_off = b_hi * p.in_hi + b_lo * p.in_lo, out_off = b_hi * p.out_hi + b_lo * p.out_lo;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < (R >> 1); e += NT) lds_put(twlo, twhi, e, g_get(tw29 + tw_index((uint32_t)e * p.stage_stride, p.n_mask, p.inverse)));
+  if (!FUSE) {
+    ntt_tile_row9<0>(in + (uint64_t)blockIdx.y * p.batch_stride + in_off, out + (uint64_t)blockIdx.y * p.batch_stride + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+  } else {
+    ntt_tile_row9<1>(in + in_off, out + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+    __syncthreads();
+    ntt_tile_row9<2>(in + p.batch_stride + in_off, out + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+    __syncthreads();
+    ntt_tile_row9<3>(in + 2 * p.batch_stride + in_off, out + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+  }
+}
+
+// tw29[i] = tw[i]·2^5 (Montgomery-256 → Montgomery-261), packed canonical
+__global__ __launch_bounds__(256) void twiddles_to_261_kernel(const fe* __restrict__ tw, fe* __restrict__ tw29, uint64_t n)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g_put(tw29 + i, fr29::pack(fr29::canon4(fr29::mul(fr29::unpack(g_get(tw + i)), fr29::c256_to_261()))));
+}
+
 // natural row-major (b·n + i)  ↔  caller layout (bit-reversed index and/or columns_batch).  scatter = 0: out[b·n + i] =
 // in[caller(b, i)] ; scatter = 1: out[caller(b, i)] = in[b·n + i]
 __global__ __launch_bounds__(256) void relayout_kernel(const fe* __restrict__ in, fe* __restrict__ out, uint64_t n, int batch, int logn, int rev, int cols, int scatter)
@@ -498,7 +752,18 @@ ISNARK_API eIcicleError bn254_ntt_init_domain(const bn254_scalar_t* primitive_ro
   ICICLE_TRY(check_launch("gen_twiddles"));
   HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED); // pw (host vector) and dpw lifetimes
   if (dpw) (void)hipFree(dpw);
+  // the same roots in Montgomery-261 form for the radix-2^29 passes (fr29.h); without the memory for it those stay off
+  fe* tw29 = nullptr;
+  if (hipMalloc(&tw29, N * sizeof(fe)) == hipSuccess) {
+    hipLaunchKernelGGL(twiddles_to_261_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tw, tw29, N);
+    ICICLE_TRY(check_launch("twiddles_to_261"));
+    HIP_TRY(hipStreamSynchronize(s), ICICLE_SYNCHRONIZATION_FAILED);
+  } else {
+    (void)hipGetLastError();
+    tw29 = nullptr;
+  }
   g_dom.tw = tw;
+  g_dom.tw29 = tw29;
   g_dom.log_n = k;
   g_dom.root_std = root;
   (void)hipGetDevice(&g_dom.device);
@@ -511,6 +776,7 @@ ISNARK_API eIcicleError bn254_ntt_release_domain(void)
   if (g_dom.tw) {
     (void)hipDeviceSynchronize();
     (void)hipFree(g_dom.tw);
+    if (g_dom.tw29) (void)hipFree(g_dom.tw29);
   }
   Domain& d = g_dom;
   d = Domain();
@@ -531,6 +797,65 @@ ISNARK_API eIcicleError bn254_get_root_of_unity_from_domain(uint64_t logn, bn254
   memcpy(rou->limbs, w.l, 32);
   return ICICLE_SUCCESS;
 }
+
+namespace {
+// pass plan of the radix-2^29 kernel: 2 or 3 passes of 4 … 8 bits whose tiles are all full (2048 elements), fewest LDS rounds
+bool plan29(int logn, int& np, int (&lr)[3])
+{
+  int best = 1 << 30;
+  auto full = [&](const int* l, int n) {
+    uint64_t rem = 1ull << logn;
+    for (int pi = 0; pi < n; pi++) {
+      const uint64_t C = 1ull << (LOG_TILE - l[pi]);
+      if (pi < n - 1) {
+        const uint64_t tail = rem >> l[pi];
+        if (C > tail) return false;
+        rem = tail;
+      } else if (C > (1ull << l[0])) return false;
+    }
+    return true;
+  };
+  for (int a = 8; a >= 4; a--)
+    for (int b = 8; b >= 4; b--) {
+      {
+        const int l2[2] = {a, b};
+        const int cost = (a + 2) / 3 + (b + 2) / 3;
+        if (a + b == logn && cost < best && full(l2, 2)) { best = cost; np = 2; lr[0] = a; lr[1] = b; lr[2] = 0; }
+      }
+      for (int c = 8; c >= 4; c--) {
+        const int l3[3] = {a, b, c};
+        const int cost = (a + 2) / 3 + (b + 2) / 3 + (c + 2) / 3 + 1; // a third pass costs more than a round
+        if (a + b + c == logn && cost < best && full(l3, 3)) { best = cost; np = 3; lr[0] = a; lr[1] = b; lr[2] = c; }
+      }
+    }
+  return best < (1 << 30);
+}
+// value bounds of one pass (multiples of r): b_in at the load, ×2 per level (sums), 2B + 1 per level of the last round (its unit
+// twiddles leave differences unmultiplied); one shrink (B → B/4 + 1) in front of the last round when the end would pass `limit`
+bool bounds29(int log_r, uint32_t b_in, uint32_t limit, Plan29& pl)
+{
+  memset(&pl, 0, sizeof pl);
+  const int q_last = log_r % 3 ? log_r % 3 : 3;
+  uint32_t B = b_in;
+  for (int l = 0; l < log_r; l++) {
+    const bool last_round = l >= log_r - q_last;
+    if (l == log_r - q_last) {
+      uint32_t e = B;
+      for (int k = 0; k < q_last; k++) e = 2 * e + 1;
+      if (e > limit) {
+        pl.shrink_last = 1;
+        B = B / 4 + 2;
+      }
+    }
+    const uint32_t K = B + 1;
+    if (B + K >= 1350) return false;
+    const fr29::Limbs9 c = fr29::kr_borrow_proof(K);
+    for (int i = 0; i < 9; i++) pl.kc[l][i] = c.v[i];
+    B = last_round ? 2 * B + 1 : 2 * B;
+  }
+  return B <= limit;
+}
+} // namespace
 
 namespace {
 eIcicleError ntt_impl(const bn254_scalar_t* input, int size, NTTDir dir, const NTTConfig* cfg, bn254_scalar_t* output, const isnark::NttFuse* fuse)
@@ -607,6 +932,14 @@ eIcicleError ntt_impl(const bn254_scalar_t* input, int size, NTTDir dir, const N
   if (logn <= MAX_LOG_R) { np = 1; lr[0] = logn; }
   else if (logn <= 2 * MAX_LOG_R) { np = 2; lr[0] = (logn + 1) / 2; lr[1] = logn / 2; }
   else { np = 3; lr[0] = MAX_LOG_R; lr[1] = (logn - MAX_LOG_R + 1) / 2; lr[2] = (logn - MAX_LOG_R) / 2; } // 9 bits = three radix-8 rounds
+  // transforms whose passes can all work on full tiles of at most 8 bits run on the lazy radix-2^29 field (ntt_pass29_kernel)
+  static const bool allow29 = !(getenv("ICICLE_SNARK_NTT29") && atoi(getenv("ICICLE_SNARK_NTT29")) == 0);
+  int np29 = 0, lr29[3] = {0, 0, 0};
+  const bool use29 = allow29 && dom.tw29 && plan29(logn, np29, lr29);
+  if (use29) {
+    np = np29;
+    for (int k = 0; k < 3; k++) lr[k] = lr29[k];
+  }
 
   fe* scratch = nullptr;
   WsScoped<fe> scratch_block;
@@ -690,6 +1023,28 @@ eIcicleError ntt_impl(const bn254_scalar_t* input, int size, NTTDir dir, const N
       p.scale_tab = fuse->scale_tab;
       p.scale_stride = fuse->scale_stride;
     }
+    Plan29 pl29;
+    size_t lds29 = 0;
+    fe ninv261 = ninv;
+    if (use29) {
+      // bounds: the first pass reads canonical values, later ones what a pass stored (< 4); a pass ends in a product (→ < 4) except
+      // the last pass of a plain forward transform and the fused epilogue (→ canon / sub<600>)
+      const bool ends_in_product = !last || (inverse && true);
+      if (!full_tile || !bounds29(p.log_r, pi == 0 ? 1u : 4u, ends_in_product ? 506u : 598u, pl29)) {
+        set_last_error("ntt: internal error — no radix-2^29 bound plan for a %d-bit pass", p.log_r);
+        return ICICLE_UNKNOWN_ERROR;
+      }
+      lds29 = (size_t)NT * 8 * 36 + (size_t)R * 16;
+      static std::atomic<bool> lds29_attr_set[MAX_DEVICES];
+      if (!lds29_attr_set[devi].load(std::memory_order_acquire)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass29_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);
+        HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass29_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);
+        lds29_attr_set[devi].store(true, std::memory_order_release);
+      }
+      fe c32 = Fr::zero();
+      c32.l[0] = 32;
+      ninv261 = Fr::mul(ninv, Fr::to_mont(c32)); // n⁻¹·2^256 → n⁻¹·2^261
+    }
     if (last && fuse && fuse->fused_out) {
       // A·B − C' epilogue: one workgroup per tile walks the three rows
       if (!full_tile || batch != 3 || inverse || rev_out || cols) {
@@ -697,7 +1052,10 @@ eIcicleError ntt_impl(const bn254_scalar_t* input, int size, NTTDir dir, const N
         return ICICLE_INVALID_ARGUMENT;
       }
       p.fuse_abc = 1;
-      hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((unsigned)tiles, 1), dim3(NT), lds, s, src, fuse->fused_out, dom.tw, p, ninv);
+      if (use29) hipLaunchKernelGGL(ntt_pass29_kernel<true>, dim3((unsigned)tiles, 1), dim3(NT), lds29, s, src, fuse->fused_out, dom.tw29, p, pl29, ninv261);
+      else hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((unsigned)tiles, 1), dim3(NT), lds, s, src, fuse->fused_out, dom.tw, p, ninv);
+    } else if (use29) {
+      hipLaunchKernelGGL(ntt_pass29_kernel<false>, dim3((unsigned)tiles, (unsigned)batch), dim3(NT), lds29, s, src, dst, dom.tw29, p, pl29, ninv261);
     } else {
       hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3((unsigned)tiles, (unsigned)batch), dim3(NT), lds, s, src, dst, dom.tw, p, ninv);
     }
