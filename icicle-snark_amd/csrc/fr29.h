@@ -1,10 +1,10 @@
 // fr29.h — BN254 SCALAR field in radix 2^29 (nine limbs in u32), Montgomery with R' = 2^261, lazy reduction: the arithmetic of
 // the NTT passes (ntt.hip).  Same idea as ff29.h (the base field of the MSM bucket kernels): with 29-bit limbs a whole product
-// column fits the 64-bit accumulator of v_mad_u64_u32, so a multiply is 81 + 72 multiply-adds and no carry instructions
+// column fits the 64-bit accumulator of v_mad_u64_u32, so a multiply is 81 + 81 multiply-adds and no carry instructions
 // (the 8×32-bit form of ff.h: 136 + 128), and additions / subtractions are nine limb-wise instructions.
 //
-// r = 2^28·k + 1 (two-adicity 28), so in this radix r_0 = 2^28 + 1 and −r⁻¹ mod 2^29 = 2^28 − 1: the quotient digit is a shift
-// and a subtraction, and m·r_0 is a shift and an addition — no multiplier instruction for either.
+// (r = 2^28·k + 1, so r_0 = 2^28 + 1 and −r⁻¹ mod 2^29 = 2^28 − 1 in this radix; the shift-and-add forms of the quotient digit and
+// of m·r_0 were measured against the plain multiplies and are not faster: a multiply-add is one instruction.)
 //
 // Conventions:  "N" = limbs l[0..7] < 2^29, l[8] holds the rest (< 2^32);  "< k" = value < k·r.  R'/r ≈ 169.28.
 //   mul(a, w)     a: limbs < 2^31.5, l[8] < 2^32, any value < 2^264;  w: N, canonical (< 1)  →  N, value < a/169.28 + 1
@@ -24,14 +24,16 @@ namespace bn254 {
 namespace fr29 {
 
 constexpr uint32_t MASK = (1u << 29) - 1;
+constexpr uint32_t NINV = 0xfffffffu; // −r⁻¹ mod 2^29
 #define FR29_R_LIMBS 0x10000001u, 0x1f0fac9fu, 0xe5c2450u, 0x7d090f3u, 0x1585d283u, 0x2db40c0u, 0xa6e141u, 0xe5c2634u, 0x30644eu
 
 struct Limbs9 {
   uint32_t v[9];
 };
-// K·r with limb i raised by 2^29 and limb i + 1 lowered by 1: every limb of an N subtrahend can be subtracted without going
-// negative; the top limb is (K·r)_8 − 1, so the subtrahend's value must be below (K − 1)·r.
-constexpr Limbs9 kr_borrow_proof(uint32_t k)
+// K·r with limb i raised by j·2^29 and limb i + 1 lowered by j: every limb of a subtrahend whose limbs are ≤ j·(2^29 − 1) can be
+// subtracted without going negative; the top limb is (K·r)_8 − j, so the subtrahend's value must be below (K − 1)·r.
+// (constexpr, and cheap enough at run time for a wave-uniform K: the NTT passes compute their levels' constants in scalar registers)
+FF_HD constexpr Limbs9 kr_borrow_proof(uint32_t k, uint32_t j = 1)
 {
   constexpr uint32_t R[9] = {FR29_R_LIMBS};
   Limbs9 o{};
@@ -42,8 +44,8 @@ constexpr Limbs9 kr_borrow_proof(uint32_t k)
     carry = t >> 29;
   }
   for (int i = 0; i < 8; i++) {
-    o.v[i] += 1u << 29;
-    o.v[i + 1] -= 1u;
+    o.v[i] += j << 29;
+    o.v[i + 1] -= j;
   }
   return o;
 }
@@ -73,10 +75,8 @@ FF_HD fe9 mul(const fe9& a, const fe9& w)
     for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * w.l[k - i];
 #pragma unroll
     for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * R[k - i];
-    // m = −acc·r⁻¹ mod 2^29 with −r⁻¹ = 2^28 − 1;  m·r_0 = m·(2^28 + 1)
-    const uint32_t lo = (uint32_t)acc;
-    m[k] = ((lo << 28) - lo) & MASK;
-    acc += ((uint64_t)m[k] << 28) + m[k];
+    m[k] = ((uint32_t)acc * NINV) & MASK; // −r⁻¹ mod 2^29 = 2^28 − 1
+    acc += (uint64_t)m[k] * R[0];
     acc >>= 29;
   }
 #pragma unroll

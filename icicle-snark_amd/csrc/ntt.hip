@@ -412,8 +412,9 @@ __global__ __launch_bounds__(NT, 2) void ntt_pass_kernel(const fe* __restrict__ 
 //  * everything that leaves a pass has gone through a product (inter-pass twiddle, 1/n, per-element scale) and is < 4·r, which
 //    fits the packed 32-byte form; the LAST pass of a transform stores canonical values.
 struct Plan29 {
-  uint32_t kc[8][9];   // level l: K_l·r, borrow-proof (fr29::kr_borrow_proof)
-  int shrink_last;     // apply fr29::shrink to the operands of the last round
+  uint32_t b0;       // bound of the tile's values at the load (multiples of r): level l of a round that is not the last sees b0·2^l
+  uint32_t bs;       // bound at the start of the last round (after the shrink, if any): its level t sees (bs + 1)·2^t − 1
+  int shrink_last;   // apply fr29::shrink to the operands of the last round
 };
 struct Lds29 {
   uint4 *lo, *hi;
@@ -434,65 +435,93 @@ __device__ __forceinline__ void lds_put9(const Lds29& t, int idx, const fe9& v)
   t.hi[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
   t.top[idx] = v.l[8];
 }
-// a + K·r − b with the level's constant from the kernel arguments (scalar registers)
-__device__ __forceinline__ fe9 sub_k(const fe9& a, const fe9& b, const uint32_t (&kc)[9])
+// a + K·r − b with a wave-uniform K (the constant is computed in scalar registers); b's limbs ≤ J·(2^29 − 1), b < K − 1
+__device__ __forceinline__ fe9 sub_k(const fe9& a, const fe9& b, const fr29::Limbs9& kc)
 {
   fe9 o;
 #pragma unroll
-  for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + (kc[i] - b.l[i]);
+  for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + (kc.v[i] - b.l[i]);
   return o;
 }
-#define NTT_BF9(a, b, e, L)                                                                                    \
+// One level of a round.  NORM: the sums leave normalised (a level's sums may stay un-normalised — limbs < 2^30 — when the next
+// level of the same round subtracts them against a J = 2 constant).  Differences with a unit twiddle (_1) are always normalised.
+#define NTT_BF9(a, b, e, NORM)                                                                                 \
   {                                                                                                            \
-    const fe9 s_ = fr29::norm(fr29::add(x[a], x[b]));                                                          \
-    const fe9 d_ = sub_k(x[a], x[b], pl.kc[L]);                                                                \
+    const fe9 s_ = NORM ? fr29::norm(fr29::add(x[a], x[b])) : fr29::add(x[a], x[b]);                           \
+    const fe9 d_ = sub_k(x[a], x[b], kc);                                                                      \
     x[a] = s_;                                                                                                 \
-    x[b] = fr29::mul(d_, fr29::unpack(lds_get(twlo, twhi, (e))));                                              \
+    x[b] = fr29::mul(d_, lds_get9(tw, (e)));                                                                   \
   }
-#define NTT_BF9_1(a, b, L)                                                                                     \
+#define NTT_BF9_1(a, b, NORM)                                                                                  \
   {                                                                                                            \
-    const fe9 s_ = fr29::norm(fr29::add(x[a], x[b]));                                                          \
-    x[b] = fr29::norm(sub_k(x[a], x[b], pl.kc[L]));                                                            \
+    const fe9 s_ = NORM ? fr29::norm(fr29::add(x[a], x[b])) : fr29::add(x[a], x[b]);                           \
+    x[b] = fr29::norm(sub_k(x[a], x[b], kc));                                                                  \
     x[a] = s_;                                                                                                 \
   }
-template <int Q>
-__device__ __forceinline__ void dif_butterfly9(fe9 (&x)[1 << Q], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl);
-template <>
-__device__ __forceinline__ void dif_butterfly9<3>(fe9 (&x)[8], int j, int log_m, int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+// K of level l (inputs below B: K = B + 1)
+__device__ __forceinline__ uint32_t k_mid(const Plan29& pl, int l) { return (pl.b0 << l) + 1u; }
+__device__ __forceinline__ uint32_t k_last(const Plan29& pl, int t) { return (pl.bs + 1u) << t; }
+
+__device__ __forceinline__ void dif_butterfly9_mid(fe9 (&x)[8], int j, int log_m, int log_r, const Lds29& tw, const Plan29& pl)
 {
   const int g = 1 << (log_m - 3);
   const int s0 = log_r - log_m, s1 = s0 + 1, s2 = s0 + 2;
-  NTT_BF9(0, 4, j << s0, s0) NTT_BF9(1, 5, (j + g) << s0, s0) NTT_BF9(2, 6, (j + 2 * g) << s0, s0) NTT_BF9(3, 7, (j + 3 * g) << s0, s0)
-  NTT_BF9(0, 2, j << s1, s1) NTT_BF9(1, 3, (j + g) << s1, s1) NTT_BF9(4, 6, j << s1, s1) NTT_BF9(5, 7, (j + g) << s1, s1)
-  NTT_BF9(0, 1, j << s2, s2) NTT_BF9(2, 3, j << s2, s2) NTT_BF9(4, 5, j << s2, s2) NTT_BF9(6, 7, j << s2, s2)
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_mid(pl, s0), 1);
+    NTT_BF9(0, 4, j << s0, false) NTT_BF9(1, 5, (j + g) << s0, false) NTT_BF9(2, 6, (j + 2 * g) << s0, false) NTT_BF9(3, 7, (j + 3 * g) << s0, false)
+  }
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_mid(pl, s1), 2);
+    NTT_BF9(0, 2, j << s1, true) NTT_BF9(1, 3, (j + g) << s1, true) NTT_BF9(4, 6, j << s1, true) NTT_BF9(5, 7, (j + g) << s1, true)
+  }
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_mid(pl, s2), 1);
+    NTT_BF9(0, 1, j << s2, true) NTT_BF9(2, 3, j << s2, true) NTT_BF9(4, 5, j << s2, true) NTT_BF9(6, 7, j << s2, true)
+  }
 }
 template <int Q>
-__device__ __forceinline__ void dif_butterfly9_last(fe9 (&x)[1 << Q], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl);
+__device__ __forceinline__ void dif_butterfly9_last(fe9 (&x)[1 << Q], int log_r, const Lds29& tw, const Plan29& pl);
 template <>
-__device__ __forceinline__ void dif_butterfly9_last<3>(fe9 (&x)[8], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+__device__ __forceinline__ void dif_butterfly9_last<3>(fe9 (&x)[8], int log_r, const Lds29& tw, const Plan29& pl)
 {
-  const int s0 = log_r - 3, s1 = s0 + 1, s2 = s0 + 2;
-  NTT_BF9_1(0, 4, s0) NTT_BF9(1, 5, 1 << s0, s0) NTT_BF9(2, 6, 2 << s0, s0) NTT_BF9(3, 7, 3 << s0, s0)
-  NTT_BF9_1(0, 2, s1) NTT_BF9(1, 3, 1 << s1, s1) NTT_BF9_1(4, 6, s1) NTT_BF9(5, 7, 1 << s1, s1)
-  NTT_BF9_1(0, 1, s2) NTT_BF9_1(2, 3, s2) NTT_BF9_1(4, 5, s2) NTT_BF9_1(6, 7, s2)
+  const int s0 = log_r - 3, s1 = s0 + 1;
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_last(pl, 0), 1);
+    NTT_BF9_1(0, 4, false) NTT_BF9(1, 5, 1 << s0, false) NTT_BF9(2, 6, 2 << s0, false) NTT_BF9(3, 7, 3 << s0, false)
+  }
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_last(pl, 1), 2);
+    NTT_BF9_1(0, 2, true) NTT_BF9(1, 3, 1 << s1, true) NTT_BF9_1(4, 6, true) NTT_BF9(5, 7, 1 << s1, true)
+  }
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_last(pl, 2), 1);
+    NTT_BF9_1(0, 1, true) NTT_BF9_1(2, 3, true) NTT_BF9_1(4, 5, true) NTT_BF9_1(6, 7, true)
+  }
 }
 template <>
-__device__ __forceinline__ void dif_butterfly9_last<2>(fe9 (&x)[4], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+__device__ __forceinline__ void dif_butterfly9_last<2>(fe9 (&x)[4], int log_r, const Lds29& tw, const Plan29& pl)
 {
-  const int s0 = log_r - 2, s1 = s0 + 1;
-  NTT_BF9_1(0, 2, s0) NTT_BF9(1, 3, 1 << s0, s0)
-  NTT_BF9_1(0, 1, s1) NTT_BF9_1(2, 3, s1)
+  const int s0 = log_r - 2;
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_last(pl, 0), 1);
+    NTT_BF9_1(0, 2, false) NTT_BF9(1, 3, 1 << s0, false)
+  }
+  {
+    const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_last(pl, 1), 2);
+    NTT_BF9_1(0, 1, true) NTT_BF9_1(2, 3, true)
+  }
 }
 template <>
-__device__ __forceinline__ void dif_butterfly9_last<1>(fe9 (&x)[2], int log_r, const uint4* twlo, const uint4* twhi, const Plan29& pl)
+__device__ __forceinline__ void dif_butterfly9_last<1>(fe9 (&x)[2], int log_r, const Lds29& tw, const Plan29& pl)
 {
-  NTT_BF9_1(0, 1, log_r - 1)
+  const fr29::Limbs9 kc = fr29::kr_borrow_proof(k_last(pl, 0), 1);
+  NTT_BF9_1(0, 1, true)
 }
 #undef NTT_BF9_1
 #undef NTT_BF9
 
 template <int Q, bool LAST>
-__device__ __forceinline__ void dif_round9(const Lds29& t, const uint4* twlo, const uint4* twhi, int log_m, int log_r, int log_c, int tid, const Plan29& pl)
+__device__ __forceinline__ void dif_round9(const Lds29& t, const Lds29& tw, int log_m, int log_r, int log_c, int tid, const Plan29& pl)
 {
   const int C = 1 << log_c;
   const int log_g = log_m - Q;
@@ -512,8 +541,8 @@ __device__ __forceinline__ void dif_round9(const Lds29& t, const uint4* twlo, co
 #pragma unroll
         for (int k = 0; k < (1 << Q); k++) x[k] = fr29::shrink(x[k]);
       }
-      dif_butterfly9_last<Q>(x, log_r, twlo, twhi, pl);
-    } else dif_butterfly9<Q>(x, j, log_m, log_r, twlo, twhi, pl);
+      dif_butterfly9_last<Q>(x, log_r, tw, pl);
+    } else dif_butterfly9_mid(x, j, log_m, log_r, tw, pl);
 #pragma unroll
     for (int k = 0; k < (1 << Q); k++) lds_put9(t, ((base_row + (k << log_g)) << log_c) + c, x[k]);
   }
@@ -533,7 +562,7 @@ __device__ __forceinline__ fe9 shl5(const fe9& a)
 // MODE as in ntt_tile_row
 template <int MODE>
 __device__ __forceinline__ void ntt_tile_row9(const fe* __restrict__ src, fe* __restrict__ dst, const fe* __restrict__ tw29, const PassParams& p, const Plan29& pl, const fe& ninv261, const Lds29& t,
-                                              const uint4* twlo, const uint4* twhi, uint32_t b_lo, uint64_t out_off, int tid)
+                                              const Lds29& tw, uint32_t b_lo, uint64_t out_off, int tid)
 {
   const int R = 1 << p.log_r, C = 1 << p.log_c;
   {
@@ -559,13 +588,13 @@ __device__ __forceinline__ void ntt_tile_row9(const fe* __restrict__ src, fe* __
   {
     int log_m = p.log_r;
     while (log_m > 3) {
-      dif_round9<3, false>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
+      dif_round9<3, false>(t, tw, log_m, p.log_r, p.log_c, tid, pl);
       __syncthreads();
       log_m -= 3;
     }
-    if (log_m == 3) dif_round9<3, true>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
-    else if (log_m == 2) dif_round9<2, true>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
-    else dif_round9<1, true>(t, twlo, twhi, log_m, p.log_r, p.log_c, tid, pl);
+    if (log_m == 3) dif_round9<3, true>(t, tw, log_m, p.log_r, p.log_c, tid, pl);
+    else if (log_m == 2) dif_round9<2, true>(t, tw, log_m, p.log_r, p.log_c, tid, pl);
+    else dif_round9<1, true>(t, tw, log_m, p.log_r, p.log_c, tid, pl);
     __syncthreads();
   }
   if (MODE != 0) {
@@ -623,26 +652,28 @@ __global__ __launch_bounds__(NT, 2) void ntt_pass29_kernel(const fe* __restrict_
   ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int R = 1 << p.log_r, RC = NT * 8;
-  Lds29 t;
+  // tile: two uint4 planes + one word plane of 2048 entries; stage twiddles ω_R^e (e < R/2, Montgomery-261) in the same form
+  Lds29 t, tw;
   t.lo = reinterpret_cast<uint4*>(smem);
   t.hi = t.lo + RC;
-  uint4* twlo = t.hi + RC; // R/2 packed twiddles
-  uint4* twhi = twlo + (R >> 1);
-  t.top = reinterpret_cast<uint32_t*>(twhi + (R >> 1));
+  tw.lo = t.hi + RC;
+  tw.hi = tw.lo + (R >> 1);
+  t.top = reinterpret_cast<uint32_t*>(tw.hi + (R >> 1));
+  tw.top = t.top + RC;
 
   const uint32_t b = blockIdx.x;
   const uint32_t b_hi = b >> p.tiles_per_group_log, b_lo = b & ((1u << p.tiles_per_group_log) - 1);
   const uint64_t in_off = b_hi * p.in_hi + b_lo * p.in_lo, out_off = b_hi * p.out_hi + b_lo * p.out_lo;
   const int tid = threadIdx.x;
-  for (int e = tid; e < (R >> 1); e += NT) lds_put(twlo, twhi, e, g_get(tw29 + tw_index((uint32_t)e * p.stage_stride, p.n_mask, p.inverse)));
+  for (int e = tid; e < (R >> 1); e += NT) lds_put9(tw, e, fr29::unpack(g_get(tw29 + tw_index((uint32_t)e * p.stage_stride, p.n_mask, p.inverse))));
   if (!FUSE) {
-    ntt_tile_row9<0>(in + (uint64_t)blockIdx.y * p.batch_stride + in_off, out + (uint64_t)blockIdx.y * p.batch_stride + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+    ntt_tile_row9<0>(in + (uint64_t)blockIdx.y * p.batch_stride + in_off, out + (uint64_t)blockIdx.y * p.batch_stride + out_off, tw29, p, pl, ninv261, t, tw, b_lo, out_off, tid);
   } else {
-    ntt_tile_row9<1>(in + in_off, out + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+    ntt_tile_row9<1>(in + in_off, out + out_off, tw29, p, pl, ninv261, t, tw, b_lo, out_off, tid);
     __syncthreads();
-    ntt_tile_row9<2>(in + p.batch_stride + in_off, out + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+    ntt_tile_row9<2>(in + p.batch_stride + in_off, out + out_off, tw29, p, pl, ninv261, t, tw, b_lo, out_off, tid);
     __syncthreads();
-    ntt_tile_row9<3>(in + 2 * p.batch_stride + in_off, out + out_off, tw29, p, pl, ninv261, t, twlo, twhi, b_lo, out_off, tid);
+    ntt_tile_row9<3>(in + 2 * p.batch_stride + in_off, out + out_off, tw29, p, pl, ninv261, t, tw, b_lo, out_off, tid);
   }
 }
 
@@ -836,24 +867,20 @@ bool bounds29(int log_r, uint32_t b_in, uint32_t limit, Plan29& pl)
 {
   memset(&pl, 0, sizeof pl);
   const int q_last = log_r % 3 ? log_r % 3 : 3;
-  uint32_t B = b_in;
-  for (int l = 0; l < log_r; l++) {
-    const bool last_round = l >= log_r - q_last;
-    if (l == log_r - q_last) {
-      uint32_t e = B;
-      for (int k = 0; k < q_last; k++) e = 2 * e + 1;
-      if (e > limit) {
-        pl.shrink_last = 1;
-        B = B / 4 + 2;
-      }
-    }
-    const uint32_t K = B + 1;
-    if (B + K >= 1350) return false;
-    const fr29::Limbs9 c = fr29::kr_borrow_proof(K);
-    for (int i = 0; i < 9; i++) pl.kc[l][i] = c.v[i];
-    B = last_round ? 2 * B + 1 : 2 * B;
+  pl.b0 = b_in;
+  uint32_t B = b_in << (log_r - q_last); // at the start of the last round
+  uint32_t e = B;
+  for (int k = 0; k < q_last; k++) e = 2 * e + 1;
+  if (e > limit) {
+    pl.shrink_last = 1;
+    B = B / 4 + 2;
   }
-  return B <= limit;
+  pl.bs = B;
+  for (int k = 0; k < q_last; k++) {
+    if (2 * B + 1 >= 1350) return false; // (K·r)_8 + a_8 must fit 32 bits
+    B = 2 * B + 1;
+  }
+  return B <= limit && (uint64_t)b_in << (log_r - q_last) < 650;
 }
 } // namespace
 
@@ -1034,7 +1061,7 @@ eIcicleError ntt_impl(const bn254_scalar_t* input, int size, NTTDir dir, const N
         set_last_error("ntt: internal error — no radix-2^29 bound plan for a %d-bit pass", p.log_r);
         return ICICLE_UNKNOWN_ERROR;
       }
-      lds29 = (size_t)NT * 8 * 36 + (size_t)R * 16;
+      lds29 = (size_t)NT * 8 * 36 + (size_t)(R >> 1) * 36;
       static std::atomic<bool> lds29_attr_set[MAX_DEVICES];
       if (!lds29_attr_set[devi].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass29_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_UNKNOWN_ERROR);

@@ -1,4 +1,4 @@
-// host check of csrc/fr29.h against the 8×32-bit Fr of ff.h:  g++ -O2 -std=c++17 -Iicicle-snark_amd/csrc -o /tmp/fr29_check scratch/tools/fr29_check.cc
+// host check of csrc/fr29.h against the 8×32-bit Fr of ff.h:  g++ -O2 -std=c++17 -Iicicle-snark_amd/csrc -o /tmp/fr29_check tests/fr29_check.cc  (tests/test_fr29.py does that)
 #include <cstdio>
 #include <cstring>
 #include <random>

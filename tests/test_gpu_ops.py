@@ -119,6 +119,24 @@ def test_ntt_vs_oracle(domain, O, logn):
     st.destroy(); d.free()
 
 
+@pytest.mark.parametrize("logn", [11, 12, 15, 16, 17, 20])
+def test_ntt_extreme_inputs_on_the_lazy_field(domain, O, logn):
+    """The radix-2^29 passes (csrc/fr29.h, ntt_pass29_kernel; every size from 2^11 on) do not reduce after additions: the value
+    bounds the host plans for them (bounds29) must hold for the worst inputs.  A constant vector of r − 1 drives the all-sums path
+    of every sub-transform to its bound (element 0 becomes n·(r − 1)), alternating 0 / r − 1 and r − 1 / 1 patterns the
+    difference paths; all against the oracle, forward and inverse, batch 3."""
+    K = domain
+    n = 1 << logn
+    rm1 = np.frombuffer(int(O.R_MOD - 1).to_bytes(32, "little"), dtype=np.uint64)
+    one = np.frombuffer(int(1).to_bytes(32, "little"), dtype=np.uint64)
+    rows = [np.tile(rm1, (n, 1)), np.tile(rm1, (n, 1)), np.tile(rm1, (n, 1))]
+    rows[1][0::2] = 0
+    rows[2][1::2] = one
+    x = np.ascontiguousarray(np.concatenate(rows))
+    for inverse in (False, True):
+        assert np.array_equal(K.ntt(x, inverse, batch_size=3), O.fr_ntt(x, inverse, batch=3, domain_log=20)), (logn, inverse)
+
+
 def test_ntt_out_of_place_and_errors(domain, O):
     K = domain
     rng = np.random.default_rng(99)
