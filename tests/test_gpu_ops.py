@@ -1,6 +1,8 @@
 """Parity tests proper (need an MI355X): the HIP path, called through the C ABI, against the CPU oracle on
 the same seeded inputs and against the committed golden vectors.  Bit-exact everywhere (integer work).
 Shapes follow the reference's own differential tests (wrappers/rust/icicle-core/src/{vec_ops,ntt,msm}/tests.rs)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -135,6 +137,17 @@ def test_ntt_extreme_inputs_on_the_lazy_field(domain, O, logn):
     x = np.ascontiguousarray(np.concatenate(rows))
     for inverse in (False, True):
         assert np.array_equal(K.ntt(x, inverse, batch_size=3), O.fr_ntt(x, inverse, batch=3, domain_log=20)), (logn, inverse)
+
+
+def test_ntt_8x32_kernels_behind_the_switch():
+    """ICICLE_SNARK_NTT29=0 (and a domain whose Montgomery-261 twiddle table could not be allocated) sends every size through the
+    8×32-bit pass kernels, which otherwise only see transforms below 2^11: the oracle comparison of test_ntt_vs_oracle and the golden
+    vectors once more in a process with the switch set."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_ntt_vs_oracle or test_ntt_golden or test_ntt_coset"],
+                         capture_output=True, text=True, env=dict(os.environ, ICICLE_SNARK_NTT29="0"), timeout=900)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_ntt_out_of_place_and_errors(domain, O):
