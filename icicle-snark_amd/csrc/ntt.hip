@@ -21,6 +21,9 @@
 //    multiply yields the standard-form product directly.
 //  * per element each pass reads 32 B and writes 32 B: 64·P bytes of HBM traffic per element
 //    (P = number of passes), the twiddle table (N·32 B) is L2/Infinity-Cache resident.
+//  * transforms of 2^11 elements and more whose passes can all work on full tiles run the same plan on a LAZY
+//    RADIX-2^29 field (fr29.h, ntt_pass29_kernel below): nine-word tiles, no reduction after additions, value
+//    bounds planned on the host — ≈ 20 % faster; the 8×32-bit kernels keep the small and ragged sizes.
 #include <atomic>
 #include <mutex>
 #include <string.h>
