@@ -651,12 +651,21 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
   if (prof) (void)hipEventRecord(prof->ev[1], s);
   AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets.p);
+#ifdef ICICLE_SNARK_EXPERIMENTS
+  // what a stage costs the prove, measured by running it twice (scratch/marginal_cost.sh): ISNARK_DUP bit 0 / 1 the
+  // first reduction level of G1 / G2 sets, bit 2 / 3 the G1 / G2 accumulations, bit 6 the large-bucket kernel (all idempotent)
+  static const int dupmask = getenv("ISNARK_DUP") ? atoi(getenv("ISNARK_DUP")) : 0;
+  if (dupmask & (sizeof(X) > 128 ? 8 : 4)) AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets.p);
+#endif
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
   const size_t lds_l = lb * sizeof(typename Lazy<C>::type::X); // 36 KiB
   HIP_TRY(item_partials.alloc(pl->item_cap, s), ICICLE_ALLOCATION_FAILED);
   hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lds_l, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
+#ifdef ICICLE_SNARK_EXPERIMENTS
+  if (dupmask & 64) hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lds_l, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
+#endif
   hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lds_l, s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
   item_partials.release();
@@ -685,6 +694,9 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
     const size_t lds_z = (size_t)ZR_M * sizeof(LX);
     allow_big_lds(msm_zeta_reduce_kernel<C>, lds_z);
     hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk1, 1), dim3(ZR_T), lds_z, s, buckets.p, n1, r1.p, (uint32_t*)nullptr, 0, (X*)nullptr);
+#ifdef ICICLE_SNARK_EXPERIMENTS
+    if (dupmask & (sizeof(X) > 128 ? 2 : 1)) hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk1, 1), dim3(ZR_T), lds_z, s, buckets.p, n1, r1.p, (uint32_t*)nullptr, 0, (X*)nullptr);
+#endif
     hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk2, ZR_OUT), dim3(ZR_T), lds_z, s, r1.p, nblk1, r2.p, tickets, nbits, d_partials);
     ICICLE_TRY(check_launch("msm_zeta_reduce"));
     return ICICLE_SUCCESS;

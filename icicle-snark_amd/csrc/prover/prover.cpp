@@ -351,6 +351,11 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   (void)hipEventRecord(psort->ev[0], g2);
   // (tab > 1 = table mode with exactly this digit width: a key adapted to its witnesses, cache.cpp)
   const bool adapted_w = z->geom_w.tab && z->geom_w.c != z->geom_w_default_c;
+#ifdef ICICLE_SNARK_EXPERIMENTS
+  static const int dupmask_w = getenv("ISNARK_DUP") ? atoi(getenv("ISNARK_DUP")) : 0;
+  SortPlan plan_w_dup;
+  if (dupmask_w & 32) P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w_dup, adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, adapted_w ? z->witness_entries : 0));
+#endif
   P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w, adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, adapted_w ? z->witness_entries : 0));
   if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
   (void)hipEventRecord(psort->ev[4], g2); // end of the witness digit sort (roofline.scatter)
@@ -445,6 +450,12 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
   P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
   (void)hipEventRecord(prof[4]->ev[0], g3);
+#ifdef ICICLE_SNARK_EXPERIMENTS
+  // (scratch/marginal_cost.sh) ISNARK_DUP bit 4: H's digit sort twice, bit 5: the witness digit sort twice
+  static const int dupmask = getenv("ISNARK_DUP") ? atoi(getenv("ISNARK_DUP")) : 0;
+  SortPlan plan_h_dup;
+  if (dupmask & 16) P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h_dup, z->geom_h.tab));
+#endif
   P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab));
   if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
   (void)hipEventRecord(prof[4]->ev[4], g3);
@@ -550,6 +561,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   z->proves_since_rebuild++;
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
+#ifdef ICICLE_SNARK_EXPERIMENTS
+  if (dupmask & 16) msm_sort_release(&plan_h_dup);
+  if (dupmask_w & 32) msm_sort_release(&plan_w_dup);
+#endif
   {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
