@@ -254,9 +254,10 @@ def dropin_sequence_ms(zkey, wtns, iters=7):
 
 
 def group_child(workload_unused=None):
-    """`bench.py --group-child`: the device-group leg of rank 0, in a process of its own.  Protocol on stdin / stdout (one JSON
-    object per line): build the group + first prove + warm-up → {"ready": …}; wait for the line "go"; K timed proves →
-    {"done": …}; exit.  A crash or a hang of the never-yet-run multi-GPU path then costs this leg, not the launcher's ranks."""
+    """`bench.py --group-child`: the device-group leg, in a process of its own.  Protocol on stdin / stdout (one JSON object per
+    line): [synthesise the inputs when the parent has not] + build the group + first prove + warm-up → {"ready": …}; wait for the
+    line "go"; K timed proves → {"done": …}; {"resident_ms", "proof", "public"}; exit.  A crash or a hang of the never-yet-run
+    multi-GPU path then costs this leg, not the caller (the launcher's ranks, or the stand-alone parent that retries)."""
     cfg = json.loads(sys.stdin.readline())
     os.environ["ICICLE_SNARK_QUIET"] = "1"
     out = os.fdopen(os.dup(1), "w")          # the protocol's channel; anything the library prints to fd 1 goes to stderr instead
@@ -274,32 +275,63 @@ def group_child(workload_unused=None):
         K = importlib.import_module("icicle-snark_amd")
         device, steps, warmup = cfg["device"], cfg["steps"], cfg["warmup"]
         zkey_path, wtns_path, proof_path, public_path = cfg["zkey"], cfg["wtns"], cfg["proof"], cfg["public"]
+        first_dev = K.parse_device(device)[0]
+        meta = {}
+        if not (os.path.exists(zkey_path) and os.path.exists(wtns_path)):
+            # stand-alone `bench.py --gpus N`: the parent never touches the GPU, so the inputs are synthesised here (once: a
+            # retry with another transport finds the files)
+            S = importlib.import_module("icicle-snark_amd.synth")
+            K.set_device("HIP", first_dev)
+            zkey, wtns, nc, what, standin = workload_inputs(K, S, cfg["workload"])
+            open(zkey_path + ".tmp", "wb").write(zkey)
+            open(wtns_path + ".tmp", "wb").write(wtns)
+            os.replace(zkey_path + ".tmp", zkey_path)
+            os.replace(wtns_path + ".tmp", wtns_path)
+            meta = {"constraints": nc, "what": what, "standin": standin}
+            json.dump(meta, open(zkey_path + ".meta", "w"))
+            del zkey, wtns
+        elif os.path.exists(zkey_path + ".meta"):
+            meta = json.load(open(zkey_path + ".meta"))
         key = f"{zkey_path}_{device}"
         cm = K.CacheManager()
         t0 = time.time()
         cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
         cold_ms = (time.time() - t0) * 1e3
         info = cm.info(key)
-        log(f"device group {device}: {info.shards} shards, {info.device_bytes / 1e6:.0f} MB of device memory, built + first prove in {cold_ms / 1e3:.2f} s")
+        desc = cm.group_describe(key)
+        log(f"device group {device}: {info.shards} shards, {info.device_bytes / 1e6:.0f} MB of device memory, built + first prove in {cold_ms / 1e3:.2f} s; {desc}")
         for _ in range(max(1, warmup)):
             cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
         K.check(K.lib().icicle_device_synchronize(), "sync")
         # the group's proof for fixed blinding scalars must be the one a single GPU computes (untimed; the exchanges have never
-        # crossed two real GPUs before the run this guards)
+        # crossed two real GPUs before the run this guards) — for the benchmark witness AND for a second, different vector
+        # handed over right after it (the exchange buffers and events are re-used with new contents), each twice
+        import numpy as np
         wtns = open(wtns_path, "rb").read()
-        want_key = "single_device_check"
-        cm.load(want_key, open(zkey_path, "rb").read(), device_id=K.parse_device(device)[0])
-        want = cm.prove_mem(want_key, wtns, 5, 9)[0]
-        cm.evict(want_key)
-        for rep in range(2):
-            if cm.prove_mem(key, wtns, 5, 9)[0] != want:
-                raise RuntimeError(f"the device group's proof differs from the single-device proof for the same (r, s) (repeat {rep})")
-        K.set_device("HIP", K.parse_device(device)[0])
-        say({"ready": True, "cold_ms": cold_ms, "shards": info.shards, "device_mb": info.device_bytes / 1e6, "equals_single_device_proof": True})
+        w2 = np.frombuffer(wtns, dtype=np.uint8).copy()
+        body = w2[len(w2) - 32 * info.n_vars:].reshape(-1, 32)
+        body[1:] = body[1:][::-1].copy()          # same field elements in another order: any vector proves (the prover checks no constraint)
+        wtns2 = w2.tobytes()
+        equal = True
+        if info.shards:
+            want_key = "single_device_check"
+            cm.load(want_key, open(zkey_path, "rb").read(), device_id=first_dev)
+            want = [cm.prove_mem(want_key, w, 5, 9)[0] for w in (wtns, wtns2)]
+            cm.evict(want_key)
+            for rep in range(2):
+                for k, w in enumerate((wtns, wtns2)):
+                    if cm.prove_mem(key, w, 5, 9)[0] != want[k]:
+                        raise RuntimeError(f"the device group's proof differs from the single-device proof for the same (r, s) (witness {k}, repeat {rep})")
+            cm.prove_mem(key, wtns, 5, 9)
+        K.set_device("HIP", first_dev)
+        hbm_copy_gbps, mad_tops = K.microbench()
+        say({"ready": True, "cold_ms": cold_ms, "shards": info.shards, "device_mb": info.device_bytes / 1e6, "equals_single_device_proof": equal if info.shards else None,
+             "describe": desc, "hbm_copy_gbps": hbm_copy_gbps, "mad_tops": mad_tops, "n_vars": info.n_vars, "domain_size": info.domain_size, **meta})
         if sys.stdin.readline().strip() != "go":
             return 1
         qap = msm = 0.0
         acc, geom = [], None
+        K.check(K.lib().icicle_device_synchronize(), "sync")
         t0 = time.perf_counter()
         for _ in range(steps):
             cm.prove_files(wtns_path, zkey_path, proof_path, public_path, device)
@@ -429,6 +461,140 @@ def inproc_group_bench(args, dist, rank, world, zkey, wtns, tmpdir):
     return res
 
 
+def roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops):
+    """roofline object of the dominant kernel (G1 bucket accumulation of the H MSM) from its geometry and HIP-event time"""
+    # algorithmic bytes of one bucket-accumulation launch (DESIGN.md §kernels): per non-zero digit one 4-B
+    # sorted index + one 64-B affine base gathered; per bucket 8 B of (offset,count) + a 128-B XYZZ result
+    alg_bytes = g["L"] * g["W"] * (4 + 64) + g["nbuckets"] * (8 + 128)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    n_add = g["L"] * g["W"]
+    return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": pmc.get("acc_h") if pmc else None, "traffic_source": pmc_note,
+            # FETCH_SIZE without the guide's x2 (which is calibrated for wide coalesced streams): the calibration probe with this
+            # kernel's own pattern — random 64-byte gathers — counts 1.49x its bytes in the RAW counter (profiles/r02_pmc_calibration.txt),
+            # so the raw figure is the better estimate of the gather traffic and `traffic` an upper bound
+            "traffic_raw": pmc.get("acc_h_raw") if pmc else None,
+            "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
+            "algorithmic_bytes": alg_bytes, "geometry": g,
+            # the kernel is integer-VALU bound, not HBM bound (PMC: profiles/).  Its ceiling is the issue rate of the 4-cycle
+            # multiplier instructions: one XYZZ mixed addition on the radix-2^29 field = 1467 v_mad_u64_u32 + 81 v_mul_lo_u32
+            # (csrc/ff29.h, ec29.h), L·W additions per launch; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-ops/s
+            "alu": {"achieved_tmad_per_s": n_add * 1548 / (kern_ms * 1e-3) / 1e12, "peak_tmad_per_s": 39.3216,
+                    "frac": n_add * 1548 / (kern_ms * 1e-3) / 1e12 / 39.3216,
+                    "measured_peak_tmad_per_s": mad_tops,
+                    "frac_of_measured": n_add * 1548 / (kern_ms * 1e-3) / 1e12 / mad_tops,
+                    "source": "instruction counts of the kernel's source x launches / HIP-event time (counter-derived figures: profiles/r04_pmc_*.txt)"},
+            "hbm_copy_gbps_measured": hbm_copy_gbps, "frac_of_measured_copy": achieved / hbm_copy_gbps}
+
+
+DTYPE = "u256 mod p (MSM: 9x29-bit limbs in u32, Montgomery R=2^261, lazy reduction; NTT: 9x29-bit limbs, lazy; QAP/vec ops: 8xu32 limbs, Montgomery R=2^256)"
+
+
+def _group_attempt(cfg, env_extra, first_timeout):
+    """one device-group child process from start to finish → dict with every message merged, or {"error": …}"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+    env.update(env_extra)
+    res = {}
+    proc = None
+    try:
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--group-child"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                text=True, env=env, cwd=ROOT)
+        proc.stdin.write(json.dumps(cfg) + "\n")
+        proc.stdin.flush()
+        lines = _ChildLines(proc)
+        res.update(lines.get(first_timeout))                      # synthesis + cold build of every shard + tables + warm-up + equality checks
+        if "error" not in res:
+            t0 = time.perf_counter()
+            proc.stdin.write("go\n")
+            proc.stdin.flush()
+            res.update(lines.get(120.0 + 2.0 * cfg["steps"]))     # the K timed proves (bracketed by device synchronisations in the child)
+            res["parent_ms_per_step"] = (time.perf_counter() - t0) * 1e3 / cfg["steps"]
+        if "error" not in res:
+            res.update(lines.get(120.0))
+        if "error" not in res:
+            try:
+                proc.wait(timeout=60)
+            except Exception:   # noqa: BLE001 — the numbers are in; a child that does not leave is ended below
+                pass
+    except Exception as e:   # noqa: BLE001
+        res["error"] = repr(e)[:400]
+    finally:
+        if proc is not None and proc.poll() is None:
+            proc.kill()          # this exact child
+            proc.wait()
+    return res
+
+
+def standalone_group(args, workload):
+    """`python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset): the library's own multi-GPU entry is one call in one
+    process — groth16_prove(witness, zkey, proof, public, device = "HIP:0-(N-1)") (src/lib.rs:25-61: one call, one process) —
+    and needs neither torch nor torchrun.  This process never touches the GPU: the prove runs in a child (`--group-child`)
+    so that a crash or a hang of a path that has never crossed two real GPUs can be retried with the next transport forced
+    (library default order pull → memcpy → rccl, each self-tested at group load; then ICICLE_SNARK_EXCHANGE=memcpy, =rccl) and,
+    if every group attempt fails, the line still appears — from the single-device prove, flagged as such.  K proves are timed
+    between device-wide synchronisations on both sides; `value` = constraints of one prove / that time."""
+    devices = os.environ.get("ICICLE_SNARK_BENCH_DEVICES") or f"0-{args.gpus - 1}"
+    tmpdir = tempfile.mkdtemp(prefix="isnark_bench_")
+    cfg = dict(steps=args.steps, warmup=args.warmup, workload=workload, zkey=os.path.join(tmpdir, "g.zkey"), wtns=os.path.join(tmpdir, "g.wtns"),
+               proof=os.path.join(tmpdir, "g_proof.json"), public=os.path.join(tmpdir, "g_public.json"))
+    timeout = float(os.environ.get("ICICLE_SNARK_GROUP_TIMEOUT", "900"))
+    ladder = [({}, f"HIP:{devices}")]
+    if not os.environ.get("ICICLE_SNARK_EXCHANGE"):
+        ladder += [({"ICICLE_SNARK_EXCHANGE": "memcpy"}, f"HIP:{devices}"), ({"ICICLE_SNARK_EXCHANGE": "rccl"}, f"HIP:{devices}")]
+    first = devices.replace("-", ",").split(",")[0]
+    ladder.append(({}, f"HIP:{first}"))    # last resort: one device (the line says so)
+    attempts, res = [], None
+    try:
+        for env_extra, device in ladder:
+            r = _group_attempt(dict(cfg, device=device), env_extra, timeout)
+            attempts.append({"device": device, "forced_exchange": env_extra.get("ICICLE_SNARK_EXCHANGE"), "error": r.get("error")})
+            if "error" not in r:
+                res = r
+                res["device"] = device
+                break
+            log(f"device-group attempt on {device} ({env_extra or 'library default transport order'}) failed: {r['error']}")
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    if res is None:
+        print(json.dumps({"metric": "groth16_prove_constraints_per_s", "value": None, "unit": "constraints/s", "n_gpus": args.gpus, "steps": args.steps,
+                          "warmup": args.warmup, "higher_is_better": True, "error": "every device-group attempt failed", "config": {"attempts": attempts}}), flush=True)
+        return 1
+    N, what = res["constraints"], res["what"]
+    ms_per_step = max(res["parent_ms_per_step"], res["child_ms_per_step"])
+    desc = res.get("describe") or {}
+    fell_back = res["shards"] == 0
+    if not res.get("standin"):
+        S = importlib.import_module("icicle-snark_amd.synth")
+        assert json.loads(res["public"]) == [str(pow(3, 1 << N, S.R_MOD))]
+    assert json.loads(res["proof"])["protocol"] == "groth16"
+    roof = roofline_block(res["acc_geom"], res["acc_ms"], None, "not collected with --gpus > 1 (the N = 1 line carries the PMC traffic)", res["hbm_copy_gbps"], res["mad_tops"])
+    roof["kernel"] += " of shard 0"
+    out = {
+        "metric": "groth16_prove_constraints_per_s", "value": N / (ms_per_step * 1e-3), "unit": "constraints/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": f"{what}, domain 2^{res['domain_size'].bit_length() - 1}, cached zkey, random r/s",
+                   "timed_region": (f"the reference's own (src/lib.rs:41-58) on a device group: groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json, device = {res['device']!r}) "
+                                    "with a warm cache — one process, one host thread per GPU, device-side exchanges (csrc/prover/multi.cpp); K proves between two device-wide synchronisations"),
+                   "constraints": N, "msm_sharding": f"point-range x{res['shards']}" if not fell_back else "none (FALLBACK: every device-group attempt failed, this is the single-device prove)",
+                   "launcher": "none (WORLD_SIZE unset): the prove runs in ONE child process of bench.py; torch is not imported",
+                   "host": "one process, one host thread per GPU" if not fell_back else "one process, one GPU (fallback)",
+                   # which transport moved the three exchanges, how many devices the group touched and whether RCCL saw them: the pull
+                   # and memcpy transports do not go through RCCL, so rccl_ranks is 0 for them BY DESIGN
+                   "exchange": desc.get("transport"), "devices_touched": desc.get("distinct_devices"), "rccl_ranks": desc.get("rccl_ranks"),
+                   "device_group": dict(desc, device=res["device"], device_mb=res["device_mb"], cold_ms=res["cold_ms"], resident_ms=res["resident_ms"],
+                                        equals_single_device_proof=res["equals_single_device_proof"], attempts=attempts),
+                   "qap_front_end": ("distributed: rows split by residue class, two all-to-alls of 3*(n/N)*32 B per rank" if desc.get("distributed_front_end") else
+                                     ("replicated on every shard" if not fell_back else "single GPU")),
+                   "witness_upload": "1/N of the witness per shard over PCIe + in-place all-gather over the exchange" if not fell_back else "whole witness over PCIe",
+                   "prove_ms_files": ms_per_step, "prove_ms_files_child_clock": res["child_ms_per_step"], "prove_ms_hbm_resident": res["resident_ms"],
+                   "n_vars": res["n_vars"], "phase_ms": {"qap_ntt": res["qap_ms"], "msm": res["msm_ms"]}},
+        "roofline": roof,
+    }
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,7 +620,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        return standalone_group(args, workload)   # no launcher: the library's own multi-device entry, one process, no torch
     os.environ["ICICLE_SNARK_QUIET"] = "1"   # groth16_prove prints "proof took: …" like the reference; stdout carries ONE JSON line here
 
     # HBM traffic of the dominant kernels, measured in this run: rocprofv3 PMC passes over a child process, BEFORE this
@@ -677,27 +843,7 @@ def main():
         if use_group:
             g, kern_ms = group["acc_geom"], group["acc_ms"]
             phases = dict(qap=group["qap_ms"] * args.steps, msm=group["msm_ms"] * args.steps)
-        # algorithmic bytes of one bucket-accumulation launch: per non-zero digit one 4-B
-        # sorted index + one 64-B affine base gathered; per bucket 8 B of (offset,count) + a 128-B XYZZ result
-        alg_bytes = g["L"] * g["W"] * (4 + 64) + g["nbuckets"] * (8 + 128)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        n_add = g["L"] * g["W"]
-        roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": pmc.get("acc_h") if pmc else None, "traffic_source": pmc_note,
-                # FETCH_SIZE without the guide's x2 (which is calibrated for wide coalesced streams): the calibration probe with this
-                # kernel's own pattern — random 64-byte gathers — counts 1.49x its bytes in the RAW counter (profiles/r02_pmc_calibration.txt),
-                # so the raw figure is the better estimate of the gather traffic and `traffic` an upper bound
-                "traffic_raw": pmc.get("acc_h_raw") if pmc else None,
-                "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
-                "algorithmic_bytes": alg_bytes, "geometry": g,
-                # the kernel is integer-VALU bound, not HBM bound (PMC: profiles/).  Its ceiling is the issue rate of the 4-cycle
-                # multiplier instructions: one XYZZ mixed addition on the radix-2^29 field = 1467 v_mad_u64_u32 + 81 v_mul_lo_u32
-                # (csrc/ff29.h, ec29.h), L·W additions per launch; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-ops/s
-                "alu": {"achieved_tmad_per_s": n_add * 1548 / (kern_ms * 1e-3) / 1e12, "peak_tmad_per_s": 39.3216,
-                        "frac": n_add * 1548 / (kern_ms * 1e-3) / 1e12 / 39.3216,
-                        "measured_peak_tmad_per_s": mad_tops,
-                        "frac_of_measured": n_add * 1548 / (kern_ms * 1e-3) / 1e12 / mad_tops},
-                "hbm_copy_gbps_measured": hbm_copy_gbps, "frac_of_measured_copy": achieved / hbm_copy_gbps}
+        roof = roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops)
         if sort_ms:
             sg = sort_geom[0]
             s_ms = sum(sort_ms) / len(sort_ms)
@@ -716,7 +862,7 @@ def main():
             "metric": "groth16_prove_constraints_per_s", "value": N / (ms_per_step * 1e-3), "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u256 mod p (MSM: 9x29-bit limbs in u32, Montgomery R=2^261, lazy reduction; NTT/QAP: 8xu32 limbs, Montgomery R=2^256)", "data": "synthetic",
+            "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"{what}, domain 2^{info.domain_size.bit_length() - 1}, cached zkey, random r/s",
                        "timed_region": ("the reference's own (src/lib.rs:41-58): groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json) with a warm cache — "
                                         ".wtns file opened and parsed, witness over PCIe, prove, proof.json + public.json written"
@@ -725,12 +871,16 @@ def main():
                                          "with a warm cache — one process, one host thread per GPU, device-side exchanges (csrc/prover/multi.cpp)" if use_group else
                                          "one process per GPU: host witness buffer -> commitments of this rank's shard -> all-gather -> sum -> blinding + JSON strings")),
                        "constraints": N, "msm_sharding": f"point-range x{world}" if world > 1 else "none",
-                       "exchange": ("in-process device group (ICICLE_SNARK_EXCHANGE: pull kernels over peer access | hipMemcpyPeer | rccl)" if use_group else type(exch).__name__),
+                       # which transport moved the group's three exchanges, the devices it touched and the RCCL ranks that took part in them
+                       # (0 for the pull / memcpy transports BY DESIGN: they do not go through RCCL)
+                       "exchange": ((group.get("describe") or {}).get("transport") if use_group else type(exch).__name__),
+                       "devices_touched": ((group.get("describe") or {}).get("distinct_devices") if use_group else world),
+                       "rccl_ranks": ((group.get("describe") or {}).get("rccl_ranks") if use_group else (world if type(exch).__name__ == "RcclExchange" else 0)),
                        "host": ("one process, one host thread per GPU" if use_group else ("one process per GPU" if world > 1 else "one process")),
                        # N > 1: the other host of the same shard pipeline — one process per GPU, exchanges through type(exch)
                        "prove_ms_rank_per_gpu": ranks_ms_per_step if world > 1 else None,
                        "rank_per_gpu_exchange": type(exch).__name__ if world > 1 else None,
-                       "device_group": ({k: group.get(k) for k in ("device", "shards", "device_mb", "cold_ms", "resident_ms", "equals_single_device_proof", "error")} if group else None),
+                       "device_group": (dict(group.get("describe") or {}, **{k: group.get(k) for k in ("device", "shards", "device_mb", "cold_ms", "resident_ms", "equals_single_device_proof", "error")}) if group else None),
                        "qap_front_end": ("distributed: rows split by residue class, two all-to-alls of 3*(n/N)*32 B per rank" if world > 1 and dist_qap[0]
                                          else ("replicated on every rank" if world > 1 else "single GPU")),
                        "witness_upload": ("1/N of the witness per rank over PCIe + in-place all-gather over the exchange" if world > 1 and shard_w[0]

@@ -584,6 +584,13 @@ class CacheManager:
         _pcheck(lib().groth16_cache_info(self._h, key.encode(), C.byref(ci)), "cache_info")
         return ci
 
+    def group_describe(self, key: str) -> dict:
+        """what the key runs on: shards, devices, exchange transport, RCCL ranks (groth16_group_describe)"""
+        import json
+        buf = C.create_string_buffer(2048)
+        _pcheck(lib().groth16_group_describe(self._h, key.encode(), buf, C.c_size_t(len(buf))), "group_describe")
+        return json.loads(buf.value.decode())
+
     def commitments(self, key: str, wtns: bytes | None):
         """groth16_commitments (incl. construct_r1cs) for this process's shard → (576-byte block, Timings).
         wtns=None re-uses the witness already resident on the device."""
@@ -665,7 +672,7 @@ groth16_cache_contains groth16_cache_evict groth16_commitments groth16_sum_commi
 groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error groth16_last_timings
 groth16_dist_supported groth16_dist_stage1 groth16_dist_stage2 groth16_dist_exchange_done groth16_upload_witness_slice
 groth16_witness_ready groth16_cache_load_devices groth16_parse_device groth16_cache_set_budget groth16_cache_info_sized
-groth16_verify groth16_verify_json groth16_verify_last_error
+groth16_verify groth16_verify_json groth16_verify_last_error groth16_group_describe
 """.split()
 
 

@@ -16,6 +16,7 @@
 //   rccl    ncclAllGather / grouped ncclSend+ncclRecv on communicators of ncclCommInitAll (libicicle_snark_rccl.so, loaded on
 //           demand so that the single-GPU library carries no RCCL dependency).
 // Every transport is checked once per group with a data pattern before a prove relies on it.
+#include <algorithm>
 #include <dlfcn.h>
 
 #include "../team.h"
@@ -134,6 +135,26 @@ void group_info(const DeviceGroup* g, Groth16CircuitInfo* info)
   info->shards = (uint32_t)g->shards.size();
 }
 
+// what the group runs on, as one line of JSON (groth16_group_describe; bench.py reports it: the reader of a scaling run must
+// be able to tell which transport moved the exchanges and whether RCCL saw the devices at all)
+std::string group_describe(const DeviceGroup* g)
+{
+  std::vector<int> distinct;
+  for (int d : g->devs)
+    if (std::find(distinct.begin(), distinct.end(), d) == distinct.end()) distinct.push_back(d);
+  std::string out = "{\"shards\": " + std::to_string(g->devs.size()) + ", \"devices\": [";
+  for (size_t i = 0; i < g->devs.size(); i++) out += (i ? ", " : "") + std::to_string(g->devs[i]);
+  out += "], \"distinct_devices\": " + std::to_string(distinct.size());
+  out += std::string(", \"transport\": \"") + mode_name(g->mode) + "\"";
+  out += std::string(", \"peer_access\": ") + (g->peer_ok ? "true" : "false");
+  // ranks of an RCCL communicator that take part in the exchanges: 0 unless the rccl transport was selected
+  out += ", \"rccl_ranks\": " + std::to_string(g->mode == XCHG_RCCL ? g->comms.size() : (size_t)0);
+  out += std::string(", \"distributed_front_end\": ") + (g->dist ? "true" : "false");
+  out += std::string(", \"transport_forced_by_env\": ") + (getenv("ICICLE_SNARK_EXCHANGE") && *getenv("ICICLE_SNARK_EXCHANGE") ? "true" : "false");
+  out += "}";
+  return out;
+}
+
 static bool load_rccl(RcclApi& api)
 {
   if (api.dso) return true;
@@ -238,43 +259,54 @@ struct RunState {
   }
 };
 
-// one pattern all-gather + all-to-all through the group's transport, verified on the host.  The producers are made LATE on
-// purpose — a delay kernel (longer on every next rank) sits in front of the copies that put the patterns in place, and nothing
-// synchronises the host before the peers enqueue their side — so a transport whose cross-device ordering does not hold (an event of one device
-// that fails to hold back a stream of another) reads the zeroed buffers and is rejected here, not in a proof.
+// Pattern all-gather + all-to-all through the group's transport, verified on the host — TWO rounds with different patterns on
+// the SAME buffers and the SAME events, which is what a sequence of proves does to d_witness / d_dist_y / d_dist_send2 and
+// ev_slice / ev_s1 / ev_s2.  The producers are made LATE on purpose in both rounds — a delay kernel (longer on every next rank)
+// sits in front of the copies that put the patterns in place, and nothing synchronises the host before the peers enqueue their
+// side — so a transport whose cross-device ordering does not hold (an event of one device that fails to hold back a stream of
+// another) reads the zeroed buffers in round 1, and one that keeps stale remote lines on the reader or does not honour the
+// RE-record of an event reads round 1's bytes in round 2: either is rejected here, not in a proof.
 static int exchange_self_test(DeviceGroup* g)
 {
   const int G = (int)g->devs.size();
   const size_t slice = 4096, chunk = 1024, rows = 3, row_bytes = chunk * G;
+  const int ROUNDS = 2;
   std::vector<uint8_t*> ag(G, nullptr), snd(G, nullptr), rcv(G, nullptr), stage(G, nullptr);
   std::vector<void*> agv(G), sndv(G);
   RunState st;
   std::vector<int> bad(G, 0);
+  auto ag_byte = [](int round, int rank, size_t i) { return (uint8_t)(rank * 31 + i * 7 + 1 + round * 101); };
+  auto a2a_byte = [](int round, int src, int dst, size_t q, size_t i) { return (uint8_t)(src * 17 + dst * 5 + q * 3 + i + round * 59); };
   g->team->run([&](int r) {
     int rc = set_active_device(g->devs[r]);
     ZKeyCache* z = g->shards[r].get();
     hipStream_t s = z->s_qap;
-    // patterns into a staging buffer, exchange buffers zeroed — all complete before anybody goes on
+    // exchange buffers zeroed — complete before anybody goes on
     auto prepare = [&]() -> int {
       P_HIP(hipMalloc((void**)&ag[r], slice * G));
       P_HIP(hipMalloc((void**)&snd[r], rows * row_bytes));
       P_HIP(hipMalloc((void**)&rcv[r], rows * row_bytes));
       P_HIP(hipMalloc((void**)&stage[r], slice + rows * row_bytes));
-      std::vector<uint8_t> h(slice + rows * row_bytes, 0);
-      for (size_t i = 0; i < slice; i++) h[i] = (uint8_t)(r * 31 + i * 7 + 1);
-      for (size_t q = 0; q < rows; q++)
-        for (int p = 0; p < G; p++)
-          for (size_t i = 0; i < chunk; i++) h[slice + q * row_bytes + (size_t)p * chunk + i] = (uint8_t)(r * 17 + p * 5 + q * 3 + i);
-      P_HIP(hipMemcpyAsync(stage[r], h.data(), h.size(), hipMemcpyHostToDevice, s));
       P_HIP(hipMemsetAsync(ag[r], 0, slice * G, s));
       P_HIP(hipMemsetAsync(snd[r], 0, rows * row_bytes, s));
       P_HIP(hipMemsetAsync(rcv[r], 0, rows * row_bytes, s));
       P_HIP(hipStreamSynchronize(s));
       return 0;
     };
+    // this round's patterns into the staging buffer (synchronised: the LATE part is the device-side copy below)
+    auto fill_stage = [&](int round) -> int {
+      std::vector<uint8_t> h(slice + rows * row_bytes, 0);
+      for (size_t i = 0; i < slice; i++) h[i] = ag_byte(round, r, i);
+      for (size_t q = 0; q < rows; q++)
+        for (int p = 0; p < G; p++)
+          for (size_t i = 0; i < chunk; i++) h[slice + q * row_bytes + (size_t)p * chunk + i] = a2a_byte(round, r, p, q, i);
+      P_HIP(hipMemcpyAsync(stage[r], h.data(), h.size(), hipMemcpyHostToDevice, s));
+      P_HIP(hipStreamSynchronize(s));
+      return 0;
+    };
     // the late producer: delay, then the patterns move into the buffers the peers read; the event is all the peers get.
     // The delays differ by rank (this rank's own exchange sits behind its own delay on the same stream): rank 0 is through
-    // after 2 ms and would read rank 1's still-zero buffers 2 ms too early, rank 1 rank 2's, …
+    // after 2 ms and would read rank 1's buffers 2 ms too early, rank 1 rank 2's, …
     auto produce = [&]() -> int {
       P_HIP(xchg_delay(2.0 * (r + 1), s));
       P_HIP(hipMemcpyAsync(ag[r] + (size_t)r * slice, stage[r], slice, hipMemcpyDeviceToDevice, s));
@@ -284,37 +316,43 @@ static int exchange_self_test(DeviceGroup* g)
     };
     if (!rc) rc = prepare();
     st.note(rc);
-    g->team->barrier(); // every buffer exists and is zero
-    if (!st.failed) {
-      rc = produce();
-      st.note(rc);
-    }
     agv[r] = ag[r];
     sndv[r] = snd[r];
-    g->team->barrier(); // every ev_slice is recorded (enqueued, not complete)
-    if (!st.failed) {
-      rc = xchg_allgather(g, r, agv.data(), slice, g->ev_slice.data(), s);
-      if (!rc) rc = xchg_alltoall(g, r, sndv.data(), rcv[r], (uint32_t)rows, row_bytes, chunk, g->ev_slice.data(), s);
-      if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail((int)ICICLE_UNKNOWN_ERROR, "exchange self-test: stream error");
-      st.note(rc);
-    }
-    if (!st.failed) {
-      std::vector<uint8_t> a(slice * G), b(rows * row_bytes);
-      (void)hipMemcpy(a.data(), ag[r], a.size(), hipMemcpyDeviceToHost);
-      (void)hipMemcpy(b.data(), rcv[r], b.size(), hipMemcpyDeviceToHost);
-      for (int p = 0; p < G && !bad[r]; p++)
-        for (size_t i = 0; i < slice; i++)
-          if (a[(size_t)p * slice + i] != (uint8_t)(p * 31 + i * 7 + 1)) {
-            bad[r] = 1;
-            break;
-          }
-      for (size_t q = 0; q < rows && !bad[r]; q++)
+    for (int round = 0; round < ROUNDS; round++) {
+      if (!st.failed) {
+        rc = fill_stage(round);
+        st.note(rc);
+      }
+      g->team->barrier(); // every buffer exists (round 0: zeroed); nobody still reads what the producers are about to overwrite
+      if (!st.failed) {
+        rc = produce();
+        st.note(rc);
+      }
+      g->team->barrier(); // every ev_slice is recorded (enqueued, not complete)
+      if (!st.failed) {
+        rc = xchg_allgather(g, r, agv.data(), slice, g->ev_slice.data(), s);
+        if (!rc) rc = xchg_alltoall(g, r, sndv.data(), rcv[r], (uint32_t)rows, row_bytes, chunk, g->ev_slice.data(), s);
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail((int)ICICLE_UNKNOWN_ERROR, "exchange self-test: stream error");
+        st.note(rc);
+      }
+      if (!st.failed) {
+        std::vector<uint8_t> a(slice * G), b(rows * row_bytes);
+        (void)hipMemcpy(a.data(), ag[r], a.size(), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(b.data(), rcv[r], b.size(), hipMemcpyDeviceToHost);
         for (int p = 0; p < G && !bad[r]; p++)
-          for (size_t i = 0; i < chunk; i++)
-            if (b[q * row_bytes + (size_t)p * chunk + i] != (uint8_t)(p * 17 + r * 5 + q * 3 + i)) {
-              bad[r] = 1;
+          for (size_t i = 0; i < slice; i++)
+            if (a[(size_t)p * slice + i] != ag_byte(round, p, i)) {
+              bad[r] = 1 + round;
               break;
             }
+        for (size_t q = 0; q < rows && !bad[r]; q++)
+          for (int p = 0; p < G && !bad[r]; p++)
+            for (size_t i = 0; i < chunk; i++)
+              if (b[q * row_bytes + (size_t)p * chunk + i] != a2a_byte(round, p, r, q, i)) {
+                bad[r] = 1 + round;
+                break;
+              }
+      }
     }
     g->team->barrier(); // nobody frees a buffer a peer may still be reading
     for (uint8_t* p : {ag[r], snd[r], rcv[r], stage[r]})
@@ -322,7 +360,7 @@ static int exchange_self_test(DeviceGroup* g)
   });
   if (int rc = st.finish()) return rc;
   for (int r = 0; r < G; r++)
-    if (bad[r]) return fail((int)ICICLE_UNKNOWN_ERROR, "exchange self-test (%s): rank %d received wrong data", mode_name(g->mode), r);
+    if (bad[r]) return fail((int)ICICLE_UNKNOWN_ERROR, "exchange self-test (%s): rank %d received wrong data in round %d", mode_name(g->mode), r, bad[r]);
   return 0;
 }
 

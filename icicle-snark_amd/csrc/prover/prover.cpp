@@ -256,6 +256,24 @@ __attribute__((visibility("default"))) int groth16_cache_info_sized(const Groth1
   return 0;
 }
 
+// What a device-group key runs on, as one line of JSON: {"shards", "devices", "distinct_devices", "transport": "pull" | "memcpy" |
+// "rccl", "peer_access", "rccl_ranks" (0 unless the rccl transport moves the exchanges), "distributed_front_end", …}.  A
+// single-device key answers {"shards": 0, "devices": [id]}.  Returns 0, or the size needed (incl. NUL) when `cap` is too small.
+__attribute__((visibility("default"))) int groth16_group_describe(const Groth16CacheManager* cm, const char* key, char* out, size_t cap)
+{
+  if (!cm || !out) return fail(ERR_ARG, "null argument");
+  Groth16CacheManager* m = const_cast<Groth16CacheManager*>(cm);
+  std::string text;
+  if (const std::shared_ptr<DeviceGroup> g = find_group(m, key)) text = group_describe(g.get());
+  else if (const std::shared_ptr<ZKeyCache> zp = find(m, key))
+    text = "{\"shards\": 0, \"devices\": [" + std::to_string(zp->device_id) + "], \"distinct_devices\": 1, \"transport\": \"none\", \"rccl_ranks\": 0}";
+  else
+    return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  if (text.size() + 1 > cap) return (int)text.size() + 1;
+  memcpy(out, text.c_str(), text.size() + 1);
+  return 0;
+}
+
 __attribute__((visibility("default"))) int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, uint8_t out_points[GROTH16_COMMITMENTS_BYTES], Groth16Timings* tm)
 {
   if (!cm || !out_points) return fail(ERR_ARG, "null argument");

@@ -202,5 +202,6 @@ int group_load(Groth16CacheManager* cm, const char* key, const uint8_t* zkey, si
 int group_commitments(Groth16CacheManager* cm, DeviceGroup* g, const void* wtns, size_t wtns_len, uint8_t* out_points, Groth16Timings* tm);
 const ZKeyCache* group_lead(const DeviceGroup* g);
 void group_info(const DeviceGroup* g, Groth16CircuitInfo* info);
+std::string group_describe(const DeviceGroup* g); // one line of JSON: shards, devices, transport, RCCL ranks (groth16_group_describe)
 } // namespace prover
 } // namespace isnark

@@ -142,6 +142,12 @@ int groth16_cache_info(const Groth16CacheManager* cm, const char* key, Groth16Ci
  * built against an older, shorter struct keeps working when the struct grows */
 int groth16_cache_info_sized(const Groth16CacheManager* cm, const char* key, void* info, size_t info_size);
 
+/* What the key runs on, as one line of JSON — for a device group {"shards": G, "devices": [...], "distinct_devices": k,
+ * "transport": "pull" | "memcpy" | "rccl", "peer_access": bool, "rccl_ranks": n (0 unless the rccl transport moves the
+ * exchanges), "distributed_front_end": bool, "transport_forced_by_env": bool}; a single-device key answers "shards": 0.
+ * Returns 0, or the size needed (incl. NUL) when `cap` is too small.  bench.py prints it with every multi-GPU line. */
+int groth16_group_describe(const Groth16CacheManager* cm, const char* key, char* out, size_t cap);
+
 /* phase timings (HIP events) of the most recent prove of `key` through ANY entry point — groth16_prove returns none,
  * like the reference's; bench.py reads them here.  ICICLE_SNARK_QUIET=1 suppresses groth16_prove's "proof took: …" line
  * (src/lib.rs:58) for callers whose stdout is machine-read. */

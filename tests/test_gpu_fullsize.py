@@ -298,6 +298,44 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert d["config"]["host"].startswith("one process, one host thread per GPU") and d["config"]["prove_ms_rank_per_gpu"] > 0
 
 
+def test_bench_gpus_without_a_launcher(gpu):
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset (no torchrun): the library's own multi-device entry — one process,
+    groth16_prove with the device list "HIP:0,0" — is timed in a child of bench.py; rc 0, ONE JSON line, and the line says which
+    transport moved the exchanges, how many devices the group touched, how many RCCL ranks took part (0: the pull / memcpy
+    transports do not go through RCCL) and that the group's proofs equal the single-device ones (two witnesses)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ICICLE_SNARK_BENCH_DEVICES"] = "0,0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--constraints", "100000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["achieved"] > 0
+    assert c["msm_sharding"] == "point-range x2" and c["launcher"].startswith("none")
+    assert c["exchange"] in ("pull", "memcpy") and c["rccl_ranks"] == 0 and c["devices_touched"] == 1
+    g = c["device_group"]
+    assert g["shards"] == 2 and g["devices"] == [0, 0] and g["equals_single_device_proof"] is True
+    assert g["attempts"][-1]["error"] is None and len(g["attempts"]) == 1
+
+
+def test_bench_gpus_without_a_launcher_falls_back(gpu):
+    """the same entry when every device-group attempt fails (a device that does not exist): the ladder — library default
+    transports, memcpy forced, rccl forced — is walked, the line still appears from the single-device prove and says so"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ICICLE_SNARK_BENCH_DEVICES"] = "0,97"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--constraints", "100000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert d["value"] > 0 and "FALLBACK" in c["msm_sharding"]
+    assert [a["error"] is None for a in c["device_group"]["attempts"]] == [False, False, False, True]
+
+
 @pytest.mark.parametrize("fault", ["abort", "hang", "no_such_device"])
 def test_bench_survives_a_failing_device_group(gpu, fault):
     """The device-group leg of bench.py runs in a child process of rank 0: when that process aborts, hangs (ended after

@@ -69,6 +69,10 @@ cm.load("full", zkey)
 want = cm.prove_mem("full", wtns, 2, 3)[0]
 cm.load_devices("g", zkey, [0, 0, 0, 0])
 assert cm.prove_mem("g", wtns, 2, 3)[0] == want
+d = cm.group_describe("g")
+assert d["shards"] == 4 and d["devices"] == [0, 0, 0, 0] and d["distinct_devices"] == 1 and d["rccl_ranks"] == 0, d
+assert d["transport"] == os.environ["ICICLE_SNARK_EXCHANGE"] and d["transport_forced_by_env"] is True, d
+assert cm.group_describe("full")["shards"] == 0
 print("GROUP_OK")
 ''' % ROOT
     env = dict(os.environ, ICICLE_SNARK_EXCHANGE=mode, ICICLE_SNARK_VERBOSE="1")
