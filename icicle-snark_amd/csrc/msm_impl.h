@@ -516,6 +516,76 @@ __global__ __launch_bounds__(256) void msm_table_rows_kernel(const typename C::A
       for (int k = 0; k < (w < wide ? c : c - 1); k++) x = CL::x_dbl(x); // row w + 1 sits at the bit where window w ends
   }
 }
+// ---- content guard of the automatic tables (msm_plan.h) -----------------------------------------------------------------------
+// 64-bit sum over all 16-byte words of a position-dependent mix: order-independent (one atomic per workgroup), sensitive to
+// any changed, moved or swapped word.  `out` must be zero before the launch.
+__global__ __launch_bounds__(256) void bases_hash_sum_kernel(const uint4* __restrict__ p, uint64_t nwords, unsigned long long* __restrict__ out)
+{
+  unsigned long long h = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 w = p[i];
+    const unsigned long long a = (unsigned long long)w.x | ((unsigned long long)w.y << 32), b = (unsigned long long)w.z | ((unsigned long long)w.w << 32);
+    const unsigned long long k = (i + 1) * 0x9E3779B97F4A7C15ull;
+    unsigned long long x = (a ^ k) * 0xFF51AFD7ED558CCDull;
+    x ^= x >> 33;
+    unsigned long long y = (b + ((k << 29) | (k >> 35))) * 0xC4CEB9FE1A85EC53ull;
+    y ^= y >> 29;
+    h += (x + y) * 0xD6E8FEB86659FD93ull + (x ^ (y >> 17));
+  }
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
+  __shared__ unsigned long long sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+// Guarded refresh: nothing when the bases still hash to the sum the table was built from; otherwise every row of the table is
+// recomputed from the bases in place — the same functions as the regular build (rows → affine → internal encoding), but one
+// thread per base with one field inversion per row and no temporaries: slow (≈ 0.1–0.3 s at a million bases), rare, correct.
+template <class C, class F>
+__global__ __launch_bounds__(128) void msm_table_refresh_kernel(const typename C::A* __restrict__ pts, uint32_t n, int from_form, int c, int W, int wide, typename C::A* __restrict__ table,
+                                                                const unsigned long long* __restrict__ built_sum, const unsigned long long* __restrict__ cur_sum)
+{
+  typedef typename Lazy<C>::type CL;
+  if (*built_sum == *cur_sum) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const typename C::A p = pts[i];
+  typename CL::X x = CL::x_zero();
+  if (!C::aff_is_zero(p)) {
+    const typename CL::A a = CL::load_affine(p, from_form, false);
+    CL::x_madd(x, a);
+  }
+  for (int w = 0; w < W; w++) {
+    const typename C::P pr = C::x_to_projective(CL::x_store(x)); // Montgomery-256 projective, identity → (0, 1, 0)
+    typename C::A a;
+    if (F::is_zero(pr.z)) {
+      a.x = F::zero();
+      a.y = F::zero();
+    } else {
+      const typename F::T zi = F::inv(pr.z);
+      a.x = F::from_mont(F::mul(pr.x, zi));
+      a.y = F::from_mont(F::mul(pr.y, zi));
+      a = CL::store_affine_internal(CL::load_affine(a, 0, false));
+    }
+    table[(size_t)w * n + i] = a;
+    if (w + 1 < W)
+      for (int k = 0; k < (w < wide ? c : c - 1); k++) x = CL::x_dbl(x);
+  }
+}
+__global__ void bases_hash_commit_kernel(unsigned long long* built_sum, const unsigned long long* cur_sum) { *built_sum = *cur_sum; }
+
+inline hipError_t bases_hash_sum(const void* bases, size_t bytes, unsigned long long* out, hipStream_t s)
+{
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  const uint64_t nwords = bytes / 16;
+  unsigned grid = (unsigned)((nwords + 256 * 8 - 1) / (256 * 8));
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(bases_hash_sum_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)bases, nwords, out);
+  return hipGetLastError();
+}
+
 // `async`: temporaries from the stream's workspace arena, nothing synchronised — the table is complete in stream order (the
 // automatic tables of bn254_msm); else plain allocations and a synchronised stream on return (cache build of the prover).
 template <class C, class F>
@@ -873,9 +943,15 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
 
   int lbf = 0; // 0 = this library's default (msm_sort_run)
   ext_get_int(cfg->ext, "large_bucket_factor", &lbf);
-  // automatic fixed-base table (msm_plan.h): one MSM of full-width scalars over a device-resident base array this runtime tracks
+  // automatic fixed-base table (msm_plan.h): one MSM of full-width scalars over a device-resident base array this runtime tracks.
+  // The table is used for the bases' CURRENT contents only: hash sum of the array in stream order + guarded in-place refresh.
   BaseTableRef tref;
   bool use_table = false;
+  struct Unpin {
+    uint64_t id = 0;
+    ~Unpin() { base_table_unpin(id); } // after the last kernel of this call has been enqueued (hipFree waits for enqueued work)
+  } unpin;
+  WsScoped<unsigned long long> cur_sum;
   if (batch == 1 && stride == 1 && cfg->c <= 0 && (cfg->bitsize == 0 || cfg->bitsize == 254) && cfg->are_points_on_device && L >= MSM_AUTO_TABLE_MIN_L &&
       is_tracked_device_ptr(bases)) {
     const MsmGeom gt = msm_geometry(L, 0, 1);
@@ -885,16 +961,31 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
       const BaseTableState st = base_table_lookup(bases, (size_t)L * sizeof(A), L, sizeof(A) > 64, form, table_bytes, &tref);
       if (st == BASE_TABLE_BUILD) {
         void* table = nullptr;
-        if (build_table_run<C, F>(bases, L, form, gt, s, &table, /*async=*/true) == ICICLE_SUCCESS) {
-          base_table_publish(bases, L, sizeof(A) > 64, form, table, table_bytes, gt, s);
-          tref.table = table;
-          tref.g = gt;
-          tref.built = nullptr; // built on this very stream
+        unsigned long long* sums = nullptr;
+        if (hipMalloc((void**)&sums, 64) == hipSuccess && bases_hash_sum(bases, (size_t)L * sizeof(A), sums, s) == hipSuccess &&
+            build_table_run<C, F>(bases, L, form, gt, s, &table, /*async=*/true) == ICICLE_SUCCESS) {
+          base_table_publish(bases, L, sizeof(A) > 64, form, table, table_bytes, gt, sums, s, &tref);
+          unpin.id = tref.id;
           use_table = true;
-        } else (void)hipGetLastError(); // no memory for the table: the classic layout still works
+        } else {
+          (void)hipGetLastError(); // no memory for the table: the classic layout still works
+          if (sums) {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(sums);
+          }
+        }
       } else if (st == BASE_TABLE_HIT) {
+        unpin.id = tref.id;
         use_table = true;
         if (tref.built) HIP_TRY(hipStreamWaitEvent(s, tref.built, 0), ICICLE_UNKNOWN_ERROR); // built on another stream, perhaps
+        // the caller may have rewritten its bases by means this library does not see (own kernels, raw hipMemcpy): hash them
+        // now, in stream order, and let the guarded refresh bring the table up to date when the sum has moved
+        HIP_TRY(cur_sum.alloc(8, s), ICICLE_ALLOCATION_FAILED);
+        HIP_TRY(bases_hash_sum(bases, (size_t)L * sizeof(A), cur_sum.p, s), ICICLE_UNKNOWN_ERROR);
+        hipLaunchKernelGGL((msm_table_refresh_kernel<C, F>), dim3((L + 127) / 128), dim3(128), 0, s, (const A*)bases, L, form, tref.g.c, tref.g.W, tref.g.wide, (A*)const_cast<void*>(tref.table),
+                           tref.sums, cur_sum.p);
+        hipLaunchKernelGGL(bases_hash_commit_kernel, dim3(1), dim3(1), 0, s, tref.sums, cur_sum.p);
+        ICICLE_TRY(check_launch("msm_table_refresh"));
       }
     }
   }

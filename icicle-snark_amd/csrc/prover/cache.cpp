@@ -49,6 +49,7 @@ ZKeyCache::~ZKeyCache()
       if (e) (void)hipEventDestroy(e);
     for (auto e : ev_done)
       if (e) (void)hipEventDestroy(e);
+    for (auto& p : prof) msm_profile_own_destroy(&p);
   }
 
 namespace {
@@ -336,20 +337,38 @@ int rebuild_witness_tables(ZKeyCache* z, int c_new)
   std::lock_guard<std::mutex> lk(rebuild_mu);
   const MsmGeom g = c_new == z->geom_w_default_c ? msm_geometry(z->A.len(), 0, 1) : msm_geometry(z->A.len(), 0, c_new);
   if (!g.tab || (c_new != z->geom_w_default_c && g.c != c_new)) return 0; // the entry encoding does not fit this width: keep what there is
-  // room for the largest new table next to the old ones (they go one by one)
+  // ALL four new tables are built next to the old ones, then pointers and geometry are swapped together: a failure at any
+  // point (allocation, launch) frees what was built and leaves the key exactly as it was — the old tables with the old
+  // geom_w — so shard_commitments never indexes tables of one geometry with digits of another (round-3 advisor finding:
+  // the one-by-one swap left A and B1 in the new geometry when B2's build failed).  Memory: the four new tables plus the
+  // temporaries of the largest build (projective rows + inversion scratch of the G2 set); when the device cannot hold that
+  // next to the old tables the key simply keeps its width.
+  struct Job { Shard* sh; bool g2; };
+  const Job jobs[4] = {{&z->A, false}, {&z->B1, false}, {&z->B2, true}, {&z->C, false}};
   size_t free_b = 0, total_b = 0;
   release_cached_device_memory();
   P_HIP(hipMemGetInfo(&free_b, &total_b));
-  const uint64_t biggest = (uint64_t)z->B2.len() * g.W * 128 + (uint64_t)z->B2.len() * g.W * (192 + 64) + (64u << 20);
-  if (biggest > free_b) return 0;
-  struct Job { Shard* sh; bool g2; };
-  const Job jobs[4] = {{&z->A, false}, {&z->B1, false}, {&z->B2, true}, {&z->C, false}};
-  for (const Job& j : jobs) {
-    void* table = nullptr;
+  uint64_t need = (uint64_t)z->B2.len() * g.W * (192 + 64) + (64u << 20);
+  for (const Job& j : jobs) need += (uint64_t)j.sh->len() * g.W * (j.g2 ? 128 : 64);
+  if (need > free_b) return 0;
+  void* fresh[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < 4; k++) {
+    const Job& j = jobs[k];
     // row 0 of the old table = the bases themselves, in the internal encoding (form 2)
-    P_ICICLE(j.g2 ? msm_g2_build_table(j.sh->d_points, j.sh->len(), 2, g, nullptr, &table) : msm_g1_build_table(j.sh->d_points, j.sh->len(), 2, g, nullptr, &table));
-    P_HIP(hipFree(j.sh->d_points));
-    j.sh->d_points = table;
+    const eIcicleError e = j.g2 ? msm_g2_build_table(j.sh->d_points, j.sh->len(), 2, g, nullptr, &fresh[k]) : msm_g1_build_table(j.sh->d_points, j.sh->len(), 2, g, nullptr, &fresh[k]);
+    if (e != ICICLE_SUCCESS) {
+      (void)hipGetLastError();
+      for (void* t : fresh)
+        if (t) (void)hipFree(t);
+      // not an error of the prove: the key keeps its tables and its width (out of memory is the expected cause)
+      if (getenv("ICICLE_SNARK_VERBOSE")) fprintf(stderr, "[icicle-snark-hip] witness tables keep c = %d (rebuild for c = %d failed: %s)\n", z->geom_w.c, c_new, icicle_snark_last_error());
+      return 0;
+    }
+  }
+  for (int k = 0; k < 4; k++) {
+    const Job& j = jobs[k];
+    (void)hipFree(j.sh->d_points); // (a synchronising free: nothing of a prove is in flight here)
+    j.sh->d_points = fresh[k];
     z->device_bytes += (int64_t)j.sh->len() * ((int64_t)g.W - (int64_t)z->geom_w.W) * (j.g2 ? 128 : 64);
   }
   z->geom_w = g;

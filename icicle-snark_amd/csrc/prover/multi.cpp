@@ -469,7 +469,10 @@ int group_load(Groth16CacheManager* cm, const char* key, const uint8_t* zkey, si
           std::unique_ptr<ZKeyCache> z;
           const int rc = build_cache(zkey, len, d, r, G, z);
           st.note(rc);
-          if (!rc) g->shards[r] = std::shared_ptr<ZKeyCache>(z.release());
+          if (!rc) {
+            z->in_group = true;
+            g->shards[r] = std::shared_ptr<ZKeyCache>(z.release());
+          }
         }
       });
     for (auto& t : builders) t.join();

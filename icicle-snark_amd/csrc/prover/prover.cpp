@@ -295,7 +295,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   if (int rc = set_active_device(z->device_id)) return rc;
   if (int rc = ensure_domain(cm, z)) return rc;
   // the key follows its witnesses: a digit width at least two bits off the one the last witness called for → rebuild the four
-  // witness tables now (nothing of this prove is enqueued yet; the streams are idle), at most once every eight proves
+  // witness tables now, at most once every eight proves.  On one device nothing of this prove is enqueued yet; in a device group
+  // the front end and the exchanges of this shard already are (multi.cpp) — they do not touch the tables, and the rebuild's
+  // synchronising frees wait for them.  The rebuild is all-or-nothing (cache.cpp): afterwards tables and geom_w agree either way.
   if (z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1) {
     const int c_t = witness_digit_target(z, z->witness_entries);
     if ((c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (z->geom_w.c == z->geom_w_default_c || z->proves_since_rebuild >= 8)) {
@@ -362,8 +364,11 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // ---- stream g2: ONE digit sort of witness[wlo:whi] (shared by A, B1, B2, C), then the G2 bucket stages
   P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));
   const uint32_t wlo = z->A.lo, wlen = z->A.len(), skip = npub + 1;
-  MsmProfile* prof[5]; // A, B1, B2, C, H
-  for (auto& p : prof) p = msm_profile_next();
+  MsmProfile* prof[5]; // A, B1, B2, C, H — this entry's own slots (published to the device's ring at the end by the lead shard)
+  for (int k = 0; k < 5; k++) {
+    prof[k] = &z->prof[k];
+    msm_profile_own_init(prof[k]);
+  }
   // the witness sort is timed with the profile of the G2 MSM that follows it on g2
   MsmProfile* psort = prof[2];
   (void)hipEventRecord(psort->ev[0], g2);
@@ -579,6 +584,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   z->proves_since_rebuild++;
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_h);
+  // HIP-event profile of the five MSMs → the ring icicle_snark_msm_profile reads (bench.py: back = 4 … 0 = A, B1, B2, C, H); in
+  // a device group only the lead shard publishes
+  if (z->shard_rank == 0 || !z->in_group) msm_profile_publish(z->prof, 5);
 #ifdef ICICLE_SNARK_EXPERIMENTS
   if (dupmask & 16) msm_sort_release(&plan_h_dup);
   if (dupmask_w & 32) msm_sort_release(&plan_w_dup);

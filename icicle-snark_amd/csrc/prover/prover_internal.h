@@ -93,6 +93,7 @@ struct ZKeyCache {
   G2::P vk_beta_2, vk_gamma_2, vk_delta_2;
   // device
   int device_id = 0, shard_rank = 0, shard_count = 1;
+  bool in_group = false; // a shard of an in-process device group (multi.cpp), as opposed to the one shard of a rank-per-GPU process
   MsmGeom geom_w, geom_h; // window geometry of the witness MSMs (A, B1, B2, C) and of the H MSM; geom_w follows the witnesses (cache.cpp)
   int geom_w_default_c = 0;        // digit width of the dense geometry chosen at cache build
   uint32_t* h_stats = nullptr;     // pinned: offset and count of the last bucket of the witness sort = its entry count
@@ -123,6 +124,7 @@ struct ZKeyCache {
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
   bool witness_event_set = false; // ev_witness was already recorded for the resident witness (behind a device-side all-gather)
   Groth16Timings last_tm = {0, 0, 0, 0}; // phase timings of the most recent prove (groth16_last_timings)
+  MsmProfile prof[5] = {};               // A, B1, B2, C, H of the most recent prove: this entry's own slots (the shards of a group may share a device)
   uint64_t last_use = 0;                 // CacheManager LRU clock
 
   ~ZKeyCache();

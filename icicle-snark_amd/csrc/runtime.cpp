@@ -445,10 +445,14 @@ struct BaseTable {
   MsmGeom g;
   hipEvent_t built;
   uint64_t last_use;
+  unsigned long long* sums; // device: hash sum of the bases at build time (msm_plan.h)
+  int pins;                 // calls that hold the table between lookup and the end of their enqueueing
+  uint64_t id;
 };
 static std::mutex g_bt_mu;
 static std::vector<BaseTable> g_bt;
-static uint64_t g_bt_clock = 0;
+static std::vector<BaseTable> g_bt_parked; // retired while pinned: freed by the last unpin
+static uint64_t g_bt_clock = 0, g_bt_next_id = 1;
 static bool base_tables_enabled()
 {
   static const bool on = !(getenv("ICICLE_SNARK_MSM_TABLES") && atoi(getenv("ICICLE_SNARK_MSM_TABLES")) == 0);
@@ -459,16 +463,52 @@ static size_t base_tables_budget()
   static const size_t v = getenv("ICICLE_SNARK_MSM_TABLE_MB") ? (size_t)atoll(getenv("ICICLE_SNARK_MSM_TABLE_MB")) << 20 : (size_t)16 << 30;
   return v;
 }
-static void base_table_drop(BaseTable& t) // caller holds g_bt_mu; hipFree waits for whatever still reads the table
+static void base_table_free(BaseTable& t) // hipFree waits for whatever enqueued work still reads the table
 {
-  if (t.table) {
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    if (cur != t.dev) (void)hipSetDevice(t.dev);
-    (void)hipFree(t.table);
-    if (t.built) (void)hipEventDestroy(t.built);
-    if (cur != t.dev) (void)hipSetDevice(cur);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != t.dev) (void)hipSetDevice(t.dev);
+  if (t.table) (void)hipFree(t.table);
+  if (t.sums) (void)hipFree(t.sums);
+  if (t.built) (void)hipEventDestroy(t.built);
+  if (cur != t.dev) (void)hipSetDevice(cur);
+  t.table = nullptr;
+  t.sums = nullptr;
+  t.built = nullptr;
+}
+// caller holds g_bt_mu.  A pinned table (a call is between its lookup and the end of its enqueueing: kernels that read the
+// table may not be in any stream yet, so a free here could run before them) is parked and freed by the last unpin.
+static void base_table_drop(BaseTable& t)
+{
+  if (!t.table) return;
+  if (t.pins > 0) {
+    g_bt_parked.push_back(t);
+    t.table = nullptr;
+    t.sums = nullptr;
+    t.built = nullptr;
+    t.pins = 0;
+    t.id = g_bt_next_id++; // the parked copy keeps the id the pin holders know
+    return;
   }
+  base_table_free(t);
+}
+void base_table_unpin(uint64_t id)
+{
+  if (!id) return;
+  std::lock_guard<std::mutex> lk(g_bt_mu);
+  for (BaseTable& t : g_bt)
+    if (t.id == id) {
+      if (t.pins > 0) t.pins--;
+      return;
+    }
+  for (size_t i = 0; i < g_bt_parked.size(); i++)
+    if (g_bt_parked[i].id == id) {
+      if (--g_bt_parked[i].pins <= 0) {
+        base_table_free(g_bt_parked[i]);
+        g_bt_parked.erase(g_bt_parked.begin() + i);
+      }
+      return;
+    }
 }
 void note_device_write(const void* p, size_t bytes)
 {
@@ -496,6 +536,9 @@ BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bo
       ref->table = t.table;
       ref->g = t.g;
       ref->built = t.built;
+      ref->sums = t.sums;
+      ref->id = t.id;
+      t.pins++;
       return BASE_TABLE_HIT;
     }
     t.sightings++;
@@ -512,8 +555,6 @@ BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bo
       }
       if (used + table_bytes <= base_tables_budget() || lru == (size_t)-1) break;
       base_table_drop(g_bt[lru]);
-      g_bt[lru].table = nullptr;
-      g_bt[lru].built = nullptr;
       g_bt[lru].sightings = 0;
     }
     return BASE_TABLE_BUILD;
@@ -526,15 +567,22 @@ BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bo
     if (old == (size_t)-1) return BASE_TABLE_NONE;
     g_bt.erase(g_bt.begin() + old);
   }
-  g_bt.push_back({dev, (uintptr_t)bases, bytes, n, g2, form, 1u, nullptr, 0, MsmGeom(), nullptr, ++g_bt_clock});
+  g_bt.push_back({dev, (uintptr_t)bases, bytes, n, g2, form, 1u, nullptr, 0, MsmGeom(), nullptr, ++g_bt_clock, nullptr, 0, g_bt_next_id++});
   return BASE_TABLE_NONE;
 }
-void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, hipStream_t s)
+// the table (and the hash sum of its bases in sums[0]) are complete in the order of stream s.  On return *ref names the table,
+// pinned for the publishing call — also when the entry went away in the meantime (a write to the bases between lookup and
+// publish): the table then serves this one call and is freed by its unpin.
+void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, unsigned long long* sums, hipStream_t s, BaseTableRef* ref)
 {
   int dev = 0;
   (void)hipGetDevice(&dev);
   hipEvent_t ev = nullptr;
   if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(ev, s);
+  ref->table = table;
+  ref->g = g;
+  ref->built = nullptr; // built on the caller's own stream
+  ref->sums = sums;
   std::lock_guard<std::mutex> lk(g_bt_mu);
   for (BaseTable& t : g_bt) {
     if (t.dev != dev || t.ptr != (uintptr_t)bases || t.n != n || t.g2 != g2 || t.form != form || t.table) continue;
@@ -542,12 +590,14 @@ void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* 
     t.table_bytes = table_bytes;
     t.g = g;
     t.built = ev;
+    t.sums = sums;
+    t.pins = 1;
+    ref->id = t.id;
     return;
   }
-  // the entry went away between lookup and publish (a write to the bases): the table is of no use
-  (void)hipStreamSynchronize(s);
-  (void)hipFree(table);
-  if (ev) (void)hipEventDestroy(ev);
+  BaseTable orphan = {dev, (uintptr_t)bases, 0, n, g2, form, 0u, table, table_bytes, g, ev, 0, sums, 1, g_bt_next_id++};
+  ref->id = orphan.id;
+  g_bt_parked.push_back(orphan);
 }
 
 } // namespace isnark

@@ -360,3 +360,54 @@ def test_msm_automatic_fixed_base_tables(gpu, O, grp, n):
     d_b = K.DeviceVec.from_host(bases3)
     check(bases3, rounds=3)
     st.destroy(); st2.destroy(); d_b.free()
+
+
+@pytest.mark.parametrize("grp,n", [("g1", 40_000), ("g2", 33_000)])
+def test_msm_tables_follow_writes_the_library_cannot_see(gpu, O, grp, n):
+    """The bases are read at call time (icicle/src/msm.cpp:12-32) however the caller wrote them: between bn254_msm calls on the
+    same pointer the array is overwritten by a RAW hipMemcpy of the HIP runtime (not through icicle_copy*, so the write tracking
+    of the C ABI sees nothing) — whole array, a single point, two points swapped — and every result is the oracle's sum over the
+    NEW contents (hash sum of the bases + guarded refresh of the table in stream order, csrc/msm_plan.h)."""
+    import ctypes as C
+    K = gpu
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
+    rng = np.random.default_rng(77 + n)
+    bases = _bases(O, grp, rng, n)
+    d_b = K.DeviceVec.from_host(bases)
+    st = K.IcicleStream()
+
+    def raw_write(arr, byte_off=0):
+        a = np.ascontiguousarray(arr)
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemcpy(C.c_void_p(d_b.ptr + byte_off), a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0   # hipMemcpyHostToDevice
+
+    def check(points, rounds, stream=None):
+        for _ in range(rounds):
+            sc = rand_fr(O, rng, n)
+            want = O.ec_to_affine(grp, O.msm(grp, sc, points))
+            d_s = K.DeviceVec.from_host(sc, stream)
+            got = K.msm(grp, d_s, d_b, stream=stream)
+            assert np.array_equal(K.ec(grp, "to_affine", got), want)
+            d_s.free()
+
+    check(bases, 3)                                   # classic, build, hit
+    psize = bases[0].nbytes
+    b2 = _bases(O, grp, rng, n)
+    raw_write(b2)                                     # everything changes behind the library's back
+    check(b2, 2)
+    b3 = b2.copy()
+    b3[n // 3] = _bases(O, grp, rng, 1)[0]            # one point
+    raw_write(b3[n // 3], (n // 3) * psize)
+    check(b3, 2, stream=st)
+    b4 = b3.copy()
+    b4[[5, n - 7]] = b4[[n - 7, 5]]                   # two points trade places (an order-blind checksum would miss this)
+    raw_write(b4[5], 5 * psize)
+    raw_write(b4[n - 7], (n - 7) * psize)
+    check(b4, 2)
+    b5 = b4.copy()
+    b5[11] = 0                                        # a base becomes the identity
+    raw_write(b5[11], 11 * psize)
+    check(b5, 2, stream=st)
+    st.destroy(); d_b.free()
