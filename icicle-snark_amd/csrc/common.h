@@ -1,5 +1,6 @@
 // common.h — shared plumbing of the C-ABI implementation (error handling, staging of host operands).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -49,7 +50,21 @@ struct CopyJob {
   size_t n;
 };
 constexpr int STAGED_LANES = 8;
-hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes = nullptr, int n_lanes = 0, bool own_temp_streams = false);
+constexpr size_t STAGED_CHUNK_BYTES = 2u << 20; // bytes per staging chunk (and per DMA)
+// Progress of a host→device staged copy that runs on a thread of its own while the caller goes on enqueueing work: the HEAD —
+// the first head_bytes of job 0 — has arrived once every lane's `ev` has completed.  Each lane records its event behind its last
+// chunk of the head and then counts itself in `lanes_reported`; the caller waits (on the host, briefly: the records follow the
+// staging copies, not the DMAs) until lanes_reported == lanes_total, and only then makes its streams wait for ev[0 … lanes_total):
+// a hipStreamWaitEvent on an event that has not been recorded yet would not wait.
+struct StagedProgress {
+  size_t head_bytes = 0;
+  hipEvent_t ev[STAGED_LANES] = {};
+  std::atomic<int> lanes_total{-1}; // set before the workers start
+  std::atomic<int> lanes_reported{0};
+  std::atomic<bool> done{false};    // set by whoever ran staged_copy, after it returned (error paths included)
+};
+hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes = nullptr, int n_lanes = 0, bool own_temp_streams = false,
+                       StagedProgress* progress = nullptr);
 // the calling thread's next staged copies read sources inside [base, base + len) from file descriptor fd (fd < 0: off)
 void staged_copy_file_hint(const void* base, size_t len, int fd);
 void staged_copy_file_hint_get(const void** base, size_t* len, int* fd); // the calling thread's hint (to hand it to worker threads)

@@ -1,7 +1,4 @@
 // msm_g1.hip — G1 instantiation of the MSM pipeline (see msm_impl.h).
-#ifdef G1_ACC_MIN_WAVES // experiment hook: waves per SIMD of the G1 accumulation only (make EXTRA=-DG1_ACC_MIN_WAVES=4)
-#define ACC_MIN_WAVES G1_ACC_MIN_WAVES
-#endif
 #include "msm_impl.h"
 
 namespace isnark {
@@ -24,6 +21,15 @@ size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
 eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len, int ticket_slot)
 {
   return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_partials, prof, ticket_slot);
+}
+size_t msm_bucket_bytes(const SortPlan* pl, bool g2) { return (size_t)(pl->nbuckets ? pl->nbuckets : 1) * (g2 ? sizeof(G2::X) : sizeof(G1::X)); }
+eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len)
+{
+  return msm_accumulate_stage<G1>(pl, (const G1::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_buckets, into, prof);
+}
+eIcicleError msm_g1_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot)
+{
+  return msm_reduce_stage<G1>(pl, s, (const G1::X*)d_buckets, (G1::X*)d_partials, ticket_slot);
 }
 eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
 {

@@ -7,6 +7,14 @@ eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int point
 {
   return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_partials, prof, ticket_slot);
 }
+eIcicleError msm_g2_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len)
+{
+  return msm_accumulate_stage<G2>(pl, (const G2::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_buckets, into, prof);
+}
+eIcicleError msm_g2_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot)
+{
+  return msm_reduce_stage<G2>(pl, s, (const G2::X*)d_buckets, (G2::X*)d_partials, ticket_slot);
+}
 eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table)
 {
   return build_table_run<G2, Fq2Ops>(d_points, n, from_form, g, s, d_table);

@@ -66,12 +66,6 @@ template <class C> struct Lazy;
 template <> struct Lazy<G1> { typedef G1L type; };
 template <> struct Lazy<G2> { typedef G2L type; };
 
-#ifndef ACC_MIN_WAVES
-#define ACC_MIN_WAVES 1
-#endif
-#ifndef REDUCE_MIN_BLOCKS
-#define REDUCE_MIN_BLOCKS 1 // experiment hook (msm_g2.hip: -DG2_REDUCE_MIN_BLOCKS=2 caps the G2 reduction at 256 VGPRs)
-#endif
 // `form`: encoding of the affine bases in memory — 0 standard, 1 Montgomery R = 2^256 (zkey files), 2 internal
 // (packed canonical Montgomery R' = 2^261, produced once by msm_points_to_internal; no per-load conversion)
 // `ib` = 0: classic entry (point index; base = bases[(i − skip)·stride]).  ib > 0: table mode, entry = i | w << ib and
@@ -95,9 +89,9 @@ __device__ __forceinline__ typename Lazy<C>::type::A load_base_lazy(const typena
 }
 
 template <class C>
-__global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+__global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                               const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, uint32_t stride, int ib, int form,
-                                                              typename C::X* __restrict__ buckets)
+                                                              int into, typename C::X* buckets)
 {
   typedef typename Lazy<C>::type CL;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,8 +99,11 @@ __global__ __launch_bounds__(256, ACC_MIN_WAVES) void msm_accumulate_kernel(cons
   const uint32_t b = order[t]; // neighbouring lanes own buckets of (nearly) equal size
   const uint32_t cnt = counts[b];
   if (cnt > large_thr) return; // step 4b
+  // `into`: the bucket array already holds the sums of an earlier SEGMENT of the same scalar vector (the prover sorts and
+  // accumulates the head of a witness while its tail is still on the way over PCIe, prover.cpp) — go on from there
+  if (into && cnt == 0) return;
   const uint32_t* idx = sorted + offsets[b];
-  typename CL::X acc = CL::x_zero();
+  typename CL::X acc = into ? CL::x_load_internal(buckets[b]) : CL::x_zero();
   if (sizeof(typename C::A) > 64) {
     // G2: a prefetched 128-byte point would push the kernel past 256 VGPRs (one wave per SIMD); only the index is prefetched
     uint32_t e_nxt = cnt ? idx[0] : 0u;
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_large_kernel(const typenam
 // large buckets, step 2: one workgroup per large bucket sums its chunk partials into the bucket
 template <class C>
 __global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_large, const uint32_t* __restrict__ large_list,
-                                                                 const uint32_t* __restrict__ large_first, const typename C::X* __restrict__ item_partials, typename C::X* __restrict__ buckets)
+                                                                 const uint32_t* __restrict__ large_first, const typename C::X* __restrict__ item_partials, int into, typename C::X* buckets)
 {
   typedef typename Lazy<C>::type CL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -225,7 +222,10 @@ __global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* 
     const uint32_t b = large_list[li];
     const uint32_t nch = (counts[b] + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK, first = large_first[li];
     if (nch == 1) { // one chunk (most buckets just above the threshold): nothing to sum
-      if (threadIdx.x == 0) buckets[b] = item_partials[first];
+      if (threadIdx.x == 0) {
+        if (into) buckets[b] = CL::x_store_internal(CL::x_add(CL::x_load_internal(buckets[b]), CL::x_load_internal(item_partials[first])));
+        else buckets[b] = item_partials[first];
+      }
       continue;
     }
     typename CL::X acc = CL::x_zero();
@@ -233,7 +233,10 @@ __global__ __launch_bounds__(256) void msm_combine_large_kernel(const uint32_t* 
     int width = 1;
     while (width < (int)blockDim.x && (uint32_t)width < nch) width <<= 1;
     acc = block_reduce_lazy<C>(acc, sh, width);
-    if (threadIdx.x == 0) buckets[b] = CL::x_store_internal(acc);
+    if (threadIdx.x == 0) {
+      if (into) acc = CL::x_add(acc, CL::x_load_internal(buckets[b])); // what an earlier segment left in this bucket
+      buckets[b] = CL::x_store_internal(acc);
+    }
     __syncthreads();
   }
 }
@@ -659,17 +662,17 @@ eIcicleError points_to_internal_run(void* d_points, uint32_t n, int from_form, h
 // (msm_g2_acc.hip, Fq2 arithmetic inlined)
 template <class C>
 struct AccumulateLauncher {
-  static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets)
+  static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, int into)
   {
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, buckets);
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, into, buckets);
   }
 };
 #if defined(ISNARK_G2_ACC_EXTERN)
 template <>
 struct AccumulateLauncher<G2> {
-  static void launch(const SortPlan* pl, const G2::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, G2::X* buckets)
+  static void launch(const SortPlan* pl, const G2::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, G2::X* buckets, int into)
   {
-    isnark::msm_g2_accumulate_launch(pl, d_points, mont_pt, skip_below, stride, s, buckets);
+    isnark::msm_g2_accumulate_launch(pl, d_points, mont_pt, skip_below, stride, s, buckets, into);
   }
 };
 #endif
@@ -711,34 +714,33 @@ inline void allow_big_lds(K kernel, size_t bytes)
   if (bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// stages 4, 4b, 5 for one base set
+// stages 4 + 4b for one base set: bucket accumulation (+ large buckets) into `buckets` (pl->nbuckets XYZZ, internal encoding).
+// `into`: the array holds the sums of an earlier segment of the same scalar vector (same geometry) and is continued;
+// otherwise every bucket is written (empty ones as the identity).
 template <class C>
-eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof, int ticket_slot = 0)
+eIcicleError msm_accumulate_stage(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, bool into, MsmProfile* prof)
 {
   typedef typename C::X X;
-  const MsmGeom& g = pl->g;
-  WsScoped<X> buckets, item_partials;
-  HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
+  WsScoped<X> item_partials;
   if (prof) (void)hipEventRecord(prof->ev[1], s);
-  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets.p);
-#ifdef ICICLE_SNARK_EXPERIMENTS
-  // what a stage costs the prove, measured by running it twice (scratch/marginal_cost.sh): ISNARK_DUP bit 0 / 1 the
-  // first reduction level of G1 / G2 sets, bit 2 / 3 the G1 / G2 accumulations, bit 6 the large-bucket kernel (all idempotent)
-  static const int dupmask = getenv("ISNARK_DUP") ? atoi(getenv("ISNARK_DUP")) : 0;
-  if (dupmask & (sizeof(X) > 128 ? 8 : 4)) AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets.p);
-#endif
+  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets, into ? 1 : 0);
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
   const size_t lds_l = lb * sizeof(typename Lazy<C>::type::X); // 36 KiB
   HIP_TRY(item_partials.alloc(pl->item_cap, s), ICICLE_ALLOCATION_FAILED);
   hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lds_l, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
-#ifdef ICICLE_SNARK_EXPERIMENTS
-  if (dupmask & 64) hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lds_l, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
-#endif
-  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lds_l, s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, buckets.p);
+  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lds_l, s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, into ? 1 : 0, buckets);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
-  item_partials.release();
+  return ICICLE_SUCCESS;
+}
+
+// stage 5 for one base set: the bucket array → partial sums for the host tail (geometry and tickets of `pl`)
+template <class C>
+eIcicleError msm_reduce_stage(const SortPlan* pl, hipStream_t s, const typename C::X* buckets, typename C::X* d_partials, int ticket_slot = 0)
+{
+  typedef typename C::X X;
+  const MsmGeom& g = pl->g;
   typedef typename Lazy<C>::type::X LX;
   WsScoped<uint32_t> own_tickets;
   uint32_t* tickets = nullptr;
@@ -763,10 +765,7 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
     }
     const size_t lds_z = (size_t)ZR_M * sizeof(LX);
     allow_big_lds(msm_zeta_reduce_kernel<C>, lds_z);
-    hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk1, 1), dim3(ZR_T), lds_z, s, buckets.p, n1, r1.p, (uint32_t*)nullptr, 0, (X*)nullptr);
-#ifdef ICICLE_SNARK_EXPERIMENTS
-    if (dupmask & (sizeof(X) > 128 ? 2 : 1)) hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk1, 1), dim3(ZR_T), lds_z, s, buckets.p, n1, r1.p, (uint32_t*)nullptr, 0, (X*)nullptr);
-#endif
+    hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk1, 1), dim3(ZR_T), lds_z, s, buckets, n1, r1.p, (uint32_t*)nullptr, 0, (X*)nullptr);
     hipLaunchKernelGGL((msm_zeta_reduce_kernel<C>), dim3(nblk2, ZR_OUT), dim3(ZR_T), lds_z, s, r1.p, nblk1, r2.p, tickets, nbits, d_partials);
     ICICLE_TRY(check_launch("msm_zeta_reduce"));
     return ICICLE_SUCCESS;
@@ -785,9 +784,19 @@ eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, 
   }
   const size_t lds_r = (size_t)rs.rblock * sizeof(LX);
   allow_big_lds(msm_bucket_reduce_kernel<C>, lds_r);
-  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets.p, g.NBb, rs.k_log, d_partials, raw.p, tickets);
+  hipLaunchKernelGGL((msm_bucket_reduce_kernel<C>), dim3(rs.bpw, g.Wb), dim3(rs.rblock), lds_r, s, buckets, g.NBb, rs.k_log, d_partials, raw.p, tickets);
   ICICLE_TRY(check_launch("msm_bucket_reduce"));
   return ICICLE_SUCCESS;
+}
+
+// stages 4, 4b, 5 for one base set
+template <class C>
+eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof, int ticket_slot = 0)
+{
+  WsScoped<typename C::X> buckets;
+  HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
+  ICICLE_TRY(msm_accumulate_stage<C>(pl, d_points, mont_pt, skip_below, stride, s, buckets.p, false, prof));
+  return msm_reduce_stage<C>(pl, s, buckets.p, d_partials, ticket_slot);
 }
 
 // host tail, table mode: part = [T | S_0 … S_{t−1}] of msm_zeta_reduce_kernel;  Σ_b (b+1)·B_b = T + Σ_j 2^j·S_j (Horner from the top bit)

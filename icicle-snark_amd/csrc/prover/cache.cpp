@@ -42,9 +42,8 @@ ZKeyCache::~ZKeyCache()
     if (ev_witness) (void)hipEventDestroy(ev_witness);
     if (ev_sort) (void)hipEventDestroy(ev_sort);
     if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
-    if (ev_g2done) (void)hipEventDestroy(ev_g2done);
-    if (ev_g4done) (void)hipEventDestroy(ev_g4done);
-    if (ev_g5done) (void)hipEventDestroy(ev_g5done);
+    for (hipEvent_t e : {ev_head_in, ev_head_sorted, ev_head_c, ev_t_head_end, ev_t_witness})
+      if (e) (void)hipEventDestroy(e);
     for (auto e : ev)
       if (e) (void)hipEventDestroy(e);
     for (auto e : ev_done)
@@ -76,9 +75,9 @@ G2::P g2_from_mont_affine(const uint8_t* p)
 // their own pair of pinned buffers and enqueue the DMAs on their own streams, so page faults / memcpy of one chunk
 // overlap the DMA of the others.  `lanes`: streams to enqueue the DMAs on (the per-prove witness upload passes the
 // prover's own streams, idle at that point); nullptr: short-lived streams of the call (cold path).
-int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in, int n_lanes)
+int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in, int n_lanes, StagedProgress* progress)
 {
-  const hipError_t e = staged_copy(device_id, jobs.data(), jobs.size(), true, lanes_in, n_lanes, /*own_temp_streams=*/lanes_in == nullptr);
+  const hipError_t e = staged_copy(device_id, jobs.data(), jobs.size(), true, lanes_in, n_lanes, /*own_temp_streams=*/lanes_in == nullptr, progress);
   if (e != hipSuccess) return fail((int)ICICLE_COPY_FAILED, "host to device upload: %s", hipGetErrorString(e));
   return 0;
 }
@@ -300,9 +299,11 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
-  P_HIP(hipEventCreateWithFlags(&z->ev_g2done, hipEventDisableTiming));
-  P_HIP(hipEventCreateWithFlags(&z->ev_g4done, hipEventDisableTiming));
-  P_HIP(hipEventCreateWithFlags(&z->ev_g5done, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_head_in, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_head_sorted, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_head_c, hipEventDisableTiming));
+  P_HIP(hipEventCreate(&z->ev_t_head_end));
+  P_HIP(hipEventCreate(&z->ev_t_witness));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
   for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   lap("work buffers, streams, events");

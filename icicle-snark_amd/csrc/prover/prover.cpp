@@ -311,10 +311,11 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   };
 
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
-  hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3;
+  hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3, gq = z->s_qap;
   double h2d_host_ms = 0;
-  bool pinned_src = false;
-  SortPlan plan_w, plan_h;
+  SortPlan plan_w, plan_head, plan_h; // witness (all of it, or its tail when the head is sorted apart), head of the witness, H scalars
+  // bucket arrays of the four witness MSMs (A, B1, B2, C): owned here because a head and a tail accumulation share them
+  WsScoped<uint8_t> bk[4];
   // Declared after the plans, so it runs before their destructors, and before the first enqueue of this call: on an error
   // return the kernels already enqueued may still read the plans' workspace (which ~SortPlan hands back to the arena) or
   // the caller's pinned witness buffer — drain the six streams first.
@@ -328,6 +329,48 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
         if (st) (void)hipStreamSynchronize(st);
     }
   } drain{z};
+  const uint32_t wlo = z->A.lo, wlen = z->A.len(), skip = npub + 1;
+  const uint32_t early_max = EARLY_MAX_DEFAULT;
+  // Witness MSMs of small circuits (domain up to 2^19) leave the GPU far from full: they start right
+  // after the witness sort instead of waiting for the QAP (200 k constraints: 3.71 → 3.51 ms, 400 k: 6.69 → 6.24 ms; the QAP
+  // itself slows down — 1.1 → 3.9 ms at 400 k — which is why the large ones are held back: 800 k: 9.87 → 10.27 ms).
+  const bool early = wlen <= early_max && n <= early_max; // shards of a large circuit keep the full-size inverse transform: neutral there
+  MsmProfile* prof[5]; // A, B1, B2, C, H — this entry's own slots (published to the device's ring at the end by the lead shard)
+  for (int k = 0; k < 5; k++) {
+    prof[k] = &z->prof[k];
+    msm_profile_own_init(prof[k]);
+  }
+  // (tab > 1 = table mode with exactly this digit width: a key adapted to its witnesses, cache.cpp)
+  const bool adapted_w = z->geom_w.tab && z->geom_w.c != z->geom_w_default_c;
+  const uint32_t skip_below = skip > wlo ? skip - wlo : 0; // C ignores witness[0..=n_public]
+  const Shard* sh4[4] = {&z->A, &z->B1, &z->B2, &z->C};
+  hipStream_t st4[4] = {g1, z->s_g4, g2, z->s_g5}; // A, B1, B2, C: separate streams, so that one MSM's latency-bound reduction overlaps another's accumulation
+  // accumulation of witness[first … first + pl.L) into the bucket array of MSM k (0 A, 1 B1, 2 B2, 3 C) on stream st: the sort
+  // entries index scalars relative to `first`, so the table pointer moves with it (C's bases start at wire n_public + 1)
+  auto accumulate = [&](int k, const SortPlan& pl, uint32_t first, bool into, hipStream_t st, MsmProfile* p) -> int {
+    const size_t esz = k == 2 ? 128 : 64;
+    uint32_t sb = 0;
+    size_t base_off = first;
+    if (k == 3) {
+      if (first >= skip_below) base_off = first - skip_below;
+      else {
+        base_off = 0;
+        sb = skip_below - first;
+      }
+    }
+    const void* pts = (const uint8_t*)sh4[k]->d_points + base_off * esz;
+    if (k == 2) P_ICICLE(msm_g2_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len()));
+    else P_ICICLE(msm_g1_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len()));
+    return 0;
+  };
+
+  // ---- the witness arrives.  HEAD / TAIL: over PCIe the witness takes 1.4 ms (host buffer) to 2.7 ms (file) at 1.6 M constraints
+  // and nothing of construct_r1cs can start before all of it is there (the spmv reads arbitrary wires) — but the witness MSMs are
+  // sums over wires: the first `head` wires are sorted and accumulated into the four bucket arrays while the rest is still on
+  // its way, and the tail's accumulation continues those buckets after the front end (msm_plan.h: `into`).  The GPU, idle during
+  // the upload before, takes ≈ a fifth of the witness accumulations off the critical path.
+  uint32_t head = 0;
+  bool pinned_src = false;
   if (wtns) {
     Wtns w;
     if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
@@ -338,57 +381,132 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     z->witness_resident = false;
     z->dist_ready = z->dist_stage2_done = false;
     z->witness_event_set = false;
-    // witness → device through the parallel pinned-staging uploader of the cold path (three workers on prover streams, 2 MB
-    // chunks): a single memcpy into one pinned buffer + one DMA took 4 ms for the 51 MB of benchmark/1600k
+    // (ICICLE_SNARK_HEAD_PCT: the head's share in percent, 0 = off; ICICLE_SNARK_HEAD_MIN: smallest witness that is split —
+    //  the tests set it to 0 so that circuits the oracle proves in seconds take the path)
+    static const int head_pct_env = getenv("ICICLE_SNARK_HEAD_PCT") ? atoi(getenv("ICICLE_SNARK_HEAD_PCT")) : -1;
+    static const long head_min_env = getenv("ICICLE_SNARK_HEAD_MIN") ? atol(getenv("ICICLE_SNARK_HEAD_MIN")) : -1;
+    const uint32_t head_min = head_min_env >= 0 ? (uint32_t)head_min_env : (1u << 20);
+    if (z->geom_w.tab && (!early || head_min_env >= 0) && z->shard_count == 1 && wlo == 0 && wlen == nv && nv >= head_min) {
+      const double frac = head_pct_env >= 0 ? head_pct_env / 100.0 : z->head_frac;
+      const uint32_t unit = (uint32_t)(STAGED_CHUNK_BYTES / 32); // whole upload chunks
+      head = (uint32_t)((double)nv * frac / unit + 0.5) * unit;
+      if (head < unit || head >= nv || nv - head < unit) head = 0;
+    }
     const auto tu = std::chrono::steady_clock::now();
-    // three lanes: 51 MB in 1.4 ms, stable; with six, one upload in four stalled for ~15 ms on the GPU box (host threads
-    // of this call, the MSM tails and the runtime's own compete for the container's CPU quota)
-    const hipStream_t lanes[3] = {z->s_qap, z->s_g2, z->s_g3};
-    const int n_lanes = 3;
-    if (is_pinned_host(w.values, z->device_id)) {
-      // the caller's buffer is pinned (hipHostMalloc / hipHostRegister) and mapped for this device: one DMA straight from it on
-      // g1, in stream order with everything that waits for ev_witness — no staging copy, no host wait (51 MB: 0.9 instead of 1.35 ms)
-      P_HIP(hipEventRecord(z->ev[0], g1));
-      P_HIP(hipMemcpyAsync(z->d_witness, w.values, (size_t)nv * 32, hipMemcpyHostToDevice, g1));
-      pinned_src = true;
-    } else if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, n_lanes)) return rc;
+    pinned_src = is_pinned_host(w.values, z->device_id);
+    P_HIP(hipEventRecord(z->ev[0], gq));
+    if (head) {
+      // the head's kernels go to g2 (sort, B2), g1 (A, then C) and g4 (B1); the staging lanes of the upload are the three
+      // streams with nothing to do before the whole witness is there (QAP, H sort, C's own) — no extra stream, no extra
+      // hardware queue
+      const hipStream_t lanes[3] = {gq, g3, z->s_g5};
+      StagedProgress prog;
+      prog.head_bytes = (size_t)head * 32;
+      int up_rc = 0;
+      std::thread uploader;
+      const void* hint_base;
+      size_t hint_len;
+      int hint_fd;
+      staged_copy_file_hint_get(&hint_base, &hint_len, &hint_fd);
+      if (pinned_src) {
+        // the caller's buffer is pinned: two DMAs straight from it on the QAP stream, an event between them
+        P_HIP(hipMemcpyAsync(z->d_witness, w.values, (size_t)head * 32, hipMemcpyHostToDevice, gq));
+        P_HIP(hipEventRecord(z->ev_head_in, gq));
+        P_HIP(hipMemcpyAsync(z->d_witness + head, (const uint8_t*)w.values + (size_t)head * 32, (size_t)(nv - head) * 32, hipMemcpyHostToDevice, gq));
+        P_HIP(hipStreamWaitEvent(g2, z->ev_head_in, 0));
+      } else {
+        uploader = std::thread([&] {
+          staged_copy_file_hint(hint_base, hint_len, hint_fd);
+          up_rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, 3, &prog);
+          staged_copy_file_hint(nullptr, 0, -1);
+          prog.done.store(true, std::memory_order_release);
+        });
+        // (joined on every path below; an exception cannot occur between here and there)
+        for (;;) {
+          const int tot = prog.lanes_total.load(std::memory_order_acquire);
+          if (tot >= 0 && prog.lanes_reported.load(std::memory_order_acquire) >= tot) break;
+          if (prog.done.load(std::memory_order_acquire)) break;
+          std::this_thread::yield();
+        }
+        const int tot = prog.lanes_total.load(std::memory_order_acquire);
+        for (int t = 0; t < tot; t++)
+          if (prog.ev[t] && hipStreamWaitEvent(g2, prog.ev[t], 0) != hipSuccess) up_rc = up_rc ? up_rc : fail((int)ICICLE_UNKNOWN_ERROR, "hipStreamWaitEvent");
+      }
+      // head: digit sort on g2, then the four accumulations (zero-initialising their bucket arrays)
+      int hrc = 0;
+      auto enqueue_head = [&]() -> int {
+        P_ICICLE(msm_sort_run(z->d_witness, head, 0, 0, 0, g2, &plan_head, z->geom_w.c, 0, 1, adapted_w ? (uint64_t)((double)z->witness_entries * head / nv) + 1 : 0));
+        if (plan_head.g.tab != z->geom_w.tab || plan_head.g.c != z->geom_w.c || plan_head.nbuckets != z->geom_w.NB)
+          return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the sort of the witness head");
+        for (int k = 0; k < 4; k++) P_HIP(bk[k].alloc(msm_bucket_bytes(&plan_head, k == 2), st4[k]));
+        P_HIP(hipEventRecord(z->ev_head_sorted, g2));
+        if (int rc = accumulate(2, plan_head, 0, false, g2, nullptr)) return rc;
+        (void)hipEventRecord(z->ev_t_head_end, g2); // (timing: where the head's longest chain ends relative to the upload)
+        P_HIP(hipStreamWaitEvent(g1, z->ev_head_sorted, 0));
+        if (int rc = accumulate(0, plan_head, 0, false, g1, nullptr)) return rc;
+        if (int rc = accumulate(3, plan_head, 0, false, g1, nullptr)) return rc; // C's head behind A's on g1: C's own stream carries a staging lane
+        P_HIP(hipEventRecord(z->ev_head_c, g1));
+        P_HIP(hipStreamWaitEvent(z->s_g4, z->ev_head_sorted, 0));
+        if (int rc = accumulate(1, plan_head, 0, false, z->s_g4, nullptr)) return rc;
+        return 0;
+      };
+      if (!up_rc) hrc = enqueue_head();
+      if (uploader.joinable()) uploader.join();
+      if (up_rc) return up_rc;
+      if (hrc) return hrc;
+      if (pinned_src) P_HIP(hipEventRecord(z->ev_witness, gq));
+    } else if (pinned_src) {
+      // the caller's buffer is pinned (hipHostMalloc / hipHostRegister) and mapped for this device: one DMA straight from it,
+      // in stream order with everything that waits for ev_witness — no staging copy, no host wait (51 MB: 0.9 instead of 1.35 ms)
+      P_HIP(hipMemcpyAsync(z->d_witness, w.values, (size_t)nv * 32, hipMemcpyHostToDevice, gq));
+      P_HIP(hipEventRecord(z->ev_witness, gq));
+    } else {
+      // witness → device through the parallel pinned-staging uploader of the cold path (three workers on prover streams, 2 MB
+      // chunks): a single memcpy into one pinned buffer + one DMA took 4 ms for the 51 MB of benchmark/1600k.
+      // three lanes: 51 MB in 1.4 ms, stable; with six, one upload in four stalled for ~15 ms on the GPU box (host threads
+      // of this call, the MSM tails and the runtime's own compete for the container's CPU quota)
+      const hipStream_t lanes[3] = {gq, g2, g3};
+      if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, 3)) return rc;
+    }
     h2d_host_ms = ms_since(tu);
-  }
-  if (!pinned_src) P_HIP(hipEventRecord(z->ev[0], g1));
+    if (!pinned_src) P_HIP(hipEventRecord(z->ev_witness, gq)); // (the staged upload has returned: every byte is there)
+    z->witness_event_set = true;
+  } else
+    P_HIP(hipEventRecord(z->ev[0], gq));
   z->witness_resident = true;
-  // group prove: ev_witness was recorded behind the witness all-gather on the exchange's stream (multi.cpp)
-  if (!z->witness_event_set) P_HIP(hipEventRecord(z->ev_witness, g1));
+  // resident witness: nothing to wait for.  Group prove: ev_witness was recorded behind the witness all-gather on the exchange's
+  // stream (multi.cpp) and witness_event_set says so
+  if (!z->witness_event_set) P_HIP(hipEventRecord(z->ev_witness, gq));
   z->witness_event_set = false;
-  P_HIP(hipEventRecord(z->ev[1], g1));
+  (void)hipEventRecord(z->ev_t_witness, gq);
 
-  // ---- stream g2: ONE digit sort of witness[wlo:whi] (shared by A, B1, B2, C), then the G2 bucket stages
-  P_HIP(hipStreamWaitEvent(g2, z->ev_witness, 0));
-  const uint32_t wlo = z->A.lo, wlen = z->A.len(), skip = npub + 1;
-  MsmProfile* prof[5]; // A, B1, B2, C, H — this entry's own slots (published to the device's ring at the end by the lead shard)
-  for (int k = 0; k < 5; k++) {
-    prof[k] = &z->prof[k];
-    msm_profile_own_init(prof[k]);
-  }
-  // the witness sort is timed with the profile of the G2 MSM that follows it on g2
+  // ---- ONE digit sort of the witness range (shared by A, B1, B2, C) — of its tail when the head was sorted above — on g2
+  // without a head (the G2 bucket stages follow it there) and on g3 with one (g2 still carries B2's head accumulation)
+  hipStream_t gs = head ? g3 : g2;
+  P_HIP(hipStreamWaitEvent(gs, z->ev_witness, 0));
+  // the witness sort is timed with the profile of the G2 MSM
   MsmProfile* psort = prof[2];
-  (void)hipEventRecord(psort->ev[0], g2);
-  // (tab > 1 = table mode with exactly this digit width: a key adapted to its witnesses, cache.cpp)
-  const bool adapted_w = z->geom_w.tab && z->geom_w.c != z->geom_w_default_c;
-#ifdef ICICLE_SNARK_EXPERIMENTS
-  static const int dupmask_w = getenv("ISNARK_DUP") ? atoi(getenv("ISNARK_DUP")) : 0;
-  SortPlan plan_w_dup;
-  if (dupmask_w & 32) P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w_dup, adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, adapted_w ? z->witness_entries : 0));
-#endif
-  P_ICICLE(msm_sort_run(z->d_witness + wlo, wlen, 0, 0, 0, g2, &plan_w, adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, adapted_w ? z->witness_entries : 0));
-  if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
-  (void)hipEventRecord(psort->ev[4], g2); // end of the witness digit sort (roofline.scatter)
+  (void)hipEventRecord(psort->ev[0], gs);
+  {
+    const uint32_t tail_len = wlen - head;
+    const uint64_t hint = adapted_w ? (uint64_t)((double)z->witness_entries * tail_len / wlen) + 1 : 0;
+    P_ICICLE(msm_sort_run(z->d_witness + wlo + head, tail_len, 0, 0, 0, gs, &plan_w, head || adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, hint));
+  }
+  if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c || (head && plan_w.nbuckets != plan_head.nbuckets))
+    return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
+  (void)hipEventRecord(psort->ev[4], gs); // end of the witness digit sort (roofline.scatter)
   psort->has_sort_end = true;
-  P_HIP(hipEventRecord(z->ev_sort, g2));
-  // entry count of this sort (offset + count of the last bucket), read at the end of the prove: it steers the digit width of
+  P_HIP(hipEventRecord(z->ev_sort, gs));
+  // entry counts of the sorts (offset + count of the last bucket), read at the end of the prove: they steer the digit width of
   // the key's witness tables (cache.cpp: rebuild_witness_tables)
+  for (int k = 0; k < 4; k++) z->h_stats[k] = 0;
   if (plan_w.nbuckets) {
-    P_HIP(hipMemcpyAsync(&z->h_stats[0], plan_w.offsets + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, g2));
-    P_HIP(hipMemcpyAsync(&z->h_stats[1], plan_w.counts + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, g2));
+    P_HIP(hipMemcpyAsync(&z->h_stats[0], plan_w.offsets + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
+    P_HIP(hipMemcpyAsync(&z->h_stats[1], plan_w.counts + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
+    if (head) {
+      P_HIP(hipMemcpyAsync(&z->h_stats[2], plan_head.offsets + plan_head.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
+      P_HIP(hipMemcpyAsync(&z->h_stats[3], plan_head.counts + plan_head.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
+    }
   }
   mark("wsort");
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
@@ -397,8 +515,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   uint8_t* DP = z->d_partials;
 
   // ---- stream gq: construct_r1cs (src/proof_helper.rs:31-170) on the device
-  hipStream_t gq = z->s_qap;
   P_HIP(hipStreamWaitEvent(gq, z->ev_witness, 0));
+  P_HIP(hipEventRecord(z->ev[1], gq));
   // the distributed stages left this rank's Z rows in d_fold — honoured only for the witness they were computed from (no new
   // witness in this call) and only once the caller has confirmed that exchange 2 delivered (groth16_dist_exchange_done)
   const bool dist_ready = !wtns && z->dist_ready && z->H.stride > 1;
@@ -452,33 +570,33 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   }
   P_HIP(hipEventRecord(z->ev[2], gq));
   mark("qap");
-  // Witness MSMs of small circuits (domain up to 2^19) leave the GPU far from full: they start right
-  // after the witness sort instead of waiting for the QAP (200 k constraints: 3.71 → 3.51 ms, 400 k: 6.69 → 6.24 ms; the QAP
-  // itself slows down — 1.1 → 3.9 ms at 400 k — which is why the large ones are held back: 800 k: 9.87 → 10.27 ms).
-  const uint32_t early_max = EARLY_MAX_DEFAULT;
-  const bool early = wlen <= early_max && n <= early_max; // shards of a large circuit keep the full-size inverse transform: neutral there
-  if (!early) P_HIP(hipStreamWaitEvent(g1, z->ev[2], 0));
 
-  // ---- stream g2: G2 bucket stages.  Held back until the QAP front end is done: the G2 accumulation
-  // fills every CU with ~4 ms workgroups, and the NTT passes of the (longer) g1 chain measured 8× slower
-  // when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
-  if (!early) P_HIP(hipStreamWaitEvent(g2, z->ev[2], 0));
-  fill(prof[2], plan_w, 1);
-  P_ICICLE(msm_g2_partials(&plan_w, z->B2.d_points, 2, 0, g2, DP + 2 * PARTIALS_STRIDE, prof[2], z->B2.len(), 3)); // commitment_b — src/proof_helper.rs:206
-  (void)hipEventRecord(prof[2]->ev[3], g2);
-  prof[2]->valid = true;
-  P_HIP(hipEventRecord(z->ev_g2done, g2));
+  // ---- groth16_commitments — src/proof_helper.rs:198-206.  A, B1, B2, C share the witness sort and run on four streams.
+  // Held back until the QAP front end is done (large circuits): the accumulations fill every CU with milliseconds-long
+  // workgroups, and the NTT passes measured 8× slower when they had to wait for those to retire (rocprof: 2.9 ms vs 0.35 ms per pass).
+  if (!head)
+    for (int k = 0; k < 4; k++) P_HIP(bk[k].alloc(msm_bucket_bytes(&plan_w, k == 2), st4[k]));
+  const int slot4[4] = {0, 1, 3, 2}; // ticket slots of the plan: A 0, B1 1, B2 3, C 2
+  auto bucket_stages = [&](int k) -> int {
+    MsmProfile* p = prof[k];
+    hipStream_t st = st4[k];
+    fill(p, plan_w, k == 2);
+    P_HIP(hipStreamWaitEvent(st, z->ev_sort, 0));
+    if (!early) P_HIP(hipStreamWaitEvent(st, z->ev[2], 0));
+    if (head && k == 3) P_HIP(hipStreamWaitEvent(st, z->ev_head_c, 0)); // C's head was accumulated on g1
+    if (p != psort) (void)hipEventRecord(p->ev[0], st);
+    if (int rc = accumulate(k, plan_w, wlo ? 0 : head, head != 0, st, p)) return rc;
+    P_ICICLE(k == 2 ? msm_g2_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]) : msm_g1_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]));
+    (void)hipEventRecord(p->ev[3], st);
+    p->valid = true;
+    return 0;
+  };
+  if (int rc = bucket_stages(2)) return rc; // commitment_b (G2) — src/proof_helper.rs:206: the longest chain first
   mark("g2");
 
   // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
   P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
   (void)hipEventRecord(prof[4]->ev[0], g3);
-#ifdef ICICLE_SNARK_EXPERIMENTS
-  // (scratch/marginal_cost.sh) ISNARK_DUP bit 4: H's digit sort twice, bit 5: the witness digit sort twice
-  static const int dupmask = getenv("ISNARK_DUP") ? atoi(getenv("ISNARK_DUP")) : 0;
-  SortPlan plan_h_dup;
-  if (dupmask & 16) P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h_dup, z->geom_h.tab));
-#endif
   P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab));
   if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
   (void)hipEventRecord(prof[4]->ev[4], g3);
@@ -486,36 +604,19 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   P_HIP(hipEventRecord(z->ev_sort_h, g3));
   mark("hsort");
 
-  // ---- groth16_commitments — src/proof_helper.rs:198-205.  A, B1, C share the witness sort and run on three
-  // streams (g1, g4, g5) so that the latency-bound bucket reduction of one overlaps the accumulation of the
-  // others; H follows A on g1.
-  const uint32_t skip_below = skip > wlo ? skip - wlo : 0; // C ignores witness[0..=n_public]
-  const int order[3] = {0, 1, 3};
-  const Shard* sh3[3] = {&z->A, &z->B1, &z->C};
-  hipStream_t st3[3] = {g1, z->s_g4, z->s_g5};
-  for (int k = 0; k < 3; k++) {
-    MsmProfile* p = prof[order[k]];
-    const SortPlan& pl = plan_w;
-    fill(p, pl, 0);
-    P_HIP(hipStreamWaitEvent(st3[k], z->ev_sort, 0));
-    if (k && !early) P_HIP(hipStreamWaitEvent(st3[k], z->ev[2], 0)); // not before the QAP front end is done (see g2)
-    if (p != psort) (void)hipEventRecord(p->ev[0], st3[k]);
-    P_ICICLE(msm_g1_partials(&pl, sh3[k]->d_points, 2, k == 2 ? skip_below : 0, st3[k], DP + order[k] * PARTIALS_STRIDE, p, sh3[k]->len(), k)); // ticket slots 0-2 of the plan (B2: 3)
-    (void)hipEventRecord(p->ev[3], st3[k]);
-    p->valid = true;
-  }
-  P_HIP(hipEventRecord(z->ev_g4done, z->s_g4));
-  P_HIP(hipEventRecord(z->ev_g5done, z->s_g5));
+  for (int k : {0, 1, 3})
+    if (int rc = bucket_stages(k)) return rc;
   mark("abc");
+
   // H: behind one of the witness MSMs for the large circuits (measured at 1.6 M constraints: five concurrent accumulations
   // are slower than four followed by one, 17.7 vs 17.4 ms) — behind B1, whose accumulation is the first of the three G1
   // ones to start and to finish (behind A: +0.1 ms, behind C: +0.4 ms); on g3 right behind its own sort for the small ones and for
   // multi-GPU shards, where the GPU is far from full and only the length of the chains counts (200 k: 4.3 → 3.9 ms).  Letting H
   // wait only for B1's ACCUMULATION kernel instead of B1's whole chain fills a ≈ 1 ms gap in the timeline and still makes the
   // prove slower (16.35–16.48 against 16.0–16.2 ms; DESIGN.md §4 lists this and the other schedules that were measured).
-  const int h_behind = 1;
+  const int h_behind = 1; // B1
   const bool h_chain = z->H.len() > (1u << 19);
-  hipStream_t gh = h_chain ? st3[h_behind] : g3;
+  hipStream_t gh = h_chain ? st4[h_behind] : g3;
   if (h_chain) P_HIP(hipStreamWaitEvent(gh, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
@@ -528,11 +629,11 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   uint32_t Ww = 0, bw1 = 0, Wb = 0, bw2 = 0, Wh = 0, bh = 0;
   const size_t by1 = msm_partials_bytes(&plan_w, false, &Ww, &bw1), by2 = msm_partials_bytes(&plan_w, true, &Wb, &bw2), byh = msm_partials_bytes(&plan_h, false, &Wh, &bh);
   const size_t sizes[5] = {by1, by1, by2, by1, byh};
-  hipStream_t st5[5] = {st3[0], st3[1], g2, st3[2], gh};
+  hipStream_t st5[5] = {st4[0], st4[1], st4[2], st4[3], gh};
   if (h_chain) {
     // the copy of the MSM in front of H must not wait for H (same stream): its partials were complete at its ev[3], copy them on g3 instead
-    P_HIP(hipStreamWaitEvent(g3, prof[order[h_behind]]->ev[3], 0));
-    st5[order[h_behind]] = g3;
+    P_HIP(hipStreamWaitEvent(g3, prof[h_behind]->ev[3], 0));
+    st5[h_behind] = g3;
   }
   for (int k = 0; k < 5; k++) {
     P_HIP(hipMemcpyAsync(z->h_partials + k * PARTIALS_STRIDE, DP + k * PARTIALS_STRIDE, sizes[k], hipMemcpyDeviceToHost, st5[k]));
@@ -580,17 +681,15 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // streams are drained except for ev[3] on g1, which waits for the five of them: one synchronisation instead of six
   P_HIP(hipStreamSynchronize(g1));
   drain.armed = false;
-  z->witness_entries = (uint64_t)z->h_stats[0] + z->h_stats[1]; // the copies on g2 completed before B2's ev_done
+  // (the stats copies sit on g2 / g3 in front of work whose ev_done a tail thread has waited for)
+  z->witness_entries = (uint64_t)z->h_stats[0] + z->h_stats[1] + z->h_stats[2] + z->h_stats[3];
   z->proves_since_rebuild++;
   msm_sort_release(&plan_w);
+  msm_sort_release(&plan_head);
   msm_sort_release(&plan_h);
   // HIP-event profile of the five MSMs → the ring icicle_snark_msm_profile reads (bench.py: back = 4 … 0 = A, B1, B2, C, H); in
   // a device group only the lead shard publishes
   if (z->shard_rank == 0 || !z->in_group) msm_profile_publish(z->prof, 5);
-#ifdef ICICLE_SNARK_EXPERIMENTS
-  if (dupmask & 16) msm_sort_release(&plan_h_dup);
-  if (dupmask_w & 32) msm_sort_release(&plan_w_dup);
-#endif
   {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);

@@ -118,8 +118,11 @@ struct ZKeyCache {
   uint8_t* d_partials = nullptr; // 5 × PARTIALS_STRIDE: per-window partial sums of the five MSMs
   uint8_t* h_partials = nullptr; // pinned mirror
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
-  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev_g2done = nullptr, ev_g4done = nullptr, ev_g5done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr},
-             ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // head / tail of a witness on its way in (prover.cpp): head resident (pinned source), head sorted, C's head accumulated;
+  // with timing: end of the head's longest chain, end of the upload
+  hipEvent_t ev_head_in = nullptr, ev_head_sorted = nullptr, ev_head_c = nullptr, ev_t_head_end = nullptr, ev_t_witness = nullptr;
+  double head_frac = 0.20; // share of the witness that is sorted and accumulated while the rest is still being uploaded
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
   bool witness_event_set = false; // ev_witness was already recorded for the resident witness (behind a device-side all-gather)
@@ -140,7 +143,7 @@ int rebuild_witness_tables(ZKeyCache* z, int c_new);
 // CacheManager::compute — src/cache.rs:117-241
 int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out);
 typedef CopyJob UploadJob;
-int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in = nullptr, int n_lanes = 0);
+int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in = nullptr, int n_lanes = 0, StagedProgress* progress = nullptr);
 
 // ---- blinding and proof assembly (assemble.cpp)
 // blinding terms that do not depend on the commitments: δ1·r, δ1·s, δ2·s, δ1·r·s (src/proof_helper.rs:280-283);

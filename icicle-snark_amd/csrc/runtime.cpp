@@ -114,11 +114,12 @@ static int identify(const void* p)
 bool is_tracked_device_ptr(const void* p) { return identify(p) >= 0; }
 
 // ---- pageable-memory copy engine (see common.h) ------------------------------------------------------------------
-constexpr size_t STAGED_CHUNK = 2u << 20;
+constexpr size_t STAGED_CHUNK = STAGED_CHUNK_BYTES;
 struct StagedPool { // pinned staging, events and the lane stream of ONE device (an event only records on a stream of the device
   std::mutex mu;     // it was created on; one pool and one lock per device also lets the prover threads of several GPUs upload at once)
   uint8_t* pinned = nullptr;
   hipEvent_t events[STAGED_LANES][2] = {};
+  hipEvent_t head_ev[STAGED_LANES] = {}; // StagedProgress: behind a lane's last chunk of the head
   std::vector<hipStream_t> lanes; // persistent lane stream(s)
 };
 constexpr int STAGED_DEVICES = 16;
@@ -157,7 +158,7 @@ void staged_copy_file_hint_get(const void** base, size_t* len, int* fd)
   *fd = t_file_fd;
 }
 
-hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes_in, int n_lanes, bool own_temp_streams)
+hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes_in, int n_lanes, bool own_temp_streams, StagedProgress* progress)
 {
   const uint8_t* const file_base = t_file_base;
   const size_t file_len = t_file_len;
@@ -172,6 +173,8 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
     for (int t = 0; t < STAGED_LANES; t++)
       for (int k = 0; k < 2; k++)
         if ((e0 = hipEventCreateWithFlags(&P.events[t][k], hipEventDisableTiming)) != hipSuccess) return e0;
+    for (int t = 0; t < STAGED_LANES; t++)
+      if ((e0 = hipEventCreateWithFlags(&P.head_ev[t], hipEventDisableTiming)) != hipSuccess) return e0;
   }
   // chunk size: 2 MB.  Smaller chunks for transfers of a few tens of MB (shorter pipeline fill) were measured on the 51 MB
   // witness of benchmark/1600k and are slower — 1 MB: +0.05 ms, 512 KB: +0.3 ms, 256 KB: +0.8 ms per prove (per-DMA cost);
@@ -214,7 +217,22 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
   }
   std::atomic<size_t> next{0};
   std::atomic<int> err{(int)hipSuccess};
+  // chunks of the head (StagedProgress): the first chunks of job 0
+  const size_t head_chunks = progress && to_device && njobs ? ((progress->head_bytes < jobs[0].n ? progress->head_bytes : jobs[0].n) + CH - 1) / CH : 0;
   auto worker = [&](int t) {
+    bool head_reported = progress == nullptr;
+    // behind this lane's last chunk of the head (or with nothing of it): record, then count this lane in
+    auto report_head = [&]() {
+      if (head_reported) return;
+      head_reported = true;
+      if (hipEventRecord(P.head_ev[t], streams[t]) != hipSuccess) err = (int)hipErrorUnknown;
+      progress->ev[t] = P.head_ev[t];
+      progress->lanes_reported.fetch_add(1, std::memory_order_release);
+    };
+    struct ReportOnExit {
+      decltype(report_head)& f;
+      ~ReportOnExit() { f(); }
+    } on_exit{report_head};
     if (hipSetDevice(device_id) != hipSuccess) {
       err = (int)hipErrorInvalidDevice;
       return;
@@ -224,6 +242,7 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
       bool used[2] = {false, false};
       for (int k = 0;; k ^= 1) {
         const size_t i = next.fetch_add(1);
+        if (i >= head_chunks) report_head(); // chunks are handed out in order: this lane has enqueued its last chunk of the head
         if (i >= chunks.size() || err.load() != (int)hipSuccess) break;
         hipError_t e = hipSuccess;
         if (used[k]) e = hipEventSynchronize(P.events[t][k]); // the DMA that last read this buffer is done
@@ -280,6 +299,7 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
     if (e != hipSuccess) err = (int)e;
   };
   const int nt = chunks.size() < (size_t)max_lanes ? (int)chunks.size() : max_lanes;
+  if (progress) progress->lanes_total.store(nt, std::memory_order_release);
   std::vector<std::thread> th;
   for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
   if (nt > 0) worker(0);

@@ -6,6 +6,7 @@ import base64
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -428,3 +429,59 @@ def test_cache_info_sized_respects_the_callers_struct_size(gpu, cm):
     assert int.from_bytes(bytes(buf)[24:28], "little") == full.b_bases
     assert lib.groth16_cache_info_sized(cm._h, b"nokey", buf, C.c_size_t(64)) != 0
     assert bytes(buf)[28:32] == (0).to_bytes(4, "little")                # one shard: not a device group
+
+
+@pytest.mark.parametrize("pct", [35, 60])
+def test_witness_head_and_tail_accumulate_into_the_same_buckets(gpu, pct):
+    """A witness on its way in is split (csrc/prover/prover.cpp): the head is sorted and accumulated into the four bucket arrays
+    while the tail is still being uploaded, the tail's accumulation continues those buckets (`into`).  Forced here on circuits
+    the oracle proves in seconds (ICICLE_SNARK_HEAD_MIN=0; in production only witnesses of ≥ 2^20 wires are split): dense and
+    bit-heavy witnesses (large buckets with `into`), pageable buffer, file and pinned buffer, each equal to the proof of the
+    SAME witness resident on the device — the single-sort path — for the same (r, s), to the oracle's, and accepted by the
+    pairing check."""
+    code = r'''
+import ctypes as C, importlib, json, os, sys, tempfile
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+import oracle as O
+K = importlib.import_module("icicle-snark_amd"); S = importlib.import_module("icicle-snark_amd.synth")
+bench = importlib.import_module("bench")
+K.set_device("HIP", 0)
+hip = C.CDLL("libamdhip64.so")
+tmp = tempfile.mkdtemp()
+for name in ("chain", "bits"):
+    if name == "chain":
+        zkey, wtns = bench.make_inputs(K, S, 200000)
+        vk = None
+    else:
+        zkey, wtns, vk, nc = bench.make_standin_inputs(K, S, "aadhaar_standin", scale=0.22)
+    cm = K.CacheManager(); cm.load(name, zkey)
+    for rep in range(3):                                   # (the stand-in key rebuilds its tables after the first prove)
+        split = cm.prove_mem(name, wtns, 11 + rep, 5)[:2]  # pageable buffer in: head / tail
+        whole = cm.prove_mem(name, wtns, 11 + rep, 5, resident=True)[:2]
+        assert split == whole, (name, rep)
+    proof, public = O.groth16_prove(zkey, wtns, 13, 5)
+    assert json.loads(split[0]) == proof and json.loads(split[1]) == public, name
+    if vk is not None:
+        assert K.groth16_verify_json(split[0], split[1], S.vk_to_json(vk))
+    # pinned buffer in: two DMAs with an event between them
+    p = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(p), C.c_size_t(len(wtns)), 0) == 0
+    C.memmove(p, wtns, len(wtns))
+    pinned = (C.c_char * len(wtns)).from_address(p.value)
+    pj, qj = C.create_string_buffer(1 << 14), C.create_string_buffer(1 << 20)
+    rc = K.lib().groth16_prove_mem(cm._h, name.encode(), pinned, C.c_size_t(len(wtns)), (13).to_bytes(32, "little"), (5).to_bytes(32, "little"), pj, C.c_size_t(len(pj)), qj, C.c_size_t(len(qj)), None)
+    assert rc == 0 and (pj.value.decode(), qj.value.decode()) == split, name
+    # files in, files out (random r, s): same public signals, valid proof
+    zp, wp = os.path.join(tmp, name + ".zkey"), os.path.join(tmp, name + ".wtns")
+    open(zp, "wb").write(zkey); open(wp, "wb").write(wtns)
+    cm.prove_files(wp, zp, os.path.join(tmp, "proof.json"), os.path.join(tmp, "public.json"))
+    assert open(os.path.join(tmp, "public.json")).read() == split[1]
+    if vk is not None:
+        assert K.groth16_verify_json(open(os.path.join(tmp, "proof.json")).read(), split[1], S.vk_to_json(vk))
+    cm.close()
+print("HEAD_TAIL_OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, ICICLE_SNARK_HEAD_MIN="0", ICICLE_SNARK_HEAD_PCT=str(pct), ICICLE_SNARK_QUIET="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=env)
+    assert "HEAD_TAIL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
