@@ -23,9 +23,9 @@ eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int point
   return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_partials, prof, ticket_slot);
 }
 size_t msm_bucket_bytes(const SortPlan* pl, bool g2) { return (size_t)(pl->nbuckets ? pl->nbuckets : 1) * (g2 ? sizeof(G2::X) : sizeof(G1::X)); }
-eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len)
+eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len, bool resident)
 {
-  return msm_accumulate_stage<G1>(pl, (const G1::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_buckets, into, prof);
+  return msm_accumulate_stage<G1>(pl, (const G1::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_buckets, into, prof, resident);
 }
 eIcicleError msm_g1_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot)
 {

@@ -5,8 +5,8 @@
 #include "msm_impl.h"
 
 namespace isnark {
-void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, uint32_t stride, hipStream_t s, void* buckets, int into)
+void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, uint32_t stride, hipStream_t s, void* buckets, int into, bool resident)
 {
-  AccumulateLauncher<G2>::launch(pl, (const G2::A*)d_points, points_mont, skip_below, stride, s, (G2::X*)buckets, into);
+  AccumulateLauncher<G2>::launch(pl, (const G2::A*)d_points, points_mont, skip_below, stride, s, (G2::X*)buckets, into, resident);
 }
 } // namespace isnark

@@ -94,43 +94,49 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A
                                                               int into, typename C::X* buckets)
 {
   typedef typename Lazy<C>::type CL;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbuckets) return;
-  const uint32_t b = order[t]; // neighbouring lanes own buckets of (nearly) equal size
-  const uint32_t cnt = counts[b];
-  if (cnt > large_thr) return; // step 4b
-  // `into`: the bucket array already holds the sums of an earlier SEGMENT of the same scalar vector (the prover sorts and
-  // accumulates the head of a witness while its tail is still on the way over PCIe, prover.cpp) — go on from there
-  if (into && cnt == 0) return;
-  const uint32_t* idx = sorted + offsets[b];
-  typename CL::X acc = into ? CL::x_load_internal(buckets[b]) : CL::x_zero();
-  if (sizeof(typename C::A) > 64) {
-    // G2: a prefetched 128-byte point would push the kernel past 256 VGPRs (one wave per SIMD); only the index is prefetched
-    uint32_t e_nxt = cnt ? idx[0] : 0u;
-    for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t e = e_nxt;
-      if (k + 1 < cnt) e_nxt = idx[k + 1];
-      bool z;
-      const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, stride, ib, form, z);
-      if (!z) CL::x_madd(acc, p);
+  // Grid-stride over the size-ordered bucket list: with one thread per bucket (the usual launch) the loop runs once.  A launch
+  // capped at the number of workgroups the GPU holds at a time (`resident` launches, AccumulateLauncher) walks the list in
+  // strides instead — every thread takes one bucket of each size stratum, so the threads stay balanced — and, unlike a grid
+  // of several times that size, never leaves workgroups waiting in the dispatcher: a kernel whose workgroups queue there
+  // blocks its hardware pipe for the barrier packets (events!) and small kernels of every other queue on that pipe for as long
+  // as it runs (measured: the staging events of a witness upload stalled for the whole length of such a kernel, prover.cpp).
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nbuckets; t += gridDim.x * blockDim.x) {
+    const uint32_t b = order[t]; // neighbouring lanes own buckets of (nearly) equal size
+    const uint32_t cnt = counts[b];
+    if (cnt > large_thr) continue; // step 4b
+    // `into`: the bucket array already holds the sums of an earlier SEGMENT of the same scalar vector (the prover sorts and
+    // accumulates the head of a witness while its tail is still on the way over PCIe, prover.cpp) — go on from there
+    if (into && cnt == 0) continue;
+    const uint32_t* idx = sorted + offsets[b];
+    typename CL::X acc = into ? CL::x_load_internal(buckets[b]) : CL::x_zero();
+    if (sizeof(typename C::A) > 64) {
+      // G2: a prefetched 128-byte point would push the kernel past 256 VGPRs (one wave per SIMD); only the index is prefetched
+      uint32_t e_nxt = cnt ? idx[0] : 0u;
+      for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = e_nxt;
+        if (k + 1 < cnt) e_nxt = idx[k + 1];
+        bool z;
+        const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, stride, ib, form, z);
+        if (!z) CL::x_madd(acc, p);
+      }
+    } else {
+      // G1, software pipeline: the index two entries ahead and the (gathered, packed) point one entry ahead are in
+      // flight while the current mixed addition (~9 k cycles per wave) runs; without it every iteration starts with two
+      // dependent memory latencies (H accumulation alone: 4.0 → 3.0 ms)
+      uint32_t e_cur = cnt ? idx[0] : 0u, e_nxt = cnt > 1 ? idx[1] : 0u;
+      typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
+      for (uint32_t k = 0; k < cnt; k++) {
+        const typename C::A pk = pk_cur;
+        const uint32_t e = e_cur;
+        e_cur = e_nxt;
+        if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
+        if (k + 2 < cnt) e_nxt = idx[k + 2];
+        const bool z = entry_point(e, ib) < skip_below || C::aff_is_zero(pk);
+        if (!z) CL::x_madd(acc, CL::load_affine(pk, form, (e >> 31) != 0));
+      }
     }
-  } else {
-    // G1, software pipeline: the index two entries ahead and the (gathered, packed) point one entry ahead are in
-    // flight while the current mixed addition (~9 k cycles per wave) runs; without it every iteration starts with two
-    // dependent memory latencies (H accumulation alone: 4.0 → 3.0 ms)
-    uint32_t e_cur = cnt ? idx[0] : 0u, e_nxt = cnt > 1 ? idx[1] : 0u;
-    typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
-    for (uint32_t k = 0; k < cnt; k++) {
-      const typename C::A pk = pk_cur;
-      const uint32_t e = e_cur;
-      e_cur = e_nxt;
-      if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
-      if (k + 2 < cnt) e_nxt = idx[k + 2];
-      const bool z = entry_point(e, ib) < skip_below || C::aff_is_zero(pk);
-      if (!z) CL::x_madd(acc, CL::load_affine(pk, form, (e >> 31) != 0));
-    }
+    buckets[b] = CL::x_store_internal(acc);
   }
-  buckets[b] = CL::x_store_internal(acc);
 }
 
 // in-place conversion of an affine base array to the internal encoding (cold path, once per key)
@@ -662,17 +668,33 @@ eIcicleError points_to_internal_run(void* d_points, uint32_t n, int from_form, h
 // (msm_g2_acc.hip, Fq2 arithmetic inlined)
 template <class C>
 struct AccumulateLauncher {
-  static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, int into)
+  // `resident`: no more workgroups than the device holds at a time (the kernel strides over the bucket list)
+  static void launch(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, int into, bool resident = false)
   {
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((pl->nbuckets + 255) / 256), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, into, buckets);
+    unsigned grid = (pl->nbuckets + 255) / 256;
+    if (resident) {
+      static std::atomic<unsigned> cap{0};
+      unsigned c = cap.load();
+      if (!c) {
+        int per_cu = 0, dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msm_accumulate_kernel<C>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        c = (unsigned)per_cu * (unsigned)cus;
+        cap.store(c);
+      }
+      if (grid > c) grid = c;
+    }
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3(grid), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, into, buckets);
   }
 };
 #if defined(ISNARK_G2_ACC_EXTERN)
 template <>
 struct AccumulateLauncher<G2> {
-  static void launch(const SortPlan* pl, const G2::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, G2::X* buckets, int into)
+  static void launch(const SortPlan* pl, const G2::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, G2::X* buckets, int into, bool resident = false)
   {
-    isnark::msm_g2_accumulate_launch(pl, d_points, mont_pt, skip_below, stride, s, buckets, into);
+    isnark::msm_g2_accumulate_launch(pl, d_points, mont_pt, skip_below, stride, s, buckets, into, resident);
   }
 };
 #endif
@@ -718,12 +740,12 @@ inline void allow_big_lds(K kernel, size_t bytes)
 // `into`: the array holds the sums of an earlier segment of the same scalar vector (same geometry) and is continued;
 // otherwise every bucket is written (empty ones as the identity).
 template <class C>
-eIcicleError msm_accumulate_stage(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, bool into, MsmProfile* prof)
+eIcicleError msm_accumulate_stage(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, bool into, MsmProfile* prof, bool resident = false)
 {
   typedef typename C::X X;
   WsScoped<X> item_partials;
   if (prof) (void)hipEventRecord(prof->ev[1], s);
-  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets, into ? 1 : 0);
+  AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets, into ? 1 : 0, resident);
   ICICLE_TRY(check_launch("msm_accumulate"));
   if (prof) (void)hipEventRecord(prof->ev[2], s);
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;

@@ -123,8 +123,10 @@ eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int point
 // witness while its tail is still crossing PCIe (prover.cpp).  With segments, `d_points` and `skip_below` are the caller's to
 // offset: entries index scalars relative to the segment's first element.
 size_t msm_bucket_bytes(const SortPlan* pl, bool g2);
-eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1);
-eIcicleError msm_g2_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1);
+// `resident`: the accumulation kernel is launched with no more workgroups than the device holds at a time and strides over
+// the buckets — its dispatch then never sits in a hardware pipe's way (see msm_accumulate_kernel).
+eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1, bool resident = false);
+eIcicleError msm_g2_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1, bool resident = false);
 eIcicleError msm_g1_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot = 0);
 eIcicleError msm_g2_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot = 0);
 // host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective
@@ -132,7 +134,7 @@ void msm_g1_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, i
 void msm_g2_host_tail(const void* h_partials, uint32_t W, uint32_t bpw, int c, int wide, bn254_g2_projective_t* out);
 
 // G2 bucket accumulation, compiled with inlined Fq2 arithmetic (msm_g2_acc.hip)
-void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, uint32_t stride, hipStream_t s, void* buckets, int into);
+void msm_g2_accumulate_launch(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, uint32_t stride, hipStream_t s, void* buckets, int into, bool resident);
 
 // ---- automatic fixed-base tables behind bn254_msm / bn254_g2_msm (runtime.cpp) -------------------------------------------------
 // A caller that runs MSM after MSM over the SAME device-resident base array (the reference's host keeps its zkey points on the

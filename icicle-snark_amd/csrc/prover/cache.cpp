@@ -42,7 +42,7 @@ ZKeyCache::~ZKeyCache()
     if (ev_witness) (void)hipEventDestroy(ev_witness);
     if (ev_sort) (void)hipEventDestroy(ev_sort);
     if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
-    for (hipEvent_t e : {ev_head_in, ev_head_sorted, ev_head_c, ev_t_head_end, ev_t_witness})
+    for (hipEvent_t e : {ev_head_in, ev_head_done, ev_t_head_start, ev_t_head_end, ev_t_witness})
       if (e) (void)hipEventDestroy(e);
     for (auto e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -300,8 +300,8 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_head_in, hipEventDisableTiming));
-  P_HIP(hipEventCreateWithFlags(&z->ev_head_sorted, hipEventDisableTiming));
-  P_HIP(hipEventCreateWithFlags(&z->ev_head_c, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_head_done, hipEventDisableTiming));
+  P_HIP(hipEventCreate(&z->ev_t_head_start));
   P_HIP(hipEventCreate(&z->ev_t_head_end));
   P_HIP(hipEventCreate(&z->ev_t_witness));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));

@@ -347,7 +347,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   hipStream_t st4[4] = {g1, z->s_g4, g2, z->s_g5}; // A, B1, B2, C: separate streams, so that one MSM's latency-bound reduction overlaps another's accumulation
   // accumulation of witness[first … first + pl.L) into the bucket array of MSM k (0 A, 1 B1, 2 B2, 3 C) on stream st: the sort
   // entries index scalars relative to `first`, so the table pointer moves with it (C's bases start at wire n_public + 1)
-  auto accumulate = [&](int k, const SortPlan& pl, uint32_t first, bool into, hipStream_t st, MsmProfile* p) -> int {
+  auto accumulate = [&](int k, const SortPlan& pl, uint32_t first, bool into, hipStream_t st, MsmProfile* p, bool resident = false) -> int {
     const size_t esz = k == 2 ? 128 : 64;
     uint32_t sb = 0;
     size_t base_off = first;
@@ -359,8 +359,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       }
     }
     const void* pts = (const uint8_t*)sh4[k]->d_points + base_off * esz;
-    if (k == 2) P_ICICLE(msm_g2_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len()));
-    else P_ICICLE(msm_g1_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len()));
+    if (k == 2) P_ICICLE(msm_g2_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len(), resident));
+    else P_ICICLE(msm_g1_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len(), resident));
     return 0;
   };
 
@@ -370,7 +370,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // its way, and the tail's accumulation continues those buckets after the front end (msm_plan.h: `into`).  The GPU, idle during
   // the upload before, takes ≈ a fifth of the witness accumulations off the critical path.
   uint32_t head = 0;
-  bool pinned_src = false;
+  const uint32_t head_unit = (uint32_t)(STAGED_CHUNK_BYTES / 32); // the head is a whole number of upload chunks
+  bool pinned_src = false, head_forced = false;
   if (wtns) {
     Wtns w;
     if (int rc = parse_wtns((const uint8_t*)wtns, wtns_len, w)) return rc;
@@ -385,20 +386,26 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     //  the tests set it to 0 so that circuits the oracle proves in seconds take the path)
     static const int head_pct_env = getenv("ICICLE_SNARK_HEAD_PCT") ? atoi(getenv("ICICLE_SNARK_HEAD_PCT")) : -1;
     static const long head_min_env = getenv("ICICLE_SNARK_HEAD_MIN") ? atol(getenv("ICICLE_SNARK_HEAD_MIN")) : -1;
-    const uint32_t head_min = head_min_env >= 0 ? (uint32_t)head_min_env : (1u << 20);
-    if (z->geom_w.tab && (!early || head_min_env >= 0) && z->shard_count == 1 && wlo == 0 && wlen == nv && nv >= head_min) {
-      const double frac = head_pct_env >= 0 ? head_pct_env / 100.0 : z->head_frac;
-      const uint32_t unit = (uint32_t)(STAGED_CHUNK_BYTES / 32); // whole upload chunks
-      head = (uint32_t)((double)nv * frac / unit + 0.5) * unit;
-      if (head < unit || head >= nv || nv - head < unit) head = 0;
+    const uint32_t head_min = head_min_env >= 0 ? (uint32_t)head_min_env : (1u << 19);
+    head_forced = head_pct_env >= 0;
+    // Not for a key adapted to light witnesses (cache.cpp: mostly 0 / 1 wires, a fifth of the digits of a dense witness): its
+    // accumulations are short and the second sort, the second round of large-bucket kernels and the transforms slowed by the
+    // head's last workgroups cost more than the head takes off the MSM phase (stand-ins of BASELINE configs 4 / 5: 5.6 → 7.0 ms
+    // and 8.6 → 9.3 ms with a head; benchmark/1600k: 16.8 → 16.3 ms, 3200k: 30.7 → 29.4 ms).
+    const bool head_ok = z->geom_w.tab && z->shard_count == 1 && wlo == 0 && wlen == nv && nv >= head_min;
+    if (head_ok && head_pct_env >= 0 && (!early || head_min_env >= 0)) {
+      head = (uint32_t)((double)nv * (head_pct_env / 100.0) / head_unit + 0.5) * head_unit; // forced share (tests, sweeps)
+    } else if (head_ok && !early && !adapted_w) {
+      if (z->head_units < 0) z->head_units = (int)((double)nv * 0.10 / head_unit + 0.5); // first prove of the key: a tenth
+      head = (uint32_t)z->head_units * head_unit;
     }
+    if (head < head_unit || head >= nv || nv - head < head_unit) head = 0;
     const auto tu = std::chrono::steady_clock::now();
     pinned_src = is_pinned_host(w.values, z->device_id);
     P_HIP(hipEventRecord(z->ev[0], gq));
     if (head) {
-      // the head's kernels go to g2 (sort, B2), g1 (A, then C) and g4 (B1); the staging lanes of the upload are the three
-      // streams with nothing to do before the whole witness is there (QAP, H sort, C's own) — no extra stream, no extra
-      // hardware queue
+      // the head's kernels go to g2; the staging lanes of the upload are three of the streams with nothing to do before the whole
+      // witness is there (QAP, H sort, C's own) — no extra stream, no extra hardware queue
       const hipStream_t lanes[3] = {gq, g3, z->s_g5};
       StagedProgress prog;
       prog.head_bytes = (size_t)head * 32;
@@ -428,30 +435,34 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
           if (prog.done.load(std::memory_order_acquire)) break;
           std::this_thread::yield();
         }
+        mark("head in");
         const int tot = prog.lanes_total.load(std::memory_order_acquire);
         for (int t = 0; t < tot; t++)
           if (prog.ev[t] && hipStreamWaitEvent(g2, prog.ev[t], 0) != hipSuccess) up_rc = up_rc ? up_rc : fail((int)ICICLE_UNKNOWN_ERROR, "hipStreamWaitEvent");
       }
-      // head: digit sort on g2, then the four accumulations (zero-initialising their bucket arrays)
+      // head: digit sort, then the four accumulations (zero-initialising their bucket arrays) — ONE chain on g2, each kernel
+      // launched with no more workgroups than the GPU holds (`resident`).  Four concurrent accumulations with ordinary
+      // grids were measured first: their queued workgroups kept the hardware pipes busy dispatching, the barrier packets
+      // behind the staging DMAs (the events the upload workers wait for before they re-use a pinned buffer) were not
+      // processed until the kernels ended, and the upload stalled for their whole length (70 % of the bytes in 1.8 ms, the
+      // rest 1.1 ms late: profiles/r04_head_concurrent_timeline.txt).
       int hrc = 0;
       auto enqueue_head = [&]() -> int {
+        (void)hipEventRecord(z->ev_t_head_start, g2); // (timing, with ev_t_head_end and ev_t_witness: steers head_frac)
         P_ICICLE(msm_sort_run(z->d_witness, head, 0, 0, 0, g2, &plan_head, z->geom_w.c, 0, 1, adapted_w ? (uint64_t)((double)z->witness_entries * head / nv) + 1 : 0));
         if (plan_head.g.tab != z->geom_w.tab || plan_head.g.c != z->geom_w.c || plan_head.nbuckets != z->geom_w.NB)
           return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the sort of the witness head");
         for (int k = 0; k < 4; k++) P_HIP(bk[k].alloc(msm_bucket_bytes(&plan_head, k == 2), st4[k]));
-        P_HIP(hipEventRecord(z->ev_head_sorted, g2));
-        if (int rc = accumulate(2, plan_head, 0, false, g2, nullptr)) return rc;
-        (void)hipEventRecord(z->ev_t_head_end, g2); // (timing: where the head's longest chain ends relative to the upload)
-        P_HIP(hipStreamWaitEvent(g1, z->ev_head_sorted, 0));
-        if (int rc = accumulate(0, plan_head, 0, false, g1, nullptr)) return rc;
-        if (int rc = accumulate(3, plan_head, 0, false, g1, nullptr)) return rc; // C's head behind A's on g1: C's own stream carries a staging lane
-        P_HIP(hipEventRecord(z->ev_head_c, g1));
-        P_HIP(hipStreamWaitEvent(z->s_g4, z->ev_head_sorted, 0));
-        if (int rc = accumulate(1, plan_head, 0, false, z->s_g4, nullptr)) return rc;
+        for (int k : {2, 0, 1, 3})
+          if (int rc = accumulate(k, plan_head, 0, false, g2, nullptr, true)) return rc;
+        P_HIP(hipEventRecord(z->ev_head_done, g2));
+        (void)hipEventRecord(z->ev_t_head_end, g2); // (timing: where the head's chain ends relative to the upload)
         return 0;
       };
       if (!up_rc) hrc = enqueue_head();
+      mark("head enq");
       if (uploader.joinable()) uploader.join();
+      mark("upload");
       if (up_rc) return up_rc;
       if (hrc) return hrc;
       if (pinned_src) P_HIP(hipEventRecord(z->ev_witness, gq));
@@ -583,7 +594,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     fill(p, plan_w, k == 2);
     P_HIP(hipStreamWaitEvent(st, z->ev_sort, 0));
     if (!early) P_HIP(hipStreamWaitEvent(st, z->ev[2], 0));
-    if (head && k == 3) P_HIP(hipStreamWaitEvent(st, z->ev_head_c, 0)); // C's head was accumulated on g1
+    if (head && k != 2) P_HIP(hipStreamWaitEvent(st, z->ev_head_done, 0)); // the heads were accumulated on g2
     if (p != psort) (void)hipEventRecord(p->ev[0], st);
     if (int rc = accumulate(k, plan_w, wlo ? 0 : head, head != 0, st, p)) return rc;
     P_ICICLE(k == 2 ? msm_g2_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]) : msm_g1_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]));
@@ -690,12 +701,38 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // HIP-event profile of the five MSMs → the ring icicle_snark_msm_profile reads (bench.py: back = 4 … 0 = A, B1, B2, C, H); in
   // a device group only the lead shard publishes
   if (z->shard_rank == 0 || !z->in_group) msm_profile_publish(z->prof, 5);
+  if (head) {
+    // The head's share follows the machine: its chain should end just before the last byte of the witness lands — what is left
+    // of it then runs beside the transforms of the front end and slows them (long-lived accumulation workgroups hold the
+    // registers the transform workgroups need), what ends earlier leaves the GPU idle.  gap > 0: the head ended `gap` ms
+    // before the upload; a larger head both starts later (its bytes land later) and runs longer.
+    float work = 0, gap = 0, up = 0;
+    if (hipEventElapsedTime(&work, z->ev_t_head_start, z->ev_t_head_end) == hipSuccess && hipEventElapsedTime(&gap, z->ev_t_head_end, z->ev_t_witness) == hipSuccess &&
+        hipEventElapsedTime(&up, z->ev[0], z->ev_t_witness) == hipSuccess && work > 0 && up > 0) {
+      // Measured at 1.6 M constraints (profiles/r04_head_sweep.txt): ending 0.3 ms AFTER the upload is better than ending with
+      // it (12 % of the witness against 8 %: 16.1 against 16.4 ms file to file, 16.9–17.3 without a head) — the transforms
+      // lose less to the last of the head's workgroups than the MSM phase gains — and the optimum is flat beyond that.
+      const double f = (double)head / nv, per_unit = work / f + up; // ms by which the head's end moves per unit of share
+      const double margin = -0.30;
+      double f_new = f + 0.5 * ((double)gap - margin) / per_unit;
+      if (f_new > 0.40) f_new = 0.40;
+      // the share moves in whole upload chunks and only when it is off by most of one: a head of another size is another set of
+      // workspace blocks (a fresh hipMalloc inside a prove when it grows)
+      const double target = f_new * nv / head_unit, cur = (double)head / head_unit;
+      if (!head_forced && (target > cur + 0.75 || target < cur - 0.75)) {
+        z->head_units = (int)(target + 0.5);
+        if (z->head_units < 1) z->head_units = 1;
+      }
+      if (trace_host) fprintf(stderr, "[host] head %.1f %% of the witness: chain %.3f ms, ended %.3f ms before the upload (%.3f ms) -> next %.1f %%\n", 100 * f, work, gap, up, 100.0 * (head_forced ? head : (uint32_t)z->head_units * head_unit) / nv);
+    } else
+      (void)hipGetLastError();
+  }
   {
     float a = 0, b = 0, c = 0;
     (void)hipEventElapsedTime(&a, z->ev[0], z->ev[1]);
     (void)hipEventElapsedTime(&b, z->ev[1], z->ev[2]);
     (void)hipEventElapsedTime(&c, z->ev[2], z->ev[3]);
-    z->last_tm.h2d_ms = h2d_host_ms + a;
+    z->last_tm.h2d_ms = h2d_host_ms > a ? h2d_host_ms : a; // staged upload: the host waited for it; pinned source: the DMA in front of ev[1]
     z->last_tm.qap_ms = b;
     z->last_tm.msm_ms = c;
     z->last_tm.total_ms = ms_since(t0);

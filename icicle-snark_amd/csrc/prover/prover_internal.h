@@ -119,10 +119,10 @@ struct ZKeyCache {
   uint8_t* h_partials = nullptr; // pinned mirror
   hipStream_t s_g1 = nullptr, s_g2 = nullptr, s_g3 = nullptr, s_g4 = nullptr, s_g5 = nullptr, s_qap = nullptr;
   hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  // head / tail of a witness on its way in (prover.cpp): head resident (pinned source), head sorted, C's head accumulated;
-  // with timing: end of the head's longest chain, end of the upload
-  hipEvent_t ev_head_in = nullptr, ev_head_sorted = nullptr, ev_head_c = nullptr, ev_t_head_end = nullptr, ev_t_witness = nullptr;
-  double head_frac = 0.20; // share of the witness that is sorted and accumulated while the rest is still being uploaded
+  // head / tail of a witness on its way in (prover.cpp): head resident (pinned source), the head's four accumulations done;
+  // with timing: end of the head's chain, end of the upload
+  hipEvent_t ev_head_in = nullptr, ev_head_done = nullptr, ev_t_head_start = nullptr, ev_t_head_end = nullptr, ev_t_witness = nullptr;
+  int head_units = -1; // upload chunks of the witness that are sorted and accumulated while the rest is still on its way (follows the measured upload, prover.cpp); −1: not chosen yet
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
   bool witness_event_set = false; // ev_witness was already recorded for the resident witness (behind a device-side all-gather)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Timeline of ONE prove out of a rocprofv3 --kernel-trace run (rocpd sqlite): start/end of every dispatch of
-the last complete prove relative to its first kernel, grouped by stream (queue), plus the busy-union of the GPU.
+"""Timeline of ONE prove out of a rocprofv3 --kernel-trace [--memory-copy-trace] run (rocpd sqlite): start/end of every dispatch
+of one prove relative to its first event, grouped by stream (queue), plus the busy-union of the GPU; with a memory-copy trace the
+host→device copies of the witness upload are listed beside the kernels (merged into runs per engine queue).
 usage: timeline_rocpd.py <dir with *_results.db> [prove index, default 4 = inside bench.py's timed loop] [min dispatch ns to list, default 30000]"""
 import glob
 import sqlite3
@@ -16,23 +17,40 @@ def main():
     cols = [r[1] for r in con.execute(f"pragma table_info({kd})")]
     qcol = "queue_id" if "queue_id" in cols else "stream_id"
     rows = con.execute(f"select s.kernel_name, d.start, d.end, d.{qcol} from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-    # a prove starts with qap_spmv_kernel; take the last complete one
+    # a prove is anchored at its qap_spmv_kernel; its first kernel is the one behind the previous prove's last bucket reduction
+    # (the digit sort of the witness — of the witness HEAD, milliseconds before the spmv, when the head / tail split is on)
     starts = [i for i, r in enumerate(rows) if "qap_spmv" in r[0]]
-    # the witness sort (msm recode/hist) of the same prove is enqueued just before the spmv on another stream
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     k = min(k, len(starts) - 2)
-    i0, i1 = starts[k], starts[k + 1]
-    # include kernels launched shortly before the spmv (sort on stream g2)
-    t_spmv = rows[i0][1]
-    lo = i0
-    while lo > 0 and t_spmv - rows[lo - 1][1] < 300_000 and "reduce" not in rows[lo - 1][0]:
-        lo -= 1
-    sel = rows[lo:i1]
-    # drop kernels that belong to the next prove's early sort
-    t_next = rows[i1][1]
-    sel = [r for r in sel if r[1] < t_next - 300_000 or "msm_" not in r[0] or r[1] < t_next]
-    t0 = min(r[1] for r in sel)
-    print(f"# one prove: {len(sel)} dispatches, span {(max(r[2] for r in sel) - t0) / 1e6:.3f} ms (kernel activity only)")
+
+    def first_of(i_spmv):
+        lo = i_spmv
+        while lo > 0 and "reduce" not in rows[lo - 1][0] and rows[i_spmv][1] - rows[lo - 1][1] < 8_000_000:
+            lo -= 1
+        return lo
+    lo, hi = first_of(starts[k]), first_of(starts[k + 1])
+    sel = rows[lo:hi]
+    copies = []
+    mc = [t for t in tables if t.startswith("rocpd_memory_copy")]
+    if mc:
+        ccols = [r[1] for r in con.execute(f"pragma table_info({mc[0]})")]
+        if "start" in ccols and "end" in ccols and "size" in ccols:
+            t_lo = min(r[1] for r in sel) - 4_000_000
+            t_hi = max(r[2] for r in sel)
+            copies = [c for c in con.execute(f"select start, end, size from {mc[0]} order by start").fetchall() if t_lo <= c[0] <= t_hi and c[2] >= (1 << 20)]
+    t0 = min([r[1] for r in sel] + [c[0] for c in copies])
+    print(f"# one prove: {len(sel)} dispatches, span {(max(r[2] for r in sel) - t0) / 1e6:.3f} ms (from the first copy / kernel to the last kernel)")
+    if copies:
+        tot = sum(c[2] for c in copies)
+        print(f"# witness upload: {len(copies)} copies of >= 1 MiB, {tot / 1e6:.1f} MB, first starts {(copies[0][0] - t0) / 1e6:.3f} ms, last ends {(max(c[1] for c in copies) - t0) / 1e6:.3f} ms"
+              f" ({tot / max(1, max(c[1] for c in copies) - copies[0][0]):.1f} GB/s)")
+        # cumulative arrival: when 10 %, 20 %, … of the bytes had landed
+        acc, marks = 0, []
+        for c in sorted(copies, key=lambda c: c[1]):
+            acc += c[2]
+            while len(marks) < 10 and acc >= tot * (len(marks) + 1) / 10:
+                marks.append((c[1] - t0) / 1e6)
+        print("# bytes landed (10 % steps, ms): " + " ".join(f"{m:.2f}" for m in marks))
     print(f"{'queue':>6} {'start_ms':>9} {'end_ms':>9} {'dur_ms':>8}  kernel")
     for name, s, e, q in sel:
         short = name.split("(")[0].split("::")[-1][:60]

@@ -22,7 +22,11 @@ res, q, m = [], 0.0, 0.0
 for i in range(n):
     t = time.perf_counter(); _, _, tm = cm.prove_mem("k", wtns, resident=True); res.append((time.perf_counter() - t) * 1e3)
     q += tm.qap_ms; m += tm.msm_ms
-res.sort()
+host = []
+for i in range(n):
+    t = time.perf_counter(); cm.prove_mem("k", wtns); host.append((time.perf_counter() - t) * 1e3)
+res.sort(); host.sort()
+print(f"{wl}: host-witness median {host[n // 2]:.3f} min {host[0]:.3f}")
 print(f"{wl}: b_bases {info.b_bases} of {info.n_vars} | resident median {res[n // 2]:.3f} min {res[0]:.3f} | qap {q / n:.3f} msm {m / n:.3f}")
 for back, name in zip(range(4, -1, -1), ("A", "B1", "B2", "C", "H")):
     ms, g = K.msm_profile(back)

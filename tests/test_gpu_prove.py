@@ -435,7 +435,7 @@ def test_cache_info_sized_respects_the_callers_struct_size(gpu, cm):
 def test_witness_head_and_tail_accumulate_into_the_same_buckets(gpu, pct):
     """A witness on its way in is split (csrc/prover/prover.cpp): the head is sorted and accumulated into the four bucket arrays
     while the tail is still being uploaded, the tail's accumulation continues those buckets (`into`).  Forced here on circuits
-    the oracle proves in seconds (ICICLE_SNARK_HEAD_MIN=0; in production only witnesses of ≥ 2^20 wires are split): dense and
+    the oracle proves in seconds (ICICLE_SNARK_HEAD_MIN=0; in production only witnesses of ≥ 2^19 wires are split): dense and
     bit-heavy witnesses (large buckets with `into`), pageable buffer, file and pinned buffer, each equal to the proof of the
     SAME witness resident on the device — the single-sort path — for the same (r, s), to the oracle's, and accepted by the
     pairing check."""
