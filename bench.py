@@ -153,10 +153,13 @@ def pmc_child(workload):
     cm.close()
 
 
-def _pmc_pass(counter, workload, outdir, timeout):
+def _pmc_pass(counter, workload, outdir, timeout, extra=()):
+    """one rocprofv3 PMC pass (counters in a pass of their own, --kernel-trace only, the program directly after `--`) over the
+    PMC child → {kernel family: [per-dispatch sums of `counter` in dispatch order]}; `extra`: further counters of the same pass,
+    returned under the key (family, name)"""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     env = dict(os.environ, TMPDIR="/tmp", ICICLE_SNARK_QUIET="1")
-    cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", outdir, "--",
+    cmd = [exe, "--kernel-trace", "--pmc", counter, *extra, "--output-format", "csv", "-d", outdir, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", workload]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
@@ -168,7 +171,7 @@ def _pmc_pass(counter, workload, outdir, timeout):
     for fn in files:
         agg = {}
         for row in csv.DictReader(open(fn)):
-            if row["Counter_Name"] != counter:
+            if row["Counter_Name"] != counter and row["Counter_Name"] not in extra:
                 continue
             name = row["Kernel_Name"]
             fam = None
@@ -181,6 +184,8 @@ def _pmc_pass(counter, workload, outdir, timeout):
                         break
             if fam is None:
                 continue
+            if row["Counter_Name"] != counter:
+                fam = (fam, row["Counter_Name"])
             a = agg.setdefault((fam, int(row["Dispatch_Id"])), 0.0)
             agg[(fam, int(row["Dispatch_Id"]))] = a + float(row["Counter_Value"])   # per-XCD rows of one dispatch
         for (fam, did), v in sorted(agg.items(), key=lambda kv: kv[0][1]):
@@ -196,6 +201,10 @@ def pmc_traffic(workload, timeout=600):
     try:
         fetch = _pmc_pass("FETCH_SIZE", workload, os.path.join(tmp, "f"), timeout)
         write = _pmc_pass("WRITE_SIZE", workload, os.path.join(tmp, "w"), timeout)
+        try:
+            sq = _pmc_pass("SQ_INSTS_VALU", workload, os.path.join(tmp, "s"), timeout, extra=("GRBM_GUI_ACTIVE",))
+        except Exception:   # noqa: BLE001 — the traffic figures stand without the issue counters
+            sq = {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {"detail": {}}
@@ -207,6 +216,10 @@ def pmc_traffic(workload, timeout=600):
         out["acc_h"] = f[k] * 1024 * 2 + w[k] * 1024
         out["acc_h_raw"] = f[k] * 1024 + w[k] * 1024
         out["detail"]["acc_h"] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w[k]}
+        # issue counters of the same launch (third pass): wave-level VALU instructions and GPU-active cycles summed over the 8 XCDs
+        iv, ga = sq.get("acc_g1", []), sq.get(("acc_g1", "GRBM_GUI_ACTIVE"), [])
+        if len(iv) == len(f) and len(ga) == len(f) and ga[k] > 0:
+            out["acc_h_valu"] = {"SQ_INSTS_VALU": iv[k], "GRBM_GUI_ACTIVE": ga[k]}
     # digit sort: per prove two sorts (witness, then H), each launching every sort kernel the same number of times
     tot_f = tot_w = 0.0
     ok = False
@@ -463,6 +476,15 @@ def inproc_group_bench(args, dist, rank, world, zkey, wtns, tmpdir):
 
 def roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops):
     """roofline object of the dominant kernel (G1 bucket accumulation of the H MSM) from its geometry and HIP-event time"""
+    counters = None
+    if pmc and pmc.get("acc_h_valu"):
+        iv, ga = pmc["acc_h_valu"]["SQ_INSTS_VALU"], pmc["acc_h_valu"]["GRBM_GUI_ACTIVE"]
+        counters = {"SQ_INSTS_VALU": iv, "GRBM_GUI_ACTIVE_sum_over_8_xcds": ga,
+                    "valu_instructions_per_mixed_addition": iv * 64 / (g["L"] * g["W"]),
+                    # share of all SIMD cycles of the launch (1024 SIMDs x GPU-active cycles per XCD) in which a VALU instruction
+                    # issues when every one is priced at 4 cycles (the multiplier instructions are; 2-operand 32-bit ones take 2)
+                    "valu_issue_util_at_4_cycles": iv * 4 / (1024 * ga / 8),
+                    "source": "rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE child pass of this run (kernels serialised by the profiler)"}
     # algorithmic bytes of one bucket-accumulation launch (DESIGN.md §kernels): per non-zero digit one 4-B
     # sorted index + one 64-B affine base gathered; per bucket 8 B of (offset,count) + a 128-B XYZZ result
     alg_bytes = g["L"] * g["W"] * (4 + 64) + g["nbuckets"] * (8 + 128)
@@ -483,7 +505,8 @@ def roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops):
                     "frac": n_add * 1548 / (kern_ms * 1e-3) / 1e12 / 39.3216,
                     "measured_peak_tmad_per_s": mad_tops,
                     "frac_of_measured": n_add * 1548 / (kern_ms * 1e-3) / 1e12 / mad_tops,
-                    "source": "instruction counts of the kernel's source x launches / HIP-event time (counter-derived figures: profiles/r04_pmc_*.txt)"},
+                    "source": "instruction counts of the kernel's source x launches / HIP-event time",
+                    "counters": counters},
             "hbm_copy_gbps_measured": hbm_copy_gbps, "frac_of_measured_copy": achieved / hbm_copy_gbps}
 
 
