@@ -88,55 +88,69 @@ __device__ __forceinline__ typename Lazy<C>::type::A load_base_lazy(const typena
   return CL::load_affine(p, form, (e >> 31) != 0);
 }
 
-template <class C>
-__global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, uint32_t stride, int ib, int form,
-                                                              int into, typename C::X* buckets)
+// one bucket: the thread walks the bucket's slice of `sorted`, gathers the bases and adds them into a lazy XYZZ accumulator
+template <class C, bool INTO>
+__device__ __forceinline__ void accumulate_bucket(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                  const uint32_t* __restrict__ order, uint32_t t, uint32_t large_thr, uint32_t skip_below, uint32_t stride, int ib, int form, typename C::X* buckets)
 {
   typedef typename Lazy<C>::type CL;
-  // Grid-stride over the size-ordered bucket list: with one thread per bucket (the usual launch) the loop runs once.  A launch
-  // capped at the number of workgroups the GPU holds at a time (`resident` launches, AccumulateLauncher) walks the list in
-  // strides instead — every thread takes one bucket of each size stratum, so the threads stay balanced — and, unlike a grid
-  // of several times that size, never leaves workgroups waiting in the dispatcher: a kernel whose workgroups queue there
-  // blocks its hardware pipe for the barrier packets (events!) and small kernels of every other queue on that pipe for as long
-  // as it runs (measured: the staging events of a witness upload stalled for the whole length of such a kernel, prover.cpp).
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nbuckets; t += gridDim.x * blockDim.x) {
-    const uint32_t b = order[t]; // neighbouring lanes own buckets of (nearly) equal size
-    const uint32_t cnt = counts[b];
-    if (cnt > large_thr) continue; // step 4b
-    // `into`: the bucket array already holds the sums of an earlier SEGMENT of the same scalar vector (the prover sorts and
-    // accumulates the head of a witness while its tail is still on the way over PCIe, prover.cpp) — go on from there
-    if (into && cnt == 0) continue;
-    const uint32_t* idx = sorted + offsets[b];
-    typename CL::X acc = into ? CL::x_load_internal(buckets[b]) : CL::x_zero();
-    if (sizeof(typename C::A) > 64) {
-      // G2: a prefetched 128-byte point would push the kernel past 256 VGPRs (one wave per SIMD); only the index is prefetched
-      uint32_t e_nxt = cnt ? idx[0] : 0u;
-      for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t e = e_nxt;
-        if (k + 1 < cnt) e_nxt = idx[k + 1];
-        bool z;
-        const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, stride, ib, form, z);
-        if (!z) CL::x_madd(acc, p);
-      }
-    } else {
-      // G1, software pipeline: the index two entries ahead and the (gathered, packed) point one entry ahead are in
-      // flight while the current mixed addition (~9 k cycles per wave) runs; without it every iteration starts with two
-      // dependent memory latencies (H accumulation alone: 4.0 → 3.0 ms)
-      uint32_t e_cur = cnt ? idx[0] : 0u, e_nxt = cnt > 1 ? idx[1] : 0u;
-      typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
-      for (uint32_t k = 0; k < cnt; k++) {
-        const typename C::A pk = pk_cur;
-        const uint32_t e = e_cur;
-        e_cur = e_nxt;
-        if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
-        if (k + 2 < cnt) e_nxt = idx[k + 2];
-        const bool z = entry_point(e, ib) < skip_below || C::aff_is_zero(pk);
-        if (!z) CL::x_madd(acc, CL::load_affine(pk, form, (e >> 31) != 0));
-      }
+  const uint32_t b = order[t]; // neighbouring lanes own buckets of (nearly) equal size
+  const uint32_t cnt = counts[b];
+  if (cnt > large_thr) return; // step 4b
+  // INTO: the bucket array already holds the sums of an earlier SEGMENT of the same scalar vector (the prover sorts and
+  // accumulates the head of a witness while its tail is still on the way over PCIe, prover.cpp) — go on from there
+  if (INTO && cnt == 0) return;
+  const uint32_t* idx = sorted + offsets[b];
+  typename CL::X acc = INTO ? CL::x_load_internal(buckets[b]) : CL::x_zero();
+  if (sizeof(typename C::A) > 64) {
+    // G2: a prefetched 128-byte point would push the kernel past 256 VGPRs (one wave per SIMD); only the index is prefetched
+    uint32_t e_nxt = cnt ? idx[0] : 0u;
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint32_t e = e_nxt;
+      if (k + 1 < cnt) e_nxt = idx[k + 1];
+      bool z;
+      const typename CL::A p = load_base_lazy<C>(bases, e, skip_below, stride, ib, form, z);
+      if (!z) CL::x_madd(acc, p);
     }
-    buckets[b] = CL::x_store_internal(acc);
+  } else {
+    // G1, software pipeline: the index two entries ahead and the (gathered, packed) point one entry ahead are in
+    // flight while the current mixed addition (~9 k cycles per wave) runs; without it every iteration starts with two
+    // dependent memory latencies (H accumulation alone: 4.0 → 3.0 ms)
+    uint32_t e_cur = cnt ? idx[0] : 0u, e_nxt = cnt > 1 ? idx[1] : 0u;
+    typename C::A pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
+    for (uint32_t k = 0; k < cnt; k++) {
+      const typename C::A pk = pk_cur;
+      const uint32_t e = e_cur;
+      e_cur = e_nxt;
+      if (k + 1 < cnt) pk_cur = fetch_base<C>(bases, e_cur, skip_below, stride, ib);
+      if (k + 2 < cnt) e_nxt = idx[k + 2];
+      const bool z = entry_point(e, ib) < skip_below || C::aff_is_zero(pk);
+      if (!z) CL::x_madd(acc, CL::load_affine(pk, form, (e >> 31) != 0));
+    }
   }
+  buckets[b] = CL::x_store_internal(acc);
+}
+
+// Three instances are used — plain, INTO and STRIDED — because either option costs registers (G1: 136 → 138, past a
+// 16-register allocation step, after which one G2 and two G1 accumulation waves no longer fit a SIMD together).
+// STRIDED: grid-stride over the size-ordered bucket list.  A launch capped at the number of workgroups the GPU holds at a
+// time (`resident` launches, AccumulateLauncher) walks the list in strides — every thread takes one bucket of each size
+// stratum, so the threads stay balanced — and, unlike a grid of several times that size, never leaves workgroups waiting
+// in the dispatcher: a kernel whose workgroups queue there blocks its hardware pipe for the barrier packets (events!) and
+// small kernels of every other queue on that pipe for as long as it runs (measured: the staging events of a witness upload
+// stalled for the whole length of such a kernel, prover.cpp).  !STRIDED: one thread per bucket.
+template <class C, bool STRIDED, bool INTO>
+__global__ __launch_bounds__(256) void msm_accumulate_kernel(const typename C::A* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order, uint32_t nbuckets, uint32_t large_thr, uint32_t skip_below, uint32_t stride, int ib, int form,
+                                                              typename C::X* buckets)
+{
+  const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!STRIDED) {
+    if (t0 >= nbuckets) return;
+    accumulate_bucket<C, INTO>(bases, sorted, offsets, counts, order, t0, large_thr, skip_below, stride, ib, form, buckets);
+    return;
+  }
+  for (uint32_t t = t0; t < nbuckets; t += gridDim.x * blockDim.x) accumulate_bucket<C, INTO>(bases, sorted, offsets, counts, order, t, large_thr, skip_below, stride, ib, form, buckets);
 }
 
 // in-place conversion of an affine base array to the internal encoding (cold path, once per key)
@@ -678,13 +692,13 @@ struct AccumulateLauncher {
       if (!c) {
         int per_cu = 0, dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msm_accumulate_kernel<C>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msm_accumulate_kernel<C, true, false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         // (the occupancy API can come out one workgroup per CU high on this stack — MI355X guide, "Correctness boundaries" — and one
         //  queued workgroup is what must not happen here: bound it by the register file, 512 VGPRs per SIMD lane, a 256-thread
         //  workgroup = one wave on each of the four SIMDs)
         hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(msm_accumulate_kernel<C>)) == hipSuccess && fa.numRegs > 0) {
-          const int by_regs = 512 / ((fa.numRegs + 7) & ~7);
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(msm_accumulate_kernel<C, true, false>)) == hipSuccess && fa.numRegs > 0) {
+          const int by_regs = 512 / ((fa.numRegs + 15) & ~15);
           if (by_regs >= 1 && by_regs < per_cu) per_cu = by_regs;
         }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -694,7 +708,14 @@ struct AccumulateLauncher {
       }
       if (grid > c) grid = c;
     }
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3(grid), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, into, buckets);
+#define ISNARK_ACC_LAUNCH(STRIDED_, INTO_)                                                                                                                                                   \
+  hipLaunchKernelGGL((msm_accumulate_kernel<C, STRIDED_, INTO_>), dim3(grid), dim3(256), 0, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->order, pl->nbuckets, pl->large_thr, skip_below, \
+                     stride, pl->g.tab ? pl->g.IB : 0, mont_pt, buckets)
+    // plain | INTO (tail of a witness) | STRIDED (head of a witness; a strided launch that continues buckets does not occur)
+    if (resident && !into) ISNARK_ACC_LAUNCH(true, false);
+    else if (into) ISNARK_ACC_LAUNCH(false, true);
+    else ISNARK_ACC_LAUNCH(false, false);
+#undef ISNARK_ACC_LAUNCH
   }
 };
 #if defined(ISNARK_G2_ACC_EXTERN)
