@@ -352,6 +352,17 @@ def setup_squaring_chain(N: int, vec, fixed_base_mul, points_to_mont=None, seed:
 # benchmark/keyless/README.md is a pointer), so a random sparse R1CS of published scale stands in:
 # ≥ 70 % of the wires are bits, ~10 % are below 2^64, the rest full width; ≈ 3 non-zeros per row of A and ≈ 1.5 per row
 # of B.  Everything produced from it is labelled "synthetic stand-in".
+# Where the sizes come from (none of it checkable offline — no circom, no circomlib, no snarkjs; they are estimates and say so):
+#  * anon_aadhaar: `component main = AadhaarVerifier(121, 17, 512 * 3)` (benchmark/anon_aadhaar/circuit.circom, last line): an
+#    RSA-2048 signature check over 17 limbs of 121 bits on a SHA-256 of up to 1536 bytes = 24 compression blocks; circomlib's
+#    SHA-256 is ≈ 29 k constraints per block (≈ 0.7 M), the big-integer exponentiation to 65537 and the QR-data extractor make up the
+#    rest: ≈ 1.0 M constraints, domain 2^20.  The reference's own chart agrees: its ≈ 150 ms bar lies between its 800K (≈ 100 ms) and
+#    1600K (≈ 180 ms) bars (figures/4090_cache.png).  Public signals: nullifierSeed, signalHash + 7 outputs in the real circuit; 4 here.
+#  * keyless: benchmark/keyless/README.md only points at aptos-labs/keyless-zk-proofs; its ≈ 230 ms bar lies between the 1600K and
+#    3200K bars of the same chart, and a bit-heavy circuit proves faster per constraint than the dense benchmark chain, so 1.4 M
+#    constraints (domain 2^21) is a lower-end estimate of that scale.
+#  * sparsity / witness mix: SHA-256 and RSA limb arithmetic are dominated by boolean wires (XOR / AND / MUX of bits, bit
+#    decompositions) with a minority of range-limited limbs and full-width products — the five constraint kinds of standin_circuit.
 STANDIN_SIZES = {
     # name: (constraints, public signals, free inputs) — domain 2^20 / 2^21
     "aadhaar_standin": (1_000_000, 4, 4096),
