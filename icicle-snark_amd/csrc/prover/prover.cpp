@@ -409,7 +409,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       const hipStream_t lanes[3] = {gq, g3, z->s_g5};
       StagedProgress prog;
       prog.head_bytes = (size_t)head * 32;
-      int up_rc = 0;
+      int up_rc = 0, wait_rc = 0; // up_rc belongs to the uploader thread until it is joined
       std::thread uploader;
       const void* hint_base;
       size_t hint_len;
@@ -438,7 +438,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
         mark("head in");
         const int tot = prog.lanes_total.load(std::memory_order_acquire);
         for (int t = 0; t < tot; t++)
-          if (prog.ev[t] && hipStreamWaitEvent(g2, prog.ev[t], 0) != hipSuccess) up_rc = up_rc ? up_rc : fail((int)ICICLE_UNKNOWN_ERROR, "hipStreamWaitEvent");
+          if (prog.ev[t] && hipStreamWaitEvent(g2, prog.ev[t], 0) != hipSuccess) wait_rc = fail((int)ICICLE_UNKNOWN_ERROR, "hipStreamWaitEvent");
       }
       // head: digit sort, then the four accumulations (zero-initialising their bucket arrays) — ONE chain on g2, each kernel
       // launched with no more workgroups than the GPU holds (`resident`).  Four concurrent accumulations with ordinary
@@ -459,11 +459,12 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
         (void)hipEventRecord(z->ev_t_head_end, g2); // (timing: where the head's chain ends relative to the upload)
         return 0;
       };
-      if (!up_rc) hrc = enqueue_head();
+      if (!wait_rc) hrc = enqueue_head();
       mark("head enq");
       if (uploader.joinable()) uploader.join();
       mark("upload");
       if (up_rc) return up_rc;
+      if (wait_rc) return wait_rc;
       if (hrc) return hrc;
       if (pinned_src) P_HIP(hipEventRecord(z->ev_witness, gq));
     } else if (pinned_src) {
