@@ -551,6 +551,8 @@ __global__ __launch_bounds__(256) void msm_fine_place_kernel(const uint32_t* __r
 //     index — is found from its position in the partition (runs are in tile order) by a binary search in the partition's
 //     column of run offsets.  Per-bucket counts and offsets fall out of the chunk histograms.
 // HBM bytes: scalars 2 × 32·L, entries 4·L·W written and read twice, 4·L·W written — each once, in full lines.
+// Every scalar is recoded once for the tile histogram and once per window group for the placement (the placement pass takes
+// its per-partition counts from the histogram: round 4; it used to recode a second time to count).
 constexpr int S2_TILE = 2048;    // scalars per tile (pass A)
 constexpr int S2_WGRP = 7;       // windows per row: a row = (tile, window group) stages ≤ 2048·7 entries = 56 KiB in LDS
 constexpr int S2_CHUNK = 12288;  // entries per chunk (pass B): 48 KiB of LDS
@@ -651,7 +653,8 @@ __global__ __launch_bounds__(1024) void sort2_col_base_kernel(uint32_t* __restri
     chunk_first[p] = cf[p];
   }
 }
-__global__ __launch_bounds__(256) void sort2_col_apply_kernel(uint32_t* __restrict__ cnt, uint32_t R, uint32_t P, const uint32_t* __restrict__ partial)
+// (out of place: the counts stay — the partition pass loads its row of them instead of recoding its scalars once more to count)
+__global__ __launch_bounds__(256) void sort2_col_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, uint32_t R, uint32_t P, const uint32_t* __restrict__ partial)
 {
   ISNARK_CRITICAL_CHAIN_KERNEL();
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
@@ -659,14 +662,14 @@ __global__ __launch_bounds__(256) void sort2_col_apply_kernel(uint32_t* __restri
   const uint32_t rpg = (R + S2_RG - 1) / S2_RG, r0 = blockIdx.y * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
   uint32_t run = partial[(size_t)blockIdx.y * P + p];
   for (uint32_t r = r0; r < r1; r++) {
-    const uint32_t c = cnt[(size_t)r * P + p];
-    cnt[(size_t)r * P + p] = run;
-    run += c;
+    off[(size_t)r * P + p] = run;
+    run += cnt[(size_t)r * P + p];
   }
 }
 // pass A, step 2: the row's entries (one tile, one window group) sorted by partition in LDS, then copied out run by run
 __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t HS,
-                                                                           const uint32_t* __restrict__ off, const uint32_t* __restrict__ part_start, uint32_t* __restrict__ tmp)
+                                                                           const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ part_start,
+                                                                           uint32_t* __restrict__ tmp)
 {
   ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[];
@@ -677,19 +680,8 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const 
   const int w0 = (int)h * S2_WGRP, w1 = w0 + S2_WGRP < g.W ? w0 + S2_WGRP : g.W;
   const uint32_t first = tile * S2_TILE;
   const uint32_t low_mask = (1u << low_b) - 1;
-  for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = 0;
-  __syncthreads();
-  for (int u = 0; u < S2_TILE / S2_THREADS; u++) {
-    const uint32_t i = first + u * S2_THREADS + threadIdx.x;
-    if (i < L) {
-      uint32_t t[9], neg;
-      recode(scalars, i, g, mont, t, neg);
-      for (int w = w0; w < w1; w++) {
-        const uint32_t d = digit(t, w, g);
-        if (d) atomicAdd(&cur[((d & 0x7fffffffu) - 1) >> low_b], 1u);
-      }
-    }
-  }
+  // the row's digit counts per partition: what sort2_tile_hist_kernel counted for it (one recode pass less per row)
+  for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = cnt[(size_t)row * P + p];
   __syncthreads();
   s2_wave_scan(cur, base, P);
   __syncthreads();
@@ -1010,12 +1002,13 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   }
   if (lds_sort) {
     const uint32_t P = 1u << s2_pb, NL = 1u << s2_low, R = s2_rows, HS = s2_hs;
-    // workspace: cnt[R][P] | partial[S2_RG][P] | part_start[P + 1] | chunk_first[P + 1] | chunk_hist | chunk_off [maxchunks][NL]
+    // workspace: cnt[R][P] | off[R][P] | partial[S2_RG][P] | part_start[P + 1] | chunk_first[P + 1] | chunk_hist | chunk_off [maxchunks][NL]
     WsScoped<uint32_t> s2ws;
     const size_t n_cnt = (size_t)R * P, n_part = (size_t)S2_RG * P, n_ch = (size_t)s2_maxchunks * NL;
-    HIP_TRY(s2ws.alloc(n_cnt + n_part + 2 * (size_t)P + 2 + 2 * n_ch, s), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(s2ws.alloc(2 * n_cnt + n_part + 2 * (size_t)P + 2 + 2 * n_ch, s), ICICLE_ALLOCATION_FAILED);
     uint32_t* cnt = s2ws.p;
-    uint32_t* partial = cnt + n_cnt;
+    uint32_t* off = cnt + n_cnt;      // first entry of every (row, partition) run inside its partition
+    uint32_t* partial = off + n_cnt;
     uint32_t* pstart = partial + n_part;
     uint32_t* cfirst = pstart + P + 1;
     uint32_t* chist = cfirst + P + 1;
@@ -1039,12 +1032,12 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     hipLaunchKernelGGL(sort2_tile_hist_kernel, dim3(s2_ntiles), dim3(256), (size_t)HS * P * 4, s, d_scalars, L, g, mont_sc, s2_low, P, HS, cnt);
     hipLaunchKernelGGL(sort2_col_sum_kernel, cgrid, dim3(256), 0, s, cnt, R, P, partial);
     hipLaunchKernelGGL(sort2_col_base_kernel, dim3(1), dim3(1024), 0, s, partial, P, pstart, cfirst);
-    hipLaunchKernelGGL(sort2_col_apply_kernel, cgrid, dim3(256), 0, s, cnt, R, P, partial);
-    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(R), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, HS, cnt, pstart, s2tmp);
+    hipLaunchKernelGGL(sort2_col_apply_kernel, cgrid, dim3(256), 0, s, cnt, off, R, P, partial);
+    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(R), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, HS, cnt, off, pstart, s2tmp);
     hipLaunchKernelGGL(sort2_chunk_hist_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), 0, s, s2tmp, pstart, cfirst, P, s2_low, chist);
     hipLaunchKernelGGL(sort2_bucket_scan_kernel, dim3(P), dim3(NL), 0, s, chist, coff, pstart, cfirst, s2_low, thr, pl->counts, pl->offsets, pl->n_large, pl->large_list, pl->large_first,
                        pl->large_items, pl->item_cap);
-    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, cnt, R, HS, g, pl->sorted);
+    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, off, R, HS, g, pl->sorted);
     ICICLE_TRY(check_launch("msm_sort (LDS-staged)"));
   } else {
   unsigned zb = (3 * nb + 255) / 256;
