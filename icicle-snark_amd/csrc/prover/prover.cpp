@@ -368,7 +368,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // and nothing of construct_r1cs can start before all of it is there (the spmv reads arbitrary wires) — but the witness MSMs are
   // sums over wires: the first `head` wires are sorted and accumulated into the four bucket arrays while the rest is still on
   // its way, and the tail's accumulation continues those buckets after the front end (msm_plan.h: `into`).  The GPU, idle during
-  // the upload before, takes ≈ a fifth of the witness accumulations off the critical path.
+  // the upload before, takes 8–20 % of the witness accumulations (what the upload of the machine affords) off the critical path.
   uint32_t head = 0;
   const uint32_t head_unit = (uint32_t)(STAGED_CHUNK_BYTES / 32); // the head is a whole number of upload chunks
   bool pinned_src = false, head_forced = false;
