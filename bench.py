@@ -560,7 +560,7 @@ def standalone_group(args, workload):
     tmpdir = tempfile.mkdtemp(prefix="isnark_bench_")
     cfg = dict(steps=args.steps, warmup=args.warmup, workload=workload, zkey=os.path.join(tmpdir, "g.zkey"), wtns=os.path.join(tmpdir, "g.wtns"),
                proof=os.path.join(tmpdir, "g_proof.json"), public=os.path.join(tmpdir, "g_public.json"))
-    timeout = float(os.environ.get("ICICLE_SNARK_GROUP_TIMEOUT", "900"))
+    timeout = float(os.environ.get("ICICLE_SNARK_GROUP_TIMEOUT", "300"))   # per attempt: synthesis + cold build + warm-up + equality checks take ≈ 10-20 s
     ladder = [({}, f"HIP:{devices}")]
     if not os.environ.get("ICICLE_SNARK_EXCHANGE"):
         ladder += [({"ICICLE_SNARK_EXCHANGE": "memcpy"}, f"HIP:{devices}"), ({"ICICLE_SNARK_EXCHANGE": "rccl"}, f"HIP:{devices}")]
