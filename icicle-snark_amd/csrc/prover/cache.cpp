@@ -42,7 +42,7 @@ ZKeyCache::~ZKeyCache()
     if (ev_witness) (void)hipEventDestroy(ev_witness);
     if (ev_sort) (void)hipEventDestroy(ev_sort);
     if (ev_sort_h) (void)hipEventDestroy(ev_sort_h);
-    for (hipEvent_t e : {ev_head_in, ev_head_done, ev_t_head_start, ev_t_head_end, ev_t_witness})
+    for (hipEvent_t e : {ev_own_slice, ev_head_in, ev_head_done, ev_t_head_start, ev_t_head_end, ev_t_witness})
       if (e) (void)hipEventDestroy(e);
     for (auto e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -187,7 +187,14 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   // bases (sections 5-9), this process's point range only
   // A, B1, B2 share the witness range [wlo, whi); C (= witness[n_public+1..]) takes the part of that SAME
   // witness range it covers, so that one digit sort of witness[wlo:whi] serves all four MSMs.
-  const uint32_t wlo = (uint32_t)((uint64_t)z->n_vars * rank / count), whi = (uint32_t)((uint64_t)z->n_vars * (rank + 1) / count);
+  // The range of shard `rank` is the witness SLICE that rank uploads itself (witness_slice_elems: ⌈n_vars / count⌉ wires from
+  // rank·slice; groth16_upload_witness_slice, multi.cpp) whenever that leaves no shard empty: its digit sort and its four witness
+  // accumulations then need nothing from the other devices and run while the in-place all-gather, the distributed front end and its
+  // two all-to-alls are still under way (prover.cpp: own_slice_first).  Otherwise the even split ⌊n_vars·rank / count⌋.
+  const uint64_t slice = witness_slice_elems(z->n_vars, count);
+  z->slice_aligned = count > 1 && slice * (uint64_t)(count - 1) < z->n_vars;
+  const uint32_t wlo = z->slice_aligned ? (uint32_t)(slice * (uint64_t)rank) : (uint32_t)((uint64_t)z->n_vars * rank / count);
+  const uint32_t whi = z->slice_aligned ? (uint32_t)std::min<uint64_t>(z->n_vars, slice * (uint64_t)(rank + 1)) : (uint32_t)((uint64_t)z->n_vars * (rank + 1) / count);
   const uint32_t skip = z->n_public + 1;
   const uint32_t clo = (wlo > skip ? wlo : skip) - skip, chi = (whi > skip ? whi : skip) - skip;
   const uint32_t hlo = (uint32_t)((uint64_t)n * rank / count), hhi = (uint32_t)((uint64_t)n * (rank + 1) / count);
@@ -299,6 +306,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_sort_h, hipEventDisableTiming));
+  P_HIP(hipEventCreateWithFlags(&z->ev_own_slice, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_head_in, hipEventDisableTiming));
   P_HIP(hipEventCreateWithFlags(&z->ev_head_done, hipEventDisableTiming));
   P_HIP(hipEventCreate(&z->ev_t_head_start));

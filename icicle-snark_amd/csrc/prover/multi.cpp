@@ -531,6 +531,9 @@ int group_commitments(Groth16CacheManager* cm, DeviceGroup* g, const void* wtns,
         staged_copy_file_hint(nullptr, 0, -1);
         up_ms[r] = ms_since(tu);
         if (!rc && hipEventRecord(g->ev_slice[r], sq) != hipSuccess) rc = fail((int)ICICLE_UNKNOWN_ERROR, "hipEventRecord");
+        // the shard's own slice is in place: its witness MSMs need no more than that (shard_commitments: own_slice_first)
+        if (!rc && hipEventRecord(z->ev_own_slice, sq) != hipSuccess) rc = fail((int)ICICLE_UNKNOWN_ERROR, "hipEventRecord");
+        z->own_slice_event_set = !rc;
       }
       st.note(rc);
       g->team->barrier(); // every ev_slice is recorded
@@ -580,6 +583,7 @@ int group_commitments(Groth16CacheManager* cm, DeviceGroup* g, const void* wtns,
       z->dist_ready = z->dist_stage2_done = false;
       z->witness_event_set = false;
     }
+    z->own_slice_event_set = false;
     g->team->barrier(); // no shard returns (and lets the next prove overwrite its buffers) while a peer may still read them
   });
   (void)set_active_device(g->devs[0]);

@@ -334,7 +334,12 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // Witness MSMs of small circuits (domain up to 2^19) leave the GPU far from full: they start right
   // after the witness sort instead of waiting for the QAP (200 k constraints: 3.71 → 3.51 ms, 400 k: 6.69 → 6.24 ms; the QAP
   // itself slows down — 1.1 → 3.9 ms at 400 k — which is why the large ones are held back: 800 k: 9.87 → 10.27 ms).
-  const bool early = wlen <= early_max && n <= early_max; // shards of a large circuit keep the full-size inverse transform: neutral there
+  // A shard of an in-process device group whose point range is its own witness slice (cache.cpp: slice_aligned) starts its witness
+  // sort behind its own PCIe upload and its accumulations behind that sort: the all-gather of the witness, the distributed front
+  // end and its two all-to-alls — xGMI round trips during which the GPU would otherwise wait — then run beside them; only H needs
+  // the front end.  (On ONE GPU with every shard aliased to it this is neutral: there is no exchange latency to hide.)
+  const bool own_slice_first = z->in_group && z->slice_aligned && z->own_slice_event_set && wtns == nullptr;
+  const bool early = wlen <= early_max && (n <= early_max || own_slice_first); // (rank-per-GPU shards keep the full-size inverse transform: neutral there)
   MsmProfile* prof[5]; // A, B1, B2, C, H — this entry's own slots (published to the device's ring at the end by the lead shard)
   for (int k = 0; k < 5; k++) {
     prof[k] = &z->prof[k];
@@ -495,7 +500,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // ---- ONE digit sort of the witness range (shared by A, B1, B2, C) — of its tail when the head was sorted above — on g2
   // without a head (the G2 bucket stages follow it there) and on g3 with one (g2 still carries B2's head accumulation)
   hipStream_t gs = head ? g3 : g2;
-  P_HIP(hipStreamWaitEvent(gs, z->ev_witness, 0));
+  P_HIP(hipStreamWaitEvent(gs, own_slice_first ? z->ev_own_slice : z->ev_witness, 0));
   // the witness sort is timed with the profile of the G2 MSM
   MsmProfile* psort = prof[2];
   (void)hipEventRecord(psort->ev[0], gs);

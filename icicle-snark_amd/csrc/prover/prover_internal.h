@@ -126,6 +126,10 @@ struct ZKeyCache {
   uint64_t device_bytes = 0;
   bool witness_resident = false; // d_witness holds the witness of the last call (wtns == NULL reuses it)
   bool witness_event_set = false; // ev_witness was already recorded for the resident witness (behind a device-side all-gather)
+  // device group: this shard's own 1/count of the witness is in place (recorded behind its PCIe upload, before the all-gather);
+  // with slice_aligned — the shard's point range IS that slice — its witness sort and accumulations wait for nothing else
+  hipEvent_t ev_own_slice = nullptr;
+  bool own_slice_event_set = false, slice_aligned = false;
   Groth16Timings last_tm = {0, 0, 0, 0}; // phase timings of the most recent prove (groth16_last_timings)
   MsmProfile prof[5] = {};               // A, B1, B2, C, H of the most recent prove: this entry's own slots (the shards of a group may share a device)
   uint64_t last_use = 0;                 // CacheManager LRU clock
