@@ -720,7 +720,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       // lose less to the last of the head's workgroups than the MSM phase gains — and the optimum is flat beyond that.
       const double f = (double)head / nv, per_unit = work / f + up; // ms by which the head's end moves per unit of share
       const double margin = -0.30;
-      double f_new = f + 0.5 * ((double)gap - margin) / per_unit;
+      double f_new = f + 0.8 * ((double)gap - margin) / per_unit; // (0.8: per_unit is measured, the step lands near the target at once; the hysteresis below absorbs the jitter of the upload)
       if (f_new > 0.40) f_new = 0.40;
       // the share moves in whole upload chunks and only when it is off by most of one: a head of another size is another set of
       // workspace blocks (a fresh hipMalloc inside a prove when it grows)
