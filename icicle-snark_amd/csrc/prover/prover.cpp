@@ -411,7 +411,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     if (head) {
       // the head's kernels go to g2; the staging lanes of the upload are three of the streams with nothing to do before the whole
       // witness is there (QAP, H sort, C's own) — no extra stream, no extra hardware queue
-      const hipStream_t lanes[3] = {gq, g3, z->s_g5};
+      const hipStream_t lanes[3] = {gq, g3, z->s_g5}; // (two to five lanes measure the same: profiles/r04_upload_lanes.txt)
       StagedProgress prog;
       prog.head_bytes = (size_t)head * 32;
       int up_rc = 0, wait_rc = 0; // up_rc belongs to the uploader thread until it is joined
