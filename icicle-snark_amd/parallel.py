@@ -1,8 +1,9 @@
 """Multi-GPU decomposition of the prover: point-range sharding of the five MSM bases + one exchange step.
 
 One process per GPU (torchrun / torch.distributed gives rank, world size and the rendezvous).  Every rank
-builds a cache holding only its slice [rank·L/W, (rank+1)·L/W) of each base array (C++: upload_shard in
-csrc/prover/prover.cpp — `shard_range` below is the same arithmetic), runs the replicated QAP/NTT front end
+builds a cache holding only its range of each base array — the witness slice it uploads itself, [rank·⌈L/W⌉, (rank+1)·⌈L/W⌉), when that
+leaves no rank empty, else [rank·L/W, (rank+1)·L/W) — (C++: build_cache in
+csrc/prover/cache.cpp — `shard_range` below is the same arithmetic), runs the replicated QAP/NTT front end
 and its five partial MSMs, then all ranks all-gather their 576-byte commitment blocks and sum them with
 the group law.  The data-path collective is RCCL over xGMI (csrc/comm/rccl_comm.cpp) driven by this
 library's own HIP runtime; torch.distributed (gloo) is only the control plane that broadcasts the
@@ -42,6 +43,11 @@ def preload_rccl():
 
 
 def shard_range(total: int, rank: int, world: int):
+    """range of rank `rank` of `world` (csrc/prover/cache.cpp: build_cache): the slice of ⌈total / world⌉ elements the rank uploads
+    itself when that leaves no rank empty, else the even split"""
+    s = (total + world - 1) // world
+    if world > 1 and s * (world - 1) < total:
+        return min(total, s * rank), min(total, s * (rank + 1))
     return total * rank // world, total * (rank + 1) // world
 
 
