@@ -69,7 +69,7 @@ def test_two_rank_sharded_commitments_gloo():
         assert p.exitcode == 0
     assert [r[1] for r in res] == [True, True]
     assert [r[2] for r in res] == [2.0, 2.0]
-    assert res[0][3] == (0, 150) and res[1][3] == (150, 301)      # contiguous, disjoint, covering
+    assert res[0][3] == (0, 151) and res[1][3] == (151, 301)      # contiguous, disjoint, covering: rank r = the witness slice it uploads (⌈301 / 2⌉ wires)
 
 
 def test_shard_range_covers_everything():
@@ -81,4 +81,6 @@ def test_shard_range_covers_everything():
             edges = [P.shard_range(total, r, world) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == total
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
-            assert max(h - l for l, h in edges) - min(h - l for l, h in edges) <= 1
+            # every rank but the last takes ⌈total / world⌉ (its witness slice), the last one the rest: within `world` of each other
+            assert max(h - l for l, h in edges) - min(h - l for l, h in edges) < max(world, 2)
+            assert all(h > l for l, h in edges) or total < world * world
