@@ -9,10 +9,7 @@
 
 namespace isnark {
 
-#ifndef MSM_LARGE_CHUNK_CFG
-#define MSM_LARGE_CHUNK_CFG 1024
-#endif
-constexpr uint32_t MSM_LARGE_CHUNK = MSM_LARGE_CHUNK_CFG; // entries per work item of a large bucket (256 threads × 4 additions, then an 8-level tree; 4096 made the G2 chain 3× longer)
+constexpr uint32_t MSM_LARGE_CHUNK = 1024; // entries per work item of a large bucket (256 threads × 4 additions, then an 8-level tree; 4096 made the G2 chain 3× longer)
 
 struct MsmGeom {
   int c, W;      // digit width and digits per scalar

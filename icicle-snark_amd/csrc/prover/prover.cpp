@@ -35,10 +35,7 @@ namespace {
 // circuits with a domain (and witness) of up to this many elements start their witness MSMs right after the witness sort instead
 // of behind the QAP front end
 // (2^18 is 2-3 % better for the benchmark chain at 300-500 k constraints, 2^19 is 5 % better for the witness-light stand-in at 400 k)
-#ifndef ISNARK_EARLY_MAX_LOG
-#define ISNARK_EARLY_MAX_LOG 19
-#endif
-constexpr uint32_t EARLY_MAX_DEFAULT = 1u << ISNARK_EARLY_MAX_LOG;
+constexpr uint32_t EARLY_MAX_DEFAULT = 1u << 19;
 } // namespace
 
 namespace isnark {
