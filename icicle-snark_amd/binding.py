@@ -553,7 +553,10 @@ class CacheManager:
     def contains(self, key: str) -> bool:
         return bool(lib().groth16_cache_contains(self._h, key.encode()))
 
-    def load(self, key: str, zkey: bytes, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1):
+    def load(self, key: str, zkey: bytes, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1, wait_tables: bool = True):
+        """groth16_cache_load.  A single-device key is usable before its fixed-base tables exist (they are built behind the
+        first proofs); wait_tables=True (the default of this binding: tests and timings want the final layout) blocks until
+        they are adopted, wait_tables=False returns like the C entry point does."""
         # zero-copy views of the caller's buffer (a 0.8 GB zkey must not be duplicated on the way in)
         if isinstance(zkey, np.ndarray):
             p = zkey.ctypes.data_as(C.c_void_p)
@@ -562,6 +565,8 @@ class CacheManager:
         else:
             p = (C.c_char * len(zkey)).from_buffer(zkey)   # bytearray / writable memoryview
         _pcheck(lib().groth16_cache_load(self._h, key.encode(), p, C.c_size_t(len(zkey)), device_id, shard_rank, shard_count), "cache_load")
+        if wait_tables:
+            self.tables_ready(key, wait=True)
 
     def load_devices(self, key: str, zkey: bytes, device_ids):
         """one key over a GROUP of devices in this process (what groth16_prove builds for "HIP:0-7"): shard k lives on
@@ -573,11 +578,21 @@ class CacheManager:
     def set_budget(self, bytes_per_device: int):
         lib().groth16_cache_set_budget(self._h, C.c_uint64(bytes_per_device))
 
-    def load_file(self, key: str, path: str, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1):
+    def load_file(self, key: str, path: str, device_id: int = 0, shard_rank: int = 0, shard_count: int = 1, wait_tables: bool = True):
         _pcheck(lib().groth16_cache_load_file(self._h, key.encode(), path.encode(), device_id, shard_rank, shard_count), "cache_load_file")
+        if wait_tables:
+            self.tables_ready(key, wait=True)
 
     def evict(self, key: str):
         lib().groth16_cache_evict(self._h, key.encode())
+
+    def tables_ready(self, key: str, wait: bool = False) -> bool:
+        """deferred fixed-base tables of a single-device key (groth16_cache_tables_ready): True once the key proves in its
+        final layout; wait=True blocks until the build behind the first proofs has ended"""
+        rc = lib().groth16_cache_tables_ready(self._h, key.encode(), int(wait))
+        if rc < 0:
+            _pcheck(rc, "cache_tables_ready")
+        return rc == 1
 
     def info(self, key: str) -> CircuitInfo:
         ci = CircuitInfo()
@@ -672,7 +687,8 @@ groth16_cache_contains groth16_cache_evict groth16_commitments groth16_sum_commi
 groth16_prove_mem groth16_prove_resident groth16_cache_info groth16_last_error groth16_last_timings
 groth16_dist_supported groth16_dist_stage1 groth16_dist_stage2 groth16_dist_exchange_done groth16_upload_witness_slice
 groth16_witness_ready groth16_cache_load_devices groth16_parse_device groth16_cache_set_budget groth16_cache_info_sized
-groth16_verify groth16_verify_json groth16_verify_last_error groth16_group_describe
+groth16_verify groth16_verify_json groth16_verify_last_error groth16_group_describe groth16_cache_tables_ready
+groth16_cache_manager_prewarm
 """.split()
 
 

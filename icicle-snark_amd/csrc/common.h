@@ -35,6 +35,10 @@ void set_last_error(const char* fmt, ...);
 eIcicleError require_device();
 // `p` lies inside a block handed out by icicle_malloc{,_async} (the map behind icicle_is_active_device_memory)
 bool is_tracked_device_ptr(const void* p);
+// create on `dev`, ahead of the first cache load, what that load would pay for: the pinned staging pool and n_streams pooled
+// streams with their DMA queues set up (runtime.cpp); the device the calling thread would use, or −1 when none is chosen yet
+void prewarm_device(int dev, int n_streams);
+int default_device_or_none();
 // hand the blocks cached by icicle_free back to the driver (call before giving up on an allocation)
 void release_cached_device_memory();
 

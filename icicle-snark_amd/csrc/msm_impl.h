@@ -670,6 +670,95 @@ eIcicleError build_table_run(const void* d_points, uint32_t n, int from_form, co
   return ICICLE_SUCCESS;
 }
 
+// table[w·n + lo + i] = internal encoding of aff[w·cnt + i] (standard-form affine, identity (0,0) kept): the last step of a
+// SLICE of the table build below, out of the slice's compact temporaries into the rows of the full table
+template <class C>
+__global__ __launch_bounds__(256) void msm_table_place_kernel(const typename C::A* __restrict__ aff, uint32_t cnt, int W, typename C::A* __restrict__ table, uint32_t n, uint32_t lo)
+{
+  typedef typename Lazy<C>::type CL;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cnt * (uint32_t)W) return;
+  const uint32_t w = t / cnt, i = t - w * cnt;
+  typename C::A p = aff[t];
+  if (!C::aff_is_zero(p)) p = CL::store_affine_internal(CL::load_affine(p, 0, false));
+  table[(size_t)w * n + lo + i] = p;
+}
+
+// The same table in SLICES of the base array: rows → affine → internal encoding per slice of `slice` bases, with temporaries of
+// the slice's size (a whole-array build holds 2 GB (G1) / 5.3 GB (G2) of them at 1.6 M bases) and launches no larger than the
+// device holds at a time — what the prover's DEFERRED build needs (cache.cpp: the tables of a key are built behind its first
+// proofs, beside the proves that follow: a grid with queued workgroups would keep a hardware pipe busy for its whole length
+// and starve their short kernels, prover.cpp "head").  `cancel` is polled between slices (the key is evicted mid-build).
+// Everything is enqueued on s; returns after the stream has been synchronised.
+template <class C, class F>
+eIcicleError build_table_sliced_run(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table, uint32_t slice, const std::atomic<bool>* cancel)
+{
+  typedef typename C::A A;
+  typedef typename C::P P;
+  *d_table = nullptr;
+  const uint64_t m = (uint64_t)n * g.W;
+  A* table = nullptr;
+  HIP_TRY(hipMalloc((void**)&table, (m ? m : 1) * sizeof(A)), ICICLE_ALLOCATION_FAILED);
+  if (!n) {
+    *d_table = table;
+    return ICICLE_SUCCESS;
+  }
+  if (slice > n) slice = n;
+  const uint64_t ms = (uint64_t)slice * g.W;
+  P* rows = nullptr;
+  A* aff = nullptr;
+  typename F::T* scratch = nullptr;
+  auto cleanup = [&](bool with_table) {
+    (void)hipStreamSynchronize(s);
+    if (rows) (void)hipFree(rows);
+    if (aff) (void)hipFree(aff);
+    if (scratch) (void)hipFree(scratch);
+    if (with_table) (void)hipFree(table);
+  };
+  if (hipMalloc((void**)&rows, ms * sizeof(P)) != hipSuccess || hipMalloc((void**)&aff, ms * sizeof(A)) != hipSuccess || hipMalloc((void**)&scratch, ms * sizeof(typename F::T)) != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup(true);
+    return ICICLE_ALLOCATION_FAILED;
+  }
+  const int chunk = 32;
+  // one slice in flight and one queued: the stream never runs dry and the host is never far ahead of a cancel
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  (void)hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+  struct EvGuard {
+    hipEvent_t* e;
+    ~EvGuard()
+    {
+      for (int k = 0; k < 2; k++)
+        if (e[k]) (void)hipEventDestroy(e[k]);
+    }
+  } ev_guard{ev};
+  uint32_t k = 0;
+  for (uint32_t lo = 0; lo < n; lo += slice, k++) {
+    if (k >= 2 && ev[k & 1]) (void)hipEventSynchronize(ev[k & 1]); // slice k − 2 is done
+    if (cancel && cancel->load(std::memory_order_relaxed)) {
+      cleanup(true);
+      return ICICLE_UNKNOWN_ERROR;
+    }
+    const uint32_t cnt = n - lo < slice ? n - lo : slice;
+    const uint64_t mc = (uint64_t)cnt * g.W, nthreads = (mc + chunk - 1) / chunk;
+    hipLaunchKernelGGL((msm_table_rows_kernel<C>), dim3((cnt + 255) / 256), dim3(256), 0, s, (const A*)d_points + lo, cnt, from_form, g.c, g.W, g.wide, rows);
+    hipLaunchKernelGGL((batch_to_affine_kernel<C, F>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s, rows, mc, chunk, aff, scratch);
+    hipLaunchKernelGGL((msm_table_place_kernel<C>), dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, s, aff, cnt, g.W, table, n, lo);
+    const eIcicleError e = check_launch("msm_build_table (slice)");
+    if (e != ICICLE_SUCCESS) {
+      cleanup(true);
+      return e;
+    }
+    if (ev[k & 1]) (void)hipEventRecord(ev[k & 1], s);
+  }
+  const hipError_t he = hipStreamSynchronize(s);
+  cleanup(he != hipSuccess);
+  if (he != hipSuccess) return ICICLE_SYNCHRONIZATION_FAILED;
+  *d_table = table;
+  return ICICLE_SUCCESS;
+}
+
 template <class C>
 eIcicleError points_to_internal_run(void* d_points, uint32_t n, int from_form, hipStream_t s)
 {

@@ -107,6 +107,11 @@ eIcicleError msm_g2_points_to_internal(void* d_points, uint32_t n, int from_form
 // owned by the caller); `g` = msm_geometry(n_scalars, 0, 1) of the scalar vector the table will be used with.
 eIcicleError msm_g1_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
 eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table);
+// The same table built in slices of the base array (temporaries of a slice's size, no launch larger than the device holds at a
+// time, `cancel` polled between slices): the deferred build of a cached key's tables on a low-priority stream beside the
+// proves that already use the key (prover/cache.cpp).  Returns with stream s synchronised.
+eIcicleError msm_g1_build_table_sliced(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table, const std::atomic<bool>* cancel);
+eIcicleError msm_g2_build_table_sliced(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table, const std::atomic<bool>* cancel);
 // table mode: h_partials = [T | S_0 … S_{nbits−1}] (msm_partials_bytes gives nbits as *W)
 void msm_g1_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_projective_t* out);
 void msm_g2_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_g2_projective_t* out);

@@ -24,6 +24,11 @@ ZKeyCache::~ZKeyCache()
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
     (void)hipSetDevice(device_id);
+    // a table build still under way stops at its next slice; complete tables nobody adopted go with the key
+    tb.cancel.store(true);
+    if (tb.th.joinable()) tb.th.join();
+    for (void* t : tb.fresh)
+      if (t) (void)hipFree(t);
     if (s_qap) (void)hipStreamSynchronize(s_qap);
     if (s_g1) (void)hipStreamSynchronize(s_g1);
     if (s_g2) (void)hipStreamSynchronize(s_g2);
@@ -97,7 +102,91 @@ int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint
 } // namespace
 
 // CacheManager::compute — src/cache.rs:117-241
-int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out)
+// ---- deferred fixed-base tables (prover_internal.h: TableBuild) --------------------------------------------------------------
+namespace {
+void table_build_thread(ZKeyCache* z)
+{
+  TableBuild& tb = z->tb;
+  // behind the key's first proof, not beside it: a prove next to the build takes 24 instead of 19 ms at 1.6 M constraints, and
+  // the first one is the one a caller without a cache waits for.  A key nobody proves with gets its tables after the grace time.
+  for (int waited = 0; waited < TABLE_BUILD_GRACE_MS && !tb.go.load(std::memory_order_acquire) && !tb.cancel.load(); waited++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  const auto t0 = std::chrono::steady_clock::now();
+  bool ok = hipSetDevice(z->device_id) == hipSuccess;
+  hipStream_t s = nullptr;
+  if (ok) {
+    // the lowest stream priority: the build fills what the proves of the key (and of other keys) leave free
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
+      (void)hipGetLastError();
+      ok = false;
+    }
+  }
+  struct Job { const Shard* sh; bool g2; const MsmGeom* g; };
+  // H first: the longest of the five builds' G1 arrays; B2 (the G2 array, 60 % of the G1 four together) last
+  const Job jobs[5] = {{&z->A, false, &tb.gw}, {&z->B1, false, &tb.gw}, {&z->B2, true, &tb.gw}, {&z->C, false, &tb.gw}, {&z->H, false, &tb.gh}};
+  for (int k : {4, 0, 1, 3, 2}) {
+    if (!ok || tb.cancel.load()) {
+      ok = false;
+      break;
+    }
+    const Job& j = jobs[k];
+    // the bases are in the internal encoding already (form 2); the proves of the key only read them
+    const eIcicleError e = j.g2 ? msm_g2_build_table_sliced(j.sh->d_points, j.sh->len(), 2, *j.g, s, &tb.fresh[k], &tb.cancel)
+                                : msm_g1_build_table_sliced(j.sh->d_points, j.sh->len(), 2, *j.g, s, &tb.fresh[k], &tb.cancel);
+    if (e != ICICLE_SUCCESS) {
+      (void)hipGetLastError();
+      ok = false;
+      if (getenv("ICICLE_SNARK_VERBOSE") && !tb.cancel.load()) fprintf(stderr, "[icicle-snark-hip] deferred tables: build failed (%s); the key keeps the classic layout\n", icicle_snark_last_error());
+    }
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (!ok)
+    for (void*& t : tb.fresh) {
+      if (t) (void)hipFree(t);
+      t = nullptr;
+    }
+  tb.build_ms = ms_since(t0);
+  if (getenv("ICICLE_SNARK_TRACE_COLD")) fprintf(stderr, "[cold] deferred tables %s after %.1f ms\n", ok ? "complete" : "abandoned", tb.build_ms);
+  tb.state.store(ok ? 2 : 3, std::memory_order_release);
+}
+} // namespace
+
+int adopt_tables(ZKeyCache* z, bool wait)
+{
+  TableBuild& tb = z->tb;
+  int st = tb.state.load(std::memory_order_acquire);
+  if (st == 0) return 1;
+  if (st == 1) {
+    if (!wait) return 0;
+    if (tb.th.joinable()) tb.th.join();
+    st = tb.state.load(std::memory_order_acquire);
+  }
+  if (tb.th.joinable()) tb.th.join();
+  if (st == 2) {
+    // all five at once: pointers and both geometries change together, so no sort of one geometry ever meets tables of another.
+    // (synchronising frees: the caller holds the manager's mutex, nothing of this key is in flight and the build has ended)
+    Shard* sh5[5] = {&z->A, &z->B1, &z->B2, &z->C, &z->H};
+    for (int k = 0; k < 5; k++) {
+      (void)hipFree(sh5[k]->d_points);
+      sh5[k]->d_points = tb.fresh[k];
+      tb.fresh[k] = nullptr;
+      const MsmGeom& g = k == 4 ? tb.gh : tb.gw;
+      z->device_bytes += (uint64_t)sh5[k]->len() * (g.W - 1) * (k == 2 ? 128 : 64);
+    }
+    z->geom_w = tb.gw;
+    z->geom_h = tb.gh;
+    z->geom_w_default_c = tb.gw.c;
+    // what the classic proves measured (entries of 16-bit digits) says nothing about the table digits: the witness-driven
+    // digit width (rebuild_witness_tables) starts over from the first table-mode prove
+    z->witness_entries = 0;
+    z->proves_since_rebuild = 0;
+  }
+  tb.state.store(0, std::memory_order_release);
+  return 1;
+}
+
+int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out, bool defer_tables)
 {
   if (count < 1 || rank < 0 || rank >= count) return fail(ERR_ARG, "bad shard %d/%d", rank, count);
   const bool trace = getenv("ICICLE_SNARK_TRACE_COLD") != nullptr;
@@ -168,6 +257,18 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   strcpy(dev.type, "HIP");
   dev.id = device_id;
   P_ICICLE(icicle_set_device(&dev));
+  // six streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
+  // Stream priorities were tried (QAP chain high, G2 low, …): every variant was 1-2 ms slower than equal priorities.
+  // Created BEFORE the ingest, which uses them as its lanes: a fresh stream costs ≈ 4 ms to create and its first host→device
+  // copy sets up its DMA queue (another 3 ms) — the eight short-lived upload streams of rounds 1–4 paid both on every cold
+  // load (≈ 35 ms of a 57 ms upload at 1.6 M constraints), and the key's own streams then paid them again.
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_qap)); // QAP front end (its own hardware queue; a higher stream priority made no difference)
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g4));
+  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g5));
+  lap("six streams");
   // device CSR built by kernels from the raw records (prover/csr.hip); the records travel with the points below
   uint32_t* d_records = nullptr;
   const size_t rec_bytes = (size_t)n_coef * rec;
@@ -224,7 +325,10 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     z->device_bytes += (size_t)m * 64;
   } else if (int rc = alloc_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes, jobs)) return rc;
   lap("point buffers (hipMalloc)");
-  if (int rc = staged_upload(device_id, jobs)) return rc;
+  {
+    const hipStream_t lanes[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
+    if (int rc = staged_upload(device_id, jobs, lanes, 6)) return rc;
+  }
   if (h_strided) {
     P_HIP(qap_gather_strided((const fe*)h_full, (fe*)z->H.d_points, 2, z->H.len(), z->H.stride, z->H.first, nullptr));
     P_HIP(hipStreamSynchronize(nullptr));
@@ -260,6 +364,17 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
         z->geom_h = msm_geometry(z->H.len(), 0, 0);
       }
     }
+    const bool defer_env = !(getenv("ICICLE_SNARK_DEFER_TABLES") && atoi(getenv("ICICLE_SNARK_DEFER_TABLES")) == 0);
+    const bool defer = tables && defer_tables && defer_env && count == 1;
+    if (defer) {
+      // the key proves in the classic layout until the worker thread (started at the end of this function) has built the
+      // tables of these geometries; adopt_tables swaps them in
+      z->tb.gw = z->geom_w;
+      z->tb.gh = z->geom_h;
+      z->geom_w = msm_geometry(z->A.len(), 0, 0);
+      z->geom_h = msm_geometry(z->H.len(), 0, 0);
+      z->tb.state.store(1);
+    }
     struct Job { Shard* sh; bool g2; const MsmGeom* g; };
     const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_w}, {&z->B2, true, &z->geom_w}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
     for (const Job& j : jobs5) {
@@ -287,20 +402,11 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   z->h_stats[0] = z->h_stats[1] = 0;
   z->geom_w_default_c = z->geom_w.c;
   z->device_bytes += (size_t)z->n_vars * 32 + (size_t)n * 96;
-  // six streams; the library asks the runtime for eight hardware queues so that they do not share one (runtime.cpp).
-  // Stream priorities were tried (QAP chain high, G2 low, …): every variant was 1-2 ms slower than equal priorities.
-  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_qap)); // QAP front end (its own hardware queue; a higher stream priority made no difference)
-  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g1));
-  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g2));
-  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
-  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g4));
-  P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g5));
   {
-    // the first host→device copy on a stream sets up its DMA queue (milliseconds, measured 20 ms over six streams): do
-    // it here, not inside the first prove that brings a new witness
+    // the first host→device copy on a stream sets up its DMA queue (milliseconds, measured 20 ms over six streams): the
+    // ingest above has done that for every stream it used as a lane; a key of a few chunks leaves some untouched
     const hipStream_t all[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
-    for (int rep = 0; rep < 2; rep++)
-      for (hipStream_t st : all) P_HIP(hipMemcpyAsync(z->d_partials, z->h_partials, 4096, hipMemcpyHostToDevice, st));
+    for (hipStream_t st : all) P_HIP(hipMemcpyAsync(z->d_partials, z->h_partials, 4096, hipMemcpyHostToDevice, st));
     for (hipStream_t st : all) P_HIP(hipStreamSynchronize(st));
   }
   P_HIP(hipEventCreateWithFlags(&z->ev_witness, hipEventDisableTiming));
@@ -314,8 +420,16 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipEventCreate(&z->ev_t_witness));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
   for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  lap("work buffers, streams, events");
+  lap("work buffers, events");
   out = std::move(z);
+  // (the entry does not move any more: the worker keeps a pointer to it and ~ZKeyCache joins the worker)
+  if (out->tb.state.load() == 1) {
+    try {
+      out->tb.th = std::thread(table_build_thread, out.get());
+    } catch (...) {
+      out->tb.state.store(0); // no thread to be had: the key keeps the classic layout
+    }
+  }
   return 0;
 }
 

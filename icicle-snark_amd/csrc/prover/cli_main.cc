@@ -16,6 +16,12 @@ static void print_help()
 int main()
 {
   Groth16CacheManager* cm = groth16_cache_manager_new();
+  {
+    // the device the first `prove` will most likely name ("HIP" → device 0, or the first of ICICLE_SNARK_DEVICES): its streams
+    // and staging buffers are created while the worker waits for its first command
+    int ids[1] = {0};
+    if (groth16_parse_device("HIP", ids, 1) >= 1) groth16_cache_manager_prewarm(cm, ids[0]);
+  }
   std::string line;
   for (;;) {
     std::cout << "> " << std::flush;

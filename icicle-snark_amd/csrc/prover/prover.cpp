@@ -43,24 +43,25 @@ namespace prover {
 // get_cache — src/cache.rs:242-256: (re)initialise the NTT domain of the entry's device for this key.  Sized 2·domain_size
 // here (see file header); the reference sizes it from points_a.len() (a quirk).  Works on the calling thread's
 // active device, which the caller has set to z->device_id.
-int ensure_domain(Groth16CacheManager* cm, const ZKeyCache* z)
+int ensure_domain_for(Groth16CacheManager* cm, int device_id, uint32_t domain_size)
 {
   static std::mutex dom_mu; // the prover threads of a device group come here concurrently (and may share a device)
   std::lock_guard<std::mutex> lk(dom_mu);
-  auto it = cm->domain_n.find(z->device_id);
-  if (it != cm->domain_n.end() && it->second == z->domain_size) {
+  auto it = cm->domain_n.find(device_id);
+  if (it != cm->domain_n.end() && it->second == domain_size) {
     int lg = 0;
-    if (ntt_domain_table(&lg) && (1u << lg) >= 2 * z->domain_size) return 0;
+    if (ntt_domain_table(&lg) && (1u << lg) >= 2 * domain_size) return 0;
   }
   P_ICICLE(bn254_ntt_release_domain());
   bn254_scalar_t root;
-  P_ICICLE(bn254_get_root_of_unity(2ull * z->domain_size, &root));
+  P_ICICLE(bn254_get_root_of_unity(2ull * domain_size, &root));
   NTTInitDomainConfig ic;
   memset(&ic, 0, sizeof ic);
   P_ICICLE(bn254_ntt_init_domain(&root, &ic));
-  cm->domain_n[z->device_id] = z->domain_size;
+  cm->domain_n[device_id] = domain_size;
   return 0;
 }
+int ensure_domain(Groth16CacheManager* cm, const ZKeyCache* z) { return ensure_domain_for(cm, z->device_id, z->domain_size); }
 
 std::shared_ptr<ZKeyCache> find(Groth16CacheManager* cm, const char* key)
 {
@@ -121,11 +122,30 @@ extern "C" {
 
 __attribute__((visibility("default"))) const char* groth16_last_error(void) { return last_error_text(); }
 
+extern "C" __attribute__((visibility("default"))) void groth16_cache_manager_prewarm(Groth16CacheManager* cm, int device_id);
 __attribute__((visibility("default"))) Groth16CacheManager* groth16_cache_manager_new(void)
 {
   Groth16CacheManager* cm = new Groth16CacheManager();
   if (const char* b = getenv("ICICLE_SNARK_CACHE_BUDGET_MB")) cm->budget_bytes = (uint64_t)atoll(b) << 20;
+  // a device is already chosen (icicle_set_device before the manager, like src/lib.rs:25-31 before :44): what the first cache
+  // load needs of it — six streams with their DMA queues, the pinned staging pool — is created now, on a helper thread
+  const int dev = default_device_or_none();
+  if (dev >= 0) groth16_cache_manager_prewarm(cm, dev);
   return cm;
+}
+// The same for a caller that knows its device before it has made it current (the REPL at start-up).  Returns at once; the
+// first cache load of the manager waits for the helper thread.
+__attribute__((visibility("default"))) void groth16_cache_manager_prewarm(Groth16CacheManager* cm, int device_id)
+{
+  if (!cm || device_id < 0) return;
+  std::lock_guard<std::mutex> lk(cm->mu);
+  if (cm->warm.joinable()) return;
+  static const bool off = getenv("ICICLE_SNARK_PREWARM") && atoi(getenv("ICICLE_SNARK_PREWARM")) == 0;
+  if (off) return;
+  try {
+    cm->warm = std::thread([device_id] { prewarm_device(device_id, 6); });
+  } catch (...) {
+  }
 }
 __attribute__((visibility("default"))) void groth16_cache_manager_free(Groth16CacheManager* cm) { delete cm; }
 __attribute__((visibility("default"))) void groth16_cache_set_budget(Groth16CacheManager* cm, uint64_t bytes_per_device)
@@ -169,9 +189,31 @@ __attribute__((visibility("default"))) int groth16_cache_load(Groth16CacheManage
   if (!cm || !key || !zkey) return fail(ERR_ARG, "null argument");
   std::lock_guard<std::mutex> lk(cm->mu);
   if (find(cm, key) || find_group(cm, key)) return 0;
+  if (cm->warm.joinable()) cm->warm.join(); // (what it creates is what the build below would create itself)
   evict_for_budget(cm, device_id, estimate_entry_bytes(zkey_len) / (uint64_t)(shard_count > 0 ? shard_count : 1));
   std::unique_ptr<ZKeyCache> z;
-  if (int rc = build_cache((const uint8_t*)zkey, zkey_len, device_id, shard_rank, shard_count, z)) return rc;
+  // The NTT domain of the key (twiddle tables of 2·domain_size roots: 9–13 ms at 1.6 M constraints) is set up on a helper
+  // thread WHILE the sections cross PCIe — the GPU has nothing else to do then — instead of inside the first prove.
+  uint32_t dom_n = 0;
+  {
+    std::vector<Section> secs;
+    const Section* s2 = nullptr;
+    if (read_sections((const uint8_t*)zkey, zkey_len, "zkey", 2, secs) == 0 && unique_section(secs, 2, &s2) == 0 && s2->size >= 84) memcpy(&dom_n, s2->p + 80, 4);
+    if (dom_n == 0 || (dom_n & (dom_n - 1)) || dom_n > (1u << 27)) dom_n = 0; // (a malformed header is build_cache's to report)
+  }
+  std::thread dom_th;
+  if (dom_n && shard_count == 1) {
+    try {
+      dom_th = std::thread([cm, device_id, dom_n] {
+        if (set_active_device(device_id) == 0) (void)ensure_domain_for(cm, device_id, dom_n); // a failure here is found again by the prove
+      });
+    } catch (...) {
+    }
+  }
+  // the fixed-base tables of a single-device key are built behind its first proofs (cache.cpp: TableBuild)
+  const int brc = build_cache((const uint8_t*)zkey, zkey_len, device_id, shard_rank, shard_count, z, /*defer_tables=*/true);
+  if (dom_th.joinable()) dom_th.join();
+  if (brc) return brc;
   std::lock_guard<std::mutex> lm(cm->map_mu);
   z->last_use = ++cm->clock;
   cm->cache[key] = std::shared_ptr<ZKeyCache>(z.release());
@@ -253,6 +295,28 @@ __attribute__((visibility("default"))) int groth16_cache_info_sized(const Groth1
   return 0;
 }
 
+// Deferred tables of a single-device key: 1 = the key proves in its final layout (tables adopted, or none coming), 0 = the
+// worker thread is still building them (proves meanwhile run the classic layout: same proofs, ≈ 20 % slower at 1.6 M
+// constraints).  `wait` != 0 blocks until the build has ended and adopts the tables (bench.py, tests: a warm measurement
+// starts from here).  Device groups build their tables at load: always 1.
+__attribute__((visibility("default"))) int groth16_cache_tables_ready(Groth16CacheManager* cm, const char* key, int wait)
+{
+  if (!cm) return fail(ERR_ARG, "null argument");
+  if (find_group(cm, key)) return 1;
+  const std::shared_ptr<ZKeyCache> zp = find(cm, key);
+  if (!zp) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
+  if (zp->tb.state.load(std::memory_order_acquire) == 0) return 1;
+  if (!wait && zp->tb.state.load(std::memory_order_acquire) == 1) return 0;
+  if (wait) zp->tb.go.store(true, std::memory_order_release); // somebody waits for the tables: no point in the build waiting for a first prove
+  std::lock_guard<std::mutex> lk(cm->mu);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (int rc = set_active_device(zp->device_id)) return rc;
+  const int r = adopt_tables(zp.get(), wait != 0);
+  if (prev >= 0) (void)set_active_device(prev);
+  return r;
+}
+
 // What a device-group key runs on, as one line of JSON: {"shards", "devices", "distinct_devices", "transport": "pull" | "memcpy" |
 // "rccl", "peer_access", "rccl_ranks" (0 unless the rccl transport moves the exchanges), "distributed_front_end", …}.  A
 // single-device key answers {"shards": 0, "devices": [id]}.  Returns 0, or the size needed (incl. NUL) when `cap` is too small.
@@ -289,8 +353,15 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
 {
   if (!wtns && !z->witness_resident) return fail(ERR_ARG, "no witness given and none resident on the device");
   const auto t0 = std::chrono::steady_clock::now();
+  static const bool trace_host = getenv("ICICLE_SNARK_TRACE_HOST") != nullptr;
+  auto mark = [&](const char* what) {
+    if (trace_host) fprintf(stderr, "[host] %-12s %8.1f us\n", what, ms_since(t0) * 1e3);
+  };
   if (int rc = set_active_device(z->device_id)) return rc;
   if (int rc = ensure_domain(cm, z)) return rc;
+  mark("domain");
+  // deferred fixed-base tables (cache.cpp): complete → this prove is the first to use them; still building → classic layout
+  (void)adopt_tables(z, false);
   // the key follows its witnesses: a digit width at least two bits off the one the last witness called for → rebuild the four
   // witness tables now, at most once every eight proves.  On one device nothing of this prove is enqueued yet; in a device group
   // the front end and the exchanges of this shard already are (multi.cpp) — they do not touch the tables, and the rebuild's
@@ -302,11 +373,6 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       z->proves_since_rebuild = 0;
     }
   }
-  static const bool trace_host = getenv("ICICLE_SNARK_TRACE_HOST") != nullptr;
-  auto mark = [&](const char* what) {
-    if (trace_host) fprintf(stderr, "[host] %-12s %8.1f us\n", what, ms_since(t0) * 1e3);
-  };
-
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
   hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3, gq = z->s_qap;
   double h2d_host_ms = 0;
@@ -483,6 +549,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       if (int rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, 3)) return rc;
     }
     h2d_host_ms = ms_since(tu);
+    mark("witness in");
     if (!pinned_src) P_HIP(hipEventRecord(z->ev_witness, gq)); // (the staged upload has returned: every byte is there)
     z->witness_event_set = true;
   } else
@@ -698,6 +765,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // (the stats copies sit on g2 / g3 in front of work whose ev_done a tail thread has waited for)
   z->witness_entries = (uint64_t)z->h_stats[0] + z->h_stats[1] + z->h_stats[2] + z->h_stats[3];
   z->proves_since_rebuild++;
+  z->tb.go.store(true, std::memory_order_release); // deferred tables: the key's first proof is out, the build may start
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_head);
   msm_sort_release(&plan_h);

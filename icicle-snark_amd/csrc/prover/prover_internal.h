@@ -85,6 +85,21 @@ struct Shard {
   uint32_t len() const { return hi - lo; }
 };
 
+// Deferred build of a key's fixed-base tables (cache.cpp).  The tables cost 0.26 s at 1.6 M constraints and buy 2–3 ms per
+// prove: a key is therefore usable — in the classic layout, bases converted in place — as soon as its sections are on the
+// device, and a worker thread builds the five tables on a low-priority stream behind (and beside) the first proofs.  The prove
+// that finds them complete swaps pointers and geometry in, all five at once (adopt_tables; the caller holds the manager's mutex).
+constexpr int TABLE_BUILD_GRACE_MS = 150;
+struct TableBuild {
+  std::thread th;
+  std::atomic<int> state{0}; // 0 nothing pending, 1 building, 2 complete (fresh[] valid, not adopted yet), 3 failed / cancelled
+  std::atomic<bool> cancel{false};
+  std::atomic<bool> go{false}; // set at the end of the key's first prove: the build starts behind it, not beside it (or after TABLE_BUILD_GRACE_MS without one)
+  void* fresh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // A, B1, B2, C, H
+  MsmGeom gw, gh;            // the table geometries the build works towards
+  double build_ms = 0;       // wall clock of the build (beside whatever proves ran meanwhile)
+};
+
 struct ZKeyCache {
   // header — src/zkey.rs:6-21
   uint32_t n8q = 0, n8r = 0, n_vars = 0, n_public = 0, domain_size = 0, n_coef = 0;
@@ -133,6 +148,7 @@ struct ZKeyCache {
   Groth16Timings last_tm = {0, 0, 0, 0}; // phase timings of the most recent prove (groth16_last_timings)
   MsmProfile prof[5] = {};               // A, B1, B2, C, H of the most recent prove: this entry's own slots (the shards of a group may share a device)
   uint64_t last_use = 0;                 // CacheManager LRU clock
+  TableBuild tb;                         // deferred fixed-base tables (single-device keys)
 
   ~ZKeyCache();
 };
@@ -144,8 +160,13 @@ inline uint64_t witness_slice_elems(uint32_t n_vars, int count) { return ((uint6
 int witness_digit_target(const ZKeyCache* z, uint64_t entries);
 int rebuild_witness_tables(ZKeyCache* z, int c_new);
 
-// CacheManager::compute — src/cache.rs:117-241
-int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out);
+// deferred tables: 1 = the key proves with its tables (or has none coming: classic layout for good), 0 = still building.
+// `wait`: block until the build has ended.  Swaps complete tables in; the caller holds the manager's mutex (no prove in flight).
+int adopt_tables(ZKeyCache* z, bool wait);
+
+// CacheManager::compute — src/cache.rs:117-241.  `defer_tables`: return once the key can prove in the classic layout and build
+// the fixed-base tables on a worker thread (single-device keys; ICICLE_SNARK_DEFER_TABLES=0 builds them before returning)
+int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out, bool defer_tables = false);
 typedef CopyJob UploadJob;
 int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in = nullptr, int n_lanes = 0, StagedProgress* progress = nullptr);
 
@@ -186,6 +207,11 @@ struct Groth16CacheManager {
   std::map<int, uint32_t> domain_n; // device → domain_size its NTT domain was last initialised for (get_cache, src/cache.rs:242-256)
   uint64_t clock = 0;               // LRU clock (last_use of the entries)
   uint64_t budget_bytes = 0;        // device-memory budget per device for cached keys (0 = none): least recently used keys are evicted
+  std::thread warm;                 // prewarm_device on the device the manager was created for (joined by the first cache load and by free)
+  ~Groth16CacheManager()
+  {
+    if (warm.joinable()) warm.join();
+  }
 };
 
 namespace isnark {
@@ -194,6 +220,7 @@ std::shared_ptr<ZKeyCache> find(Groth16CacheManager* cm, const char* key);
 std::shared_ptr<DeviceGroup> find_group(Groth16CacheManager* cm, const char* key);
 int set_active_device(int device_id);
 int ensure_domain(Groth16CacheManager* cm, const ZKeyCache* z); // works on the calling thread's active device (= z->device_id)
+int ensure_domain_for(Groth16CacheManager* cm, int device_id, uint32_t domain_size);
 void evict_for_budget(Groth16CacheManager* cm, int device, uint64_t need);
 // the shard pipeline of one device; caller holds cm->mu.  wtns == NULL: the witness (and, with z->dist_ready, the Z rows) are resident
 int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, size_t wtns_len, uint8_t* out_points, Groth16Timings* tm, EarlyTerms* et);

@@ -158,6 +158,22 @@ void staged_copy_file_hint_get(const void** base, size_t* len, int* fd)
   *fd = t_file_fd;
 }
 
+// pinned staging buffers and events of a device's pool (once; the caller holds P.mu and has made the device current)
+static hipError_t staged_pool_init(StagedPool& P)
+{
+  if (P.pinned) return hipSuccess;
+  hipError_t e0;
+  uint8_t* pinned = nullptr;
+  if ((e0 = hipHostMalloc((void**)&pinned, STAGED_LANES * 2 * STAGED_CHUNK, hipHostMallocPortable)) != hipSuccess) return e0;
+  for (int t = 0; t < STAGED_LANES; t++)
+    for (int k = 0; k < 2; k++)
+      if (!P.events[t][k] && (e0 = hipEventCreateWithFlags(&P.events[t][k], hipEventDisableTiming)) != hipSuccess) return e0;
+  for (int t = 0; t < STAGED_LANES; t++)
+    if (!P.head_ev[t] && (e0 = hipEventCreateWithFlags(&P.head_ev[t], hipEventDisableTiming)) != hipSuccess) return e0;
+  P.pinned = pinned;
+  return hipSuccess;
+}
+
 hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes_in, int n_lanes, bool own_temp_streams, StagedProgress* progress)
 {
   const uint8_t* const file_base = t_file_base;
@@ -168,14 +184,7 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
   std::lock_guard<std::mutex> lk(P.mu);
   hipError_t e0 = hipSetDevice(device_id);
   if (e0 != hipSuccess) return e0;
-  if (!P.pinned) {
-    if ((e0 = hipHostMalloc((void**)&P.pinned, STAGED_LANES * 2 * STAGED_CHUNK, hipHostMallocPortable)) != hipSuccess) return e0;
-    for (int t = 0; t < STAGED_LANES; t++)
-      for (int k = 0; k < 2; k++)
-        if ((e0 = hipEventCreateWithFlags(&P.events[t][k], hipEventDisableTiming)) != hipSuccess) return e0;
-    for (int t = 0; t < STAGED_LANES; t++)
-      if ((e0 = hipEventCreateWithFlags(&P.head_ev[t], hipEventDisableTiming)) != hipSuccess) return e0;
-  }
+  if ((e0 = staged_pool_init(P)) != hipSuccess) return e0;
   // chunk size: 2 MB.  Smaller chunks for transfers of a few tens of MB (shorter pipeline fill) were measured on the 51 MB
   // witness of benchmark/1600k and are slower — 1 MB: +0.05 ms, 512 KB: +0.3 ms, 256 KB: +0.8 ms per prove (per-DMA cost);
   // two to five staging lanes make no difference either (17.3–17.5 ms): ≈ 1.3 ms for 51 MB is what this path costs
@@ -1000,6 +1009,52 @@ ISNARK_API eIcicleError icicle_destroy_stream(icicleStreamHandle stream)
   HIP_TRY(hipStreamDestroy((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
   return ICICLE_SUCCESS;
 }
+namespace isnark {
+// What the first cache load of a process would otherwise pay inside its first prove (measured on MI355X: 48 ms for six
+// streams and their DMA queues, ≈ 10 ms for the pinned staging pool): create it ahead of time on `dev` — the prover host
+// calls this from a helper thread when its CacheManager is created (prover.cpp).  Streams go to the pool icicle_create_stream
+// draws from; each has carried one host→device copy, which is what sets up its DMA queue.
+void prewarm_device(int dev, int n_streams)
+{
+  if (dev < 0 || dev >= STAGED_DEVICES || hipSetDevice(dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  {
+    StagedPool& P = g_staged[dev];
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (staged_pool_init(P) != hipSuccess) (void)hipGetLastError();
+  }
+  size_t have = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_sp_mu);
+    have = g_stream_pool[dev].size();
+  }
+  void* d = nullptr;
+  if (hipMalloc(&d, 4096) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  std::vector<hipStream_t> fresh;
+  for (size_t k = have; k < (size_t)n_streams && k < STREAM_POOL_MAX; k++) {
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+    (void)hipMemcpyAsync(d, g_staged[dev].pinned ? (void*)g_staged[dev].pinned : d, 4096, g_staged[dev].pinned ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st);
+    fresh.push_back(st);
+  }
+  for (hipStream_t st : fresh) (void)hipStreamSynchronize(st);
+  (void)hipFree(d);
+  (void)hipGetLastError();
+  std::lock_guard<std::mutex> lk(g_sp_mu);
+  std::vector<hipStream_t>& v = g_stream_pool[dev];
+  for (hipStream_t st : fresh) {
+    if (v.size() < STREAM_POOL_MAX) v.push_back(st);
+    else (void)hipStreamDestroy(st);
+  }
+}
+int default_device_or_none() { return active_device(); }
+} // namespace isnark
+
 ISNARK_API eIcicleError icicle_stream_synchronize(icicleStreamHandle stream)
 {
   ICICLE_TRY(require_device());

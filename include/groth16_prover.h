@@ -28,6 +28,11 @@ typedef struct Groth16CacheManager Groth16CacheManager;
 /* CacheManager::default() / drop — src/cache.rs:110-115 */
 Groth16CacheManager* groth16_cache_manager_new(void);
 void groth16_cache_manager_free(Groth16CacheManager* cm);
+/* Optional: create on `device_id`, on a helper thread, what the first cache load of a process would otherwise pay for inside
+ * its first prove (six streams with their DMA queues: 48 ms measured, the pinned staging pool).  groth16_cache_manager_new
+ * does this by itself when a device has been made current before it (icicle_set_device); the REPL calls it at start-up.
+ * ICICLE_SNARK_PREWARM=0 switches it off. */
+void groth16_cache_manager_prewarm(Groth16CacheManager* cm, int device_id);
 
 /* groth16_prove — src/lib.rs:33-61.  `device` is the reference's free-form device string (the reference passes the type
  * and always uses id 0, src/lib.rs:25-31); this library registers "HIP" (and the alias "CUDA"); anything else, including
@@ -50,6 +55,12 @@ int groth16_cache_load(Groth16CacheManager* cm, const char* key, const void* zke
                        int shard_rank, int shard_count);
 int groth16_cache_load_file(Groth16CacheManager* cm, const char* key, const char* zkey_path, int device_id,
                             int shard_rank, int shard_count);
+/* A single-device key is usable as soon as its sections are on the device: the first proofs run the classic bucket layout
+ * while a worker thread builds the key's fixed-base tables (13 instead of 16 digits per scalar; 0.26 s of GPU work at 1.6 M
+ * constraints) on a low-priority stream, and the first prove that finds them complete adopts them.  Proofs are identical
+ * either way.  Returns 1 when the key proves in its final layout, 0 while the build is under way, negative on error;
+ * wait != 0 blocks until the build has ended.  ICICLE_SNARK_DEFER_TABLES=0 builds the tables inside groth16_cache_load. */
+int groth16_cache_tables_ready(Groth16CacheManager* cm, const char* key, int wait);
 /* The same key over a GROUP of devices (what groth16_prove builds for "HIP:a-b"): shard k of n_devices lives on
  * device_ids[k].  Every entry point that takes a key (groth16_commitments, groth16_prove_mem, groth16_prove_resident,
  * groth16_cache_info, groth16_last_timings, groth16_cache_evict) then works on the group: groth16_commitments returns the
