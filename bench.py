@@ -48,9 +48,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# every kernel msm_sort_run launches (csrc/msm_sort.hip): recode + counting sort + the bucket order by size
 SORT_KERNELS = ("msm_zero_kernel", "msm_coarse_hist_kernel", "msm_part_scan_kernel", "msm_partition_kernel", "msm_fine_count_kernel",
                 "msm_fine_place_kernel", "sort2_tile_hist_kernel", "sort2_col_sum_kernel", "sort2_col_base_kernel", "sort2_col_apply_kernel",
-                "sort2_tile_partition_kernel", "sort2_chunk_hist_kernel", "sort2_bucket_scan_kernel", "sort2_chunk_place_kernel")
+                "sort2_tile_partition_kernel", "sort2_chunk_hist_kernel", "sort2_bucket_scan_kernel", "sort2_chunk_place_kernel",
+                "msm_hist_kernel", "msm_scan_sums_kernel", "msm_scan_top_kernel", "msm_scan_finish_kernel", "msm_scan_apply_kernel",
+                "msm_scatter_kernel", "msm_order_hist_kernel", "msm_order_scatter_kernel")
 
 
 def log(*a):
@@ -155,8 +158,7 @@ def pmc_child(workload):
 
 def _pmc_pass(counter, workload, outdir, timeout, extra=()):
     """one rocprofv3 PMC pass (counters in a pass of their own, --kernel-trace only, the program directly after `--`) over the
-    PMC child → {kernel family: [per-dispatch sums of `counter` in dispatch order]}; `extra`: further counters of the same pass,
-    returned under the key (family, name)"""
+    PMC child → the rows of its counter_collection.csv files (dicts: Dispatch_Id, Kernel_Name, Counter_Name, Counter_Value)"""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     env = dict(os.environ, TMPDIR="/tmp", ICICLE_SNARK_QUIET="1")
     cmd = [exe, "--kernel-trace", "--pmc", counter, *extra, "--output-format", "csv", "-d", outdir, "--",
@@ -164,39 +166,123 @@ def _pmc_pass(counter, workload, outdir, timeout, extra=()):
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr[-300:]}")
-    per = {}   # kernel family -> list of per-dispatch sums in dispatch order
     files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise RuntimeError("rocprofv3 wrote no counter_collection.csv")
+    rows = []
     for fn in files:
-        agg = {}
-        for row in csv.DictReader(open(fn)):
-            if row["Counter_Name"] != counter and row["Counter_Name"] not in extra:
-                continue
-            name = row["Kernel_Name"]
-            fam = None
-            if "msm_accumulate_kernel" in name:
-                fam = "acc_g2" if "Fq2" in name or "G2" in name else "acc_g1"
-            else:
-                for k in SORT_KERNELS:
-                    if k in name:
-                        fam = k
-                        break
-            if fam is None:
-                continue
-            if row["Counter_Name"] != counter:
-                fam = (fam, row["Counter_Name"])
-            a = agg.setdefault((fam, int(row["Dispatch_Id"])), 0.0)
-            agg[(fam, int(row["Dispatch_Id"]))] = a + float(row["Counter_Value"])   # per-XCD rows of one dispatch
-        for (fam, did), v in sorted(agg.items(), key=lambda kv: kv[0][1]):
-            per.setdefault(fam, []).append(v)
-    return per
+        rows += list(csv.DictReader(open(fn)))
+    return rows
+
+
+# ---- pure functions over counter_collection.csv rows (tests/test_bench_pmc.py feeds them canned rows) --------------------------
+PMC_PROVES = 3   # proves in the PMC child
+
+
+def pmc_dispatches(rows, counter):
+    """rows of one pass → [(dispatch id, kernel name, Σ of `counter` over the per-XCD rows of the dispatch)] in dispatch order
+    (= the order the host enqueued the kernels: the profiler serialises them)"""
+    agg = {}
+    for row in rows:
+        if row["Counter_Name"] != counter:
+            continue
+        k = (int(row["Dispatch_Id"]), row["Kernel_Name"])
+        agg[k] = agg.get(k, 0.0) + float(row["Counter_Value"])
+    return [(did, name, v) for (did, name), v in sorted(agg.items())]
+
+
+def sort_family(name):
+    for k in SORT_KERNELS:
+        if k in name:
+            return k
+    return None
+
+
+def sort_instances(dispatches):
+    """the digit sorts of a dispatch stream: msm_sort_run enqueues all kernels of ONE sort back to back, beginning with
+    msm_zero_kernel (one or two of them) → a list of sorts, each a list of (family, value) in launch order"""
+    inst, prev_zero = [], False
+    for _, name, v in dispatches:
+        fam = sort_family(name)
+        if fam is None:
+            continue
+        zero = fam == "msm_zero_kernel"
+        if zero and not prev_zero:
+            inst.append([])
+        if not inst:
+            inst.append([])   # (a stream that does not begin with a zero kernel: keep what there is)
+        inst[-1].append((fam, v))
+        prev_zero = zero
+    return inst
+
+
+def sorts_of_last_prove(dispatches, n_proves=PMC_PROVES):
+    """→ (witness sorts, H sort) of the LAST prove: a prove runs two digit sorts (witness, H) or three when the witness is split
+    into a head and a tail (prover.cpp, round 4) — the H sort is the last one of a prove.  None when the stream does not divide."""
+    inst = sort_instances(dispatches)
+    if not inst or len(inst) % n_proves:
+        return None
+    per = len(inst) // n_proves
+    if per not in (2, 3):
+        return None
+    last = inst[-per:]
+    return last[:-1], last[-1]
+
+
+# FETCH_SIZE on gfx950 (MI355X guide, HBM section: "calibrate on a known byte count in your own access pattern"): the raw counter
+# reads 0.500 of a coalesced 16 B/lane stream, 1.494 of random 64-byte gathers, 1.105 of random 128-byte gathers; WRITE_SIZE 1.000 of
+# coalesced stores (profiles/r02_pmc_calibration.txt, csrc/microbench.hip probes)
+FETCH_CAL = {"stream": 0.5, "gather64": 1.494, "gather128": 1.105}
+
+
+def pmc_summary(fetch_rows, write_rows, sq_rows=None, n_proves=PMC_PROVES):
+    """HBM traffic per launch from the FETCH_SIZE and WRITE_SIZE passes (both in KB) of the PMC child:
+    acc_h   bytes of the H accumulation launch, FETCH_SIZE divided by the factor measured for ITS access pattern (64-byte random
+            gathers: 1.494) — acc_h_x2 is the guide's coalesced-stream correction (×2: an upper bound here), acc_h_raw the bare counters;
+    sort_w  bytes of the witness digit sort(s) of one prove — head + tail when the witness is split — with the streaming
+            correction (×2: its kernels read scalars and entries as coalesced streams); sort_h the same for the H sort;
+    detail  per kernel family of the witness pass: FETCH_SIZE_KB, WRITE_SIZE_KB, launches."""
+    out = {"detail": {}}
+    f, w = pmc_dispatches(fetch_rows, "FETCH_SIZE"), pmc_dispatches(write_rows, "WRITE_SIZE")
+    is_acc_g1 = lambda name: "msm_accumulate_kernel" in name and not ("Fq2" in name or "G2" in name)
+    fa, wa = [v for _, n, v in f if is_acc_g1(n)], [v for _, n, v in w if is_acc_g1(n)]
+    if len(fa) >= 4 and len(fa) == len(wa):
+        # per prove the G1 accumulations of the three witness MSMs (twice with a head) and H's — the largest L, the most bytes
+        k = max(range(len(fa) - 4, len(fa)), key=lambda i: fa[i])
+        out["acc_h"] = fa[k] * 1024 / FETCH_CAL["gather64"] + wa[k] * 1024
+        out["acc_h_x2"] = fa[k] * 1024 * 2 + wa[k] * 1024
+        out["acc_h_raw"] = fa[k] * 1024 + wa[k] * 1024
+        out["acc_h_calibration"] = ("FETCH_SIZE / 1.494 + WRITE_SIZE: the raw counter reads 1.494x the bytes of random 64-byte gathers, this kernel's "
+                                    "access pattern (profiles/r02_pmc_calibration.txt); the guide's x2 is calibrated for coalesced 16 B/lane streams")
+        out["detail"]["acc_h"] = {"FETCH_SIZE_KB": fa[k], "WRITE_SIZE_KB": wa[k]}
+        if sq_rows:
+            iv = [v for _, n, v in pmc_dispatches(sq_rows, "SQ_INSTS_VALU") if is_acc_g1(n)]
+            ga = [v for _, n, v in pmc_dispatches(sq_rows, "GRBM_GUI_ACTIVE") if is_acc_g1(n)]
+            if len(iv) == len(fa) and len(ga) == len(fa) and ga[k] > 0:
+                out["acc_h_valu"] = {"SQ_INSTS_VALU": iv[k], "GRBM_GUI_ACTIVE": ga[k]}
+    sf, sw = sorts_of_last_prove(f, n_proves), sorts_of_last_prove(w, n_proves)
+    if sf and sw and [[k for k, _ in i] for i in sf[0] + [sf[1]]] == [[k for k, _ in i] for i in sw[0] + [sw[1]]]:
+        def total(insts_f, insts_w):
+            det = {}
+            for inst_f, inst_w in zip(insts_f, insts_w):
+                for (k, vf), (_, vw) in zip(inst_f, inst_w):
+                    d = det.setdefault(k, {"FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0, "launches": 0})
+                    d["FETCH_SIZE_KB"] += vf
+                    d["WRITE_SIZE_KB"] += vw
+                    d["launches"] += 1
+            tf, tw = sum(d["FETCH_SIZE_KB"] for d in det.values()), sum(d["WRITE_SIZE_KB"] for d in det.values())
+            return tf * 1024 / FETCH_CAL["stream"] + tw * 1024, det
+        out["sort_w"], det = total(sf[0], sw[0])
+        out["sort_h"], det_h = total([sf[1]], [sw[1]])
+        out["sort_instances_per_prove"] = len(sf[0]) + 1
+        out["detail"].update(det)
+        out["detail_sort_h"] = det_h
+    return out
 
 
 def pmc_traffic(workload, timeout=600):
-    """HBM traffic per launch from two separate rocprofv3 PMC passes of a child process (MI355X_MICROARCH.md: FETCH_SIZE and
-    WRITE_SIZE do not fit one pass; both in KB; FETCH_SIZE ×2 on gfx950).  Returns
-    {'acc_h': bytes of the H accumulation launch, 'sort_w': bytes of one witness digit sort, 'detail': …} or raises."""
+    """three separate rocprofv3 PMC passes of a child process (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
+    pass) → pmc_summary, or raises"""
     tmp = tempfile.mkdtemp(prefix="isnark_pmc_")
     try:
         fetch = _pmc_pass("FETCH_SIZE", workload, os.path.join(tmp, "f"), timeout)
@@ -204,41 +290,10 @@ def pmc_traffic(workload, timeout=600):
         try:
             sq = _pmc_pass("SQ_INSTS_VALU", workload, os.path.join(tmp, "s"), timeout, extra=("GRBM_GUI_ACTIVE",))
         except Exception:   # noqa: BLE001 — the traffic figures stand without the issue counters
-            sq = {}
+            sq = None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    out = {"detail": {}}
-    # per prove: four G1 accumulations in dispatch order — the three witness MSMs and H (the largest L); take the last prove
-    f, w = fetch.get("acc_g1", []), write.get("acc_g1", [])
-    if len(f) >= 4 and len(f) == len(w):
-        # H is the launch with the most fetched bytes among the last four
-        k = max(range(len(f) - 4, len(f)), key=lambda i: f[i])
-        out["acc_h"] = f[k] * 1024 * 2 + w[k] * 1024
-        out["acc_h_raw"] = f[k] * 1024 + w[k] * 1024
-        out["detail"]["acc_h"] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w[k]}
-        # issue counters of the same launch (third pass): wave-level VALU instructions and GPU-active cycles summed over the 8 XCDs
-        iv, ga = sq.get("acc_g1", []), sq.get(("acc_g1", "GRBM_GUI_ACTIVE"), [])
-        if len(iv) == len(f) and len(ga) == len(f) and ga[k] > 0:
-            out["acc_h_valu"] = {"SQ_INSTS_VALU": iv[k], "GRBM_GUI_ACTIVE": ga[k]}
-    # digit sort: per prove two sorts (witness, then H), each launching every sort kernel the same number of times
-    tot_f = tot_w = 0.0
-    ok = False
-    for k in SORT_KERNELS:
-        fk, wk = fetch.get(k, []), write.get(k, [])
-        if not fk:
-            continue
-        per_prove = len(fk) // 3            # three proves in the child
-        if per_prove < 2 or per_prove % 2 or len(fk) != len(wk):
-            continue
-        half = per_prove // 2               # launches of this kernel in ONE sort
-        lo = 2 * per_prove                  # last prove; its first half = the witness sort
-        tot_f += sum(fk[lo:lo + half])
-        tot_w += sum(wk[lo:lo + half])
-        out["detail"][k] = {"FETCH_SIZE_KB": sum(fk[lo:lo + half]), "WRITE_SIZE_KB": sum(wk[lo:lo + half]), "launches": half}
-        ok = True
-    if ok:
-        out["sort_w"] = tot_f * 1024 * 2 + tot_w * 1024
-    return out
+    return pmc_summary(fetch, write, sq)
 
 
 def dropin_sequence_ms(zkey, wtns, iters=7):
@@ -298,10 +353,12 @@ def group_child(workload_unused=None):
             zkey, wtns, nc, what, standin = workload_inputs(K, S, cfg["workload"])
             open(zkey_path + ".tmp", "wb").write(zkey)
             open(wtns_path + ".tmp", "wb").write(wtns)
-            os.replace(zkey_path + ".tmp", zkey_path)
-            os.replace(wtns_path + ".tmp", wtns_path)
+            # the description first: an attempt that dies between the two renames must not leave inputs without it (round-4 advisor)
             meta = {"constraints": nc, "what": what, "standin": standin}
-            json.dump(meta, open(zkey_path + ".meta", "w"))
+            with open(zkey_path + ".meta", "w") as mf:
+                json.dump(meta, mf)
+            os.replace(wtns_path + ".tmp", wtns_path)
+            os.replace(zkey_path + ".tmp", zkey_path)
             del zkey, wtns
         elif os.path.exists(zkey_path + ".meta"):
             meta = json.load(open(zkey_path + ".meta"))
@@ -471,11 +528,28 @@ def inproc_group_bench(args, dist, rank, world, zkey, wtns, tmpdir):
         if rank == 0:
             log(f"device-group process failed in the timed region: {res.get('error')}; falling back to the rank-per-GPU host")
         return res if rank == 0 else {"error": "rank 0 failed"}
+    # the other exchange transports on the same group (rank 0, outside every timed region; the other ranks wait): the first run
+    # on N real GPUs then says what pull and RCCL each cost and how many ranks RCCL saw
+    if rank == 0:
+        d = res.get("describe") or {}
+        if int(d.get("distinct_devices") or 1) > 1 and not os.environ.get("ICICLE_SNARK_EXCHANGE") and os.environ.get("ICICLE_SNARK_BENCH_PROBE_TRANSPORTS", "1") != "0":
+            try:
+                et = transport_probes(cfg, d.get("transport"), float(os.environ.get("ICICLE_SNARK_GROUP_TIMEOUT", "420")))["exchange_transports"]
+                if d.get("transport"):
+                    et[f"prove_ms_{d['transport']}"] = res["ms_per_step"]
+                    if d["transport"] == "rccl":
+                        et["rccl_ranks"] = d.get("rccl_ranks")
+                res["exchange_transports"] = et
+            except Exception as e:   # noqa: BLE001 — a probe never costs the line
+                res["exchange_transports"] = {"error": repr(e)[:300]}
+    dist.barrier()
     return res
 
 
 def roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops):
     """roofline object of the dominant kernel (G1 bucket accumulation of the H MSM) from its geometry and HIP-event time"""
+    if not g or not kern_ms:
+        return None   # no valid MSM profile (the line is still printed: round-4 advisor)
     counters = None
     if pmc and pmc.get("acc_h_valu"):
         iv, ga = pmc["acc_h_valu"]["SQ_INSTS_VALU"], pmc["acc_h_valu"]["GRBM_GUI_ACTIVE"]
@@ -491,10 +565,13 @@ def roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops):
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     n_add = g["L"] * g["W"]
     return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            # HBM bytes of the launch from the PMC passes of this run.  FETCH_SIZE is divided by the factor measured for THIS kernel's
+            # access pattern — random 64-byte gathers read 1.494x their bytes in the raw counter (profiles/r02_pmc_calibration.txt) —
+            # as the guide prescribes for anything but coalesced streams; traffic_guide_x2 applies the coalesced-stream correction
+            # (an upper bound here), traffic_raw is the bare FETCH_SIZE + WRITE_SIZE
             "traffic": pmc.get("acc_h") if pmc else None, "traffic_source": pmc_note,
-            # FETCH_SIZE without the guide's x2 (which is calibrated for wide coalesced streams): the calibration probe with this
-            # kernel's own pattern — random 64-byte gathers — counts 1.49x its bytes in the RAW counter (profiles/r02_pmc_calibration.txt),
-            # so the raw figure is the better estimate of the gather traffic and `traffic` an upper bound
+            "traffic_calibration": pmc.get("acc_h_calibration") if pmc else None,
+            "traffic_guide_x2": pmc.get("acc_h_x2") if pmc else None,
             "traffic_raw": pmc.get("acc_h_raw") if pmc else None,
             "kernel": "msm_accumulate_kernel<G1> (H MSM)", "launch_ms": kern_ms,
             "algorithmic_bytes": alg_bytes, "geometry": g,
@@ -582,21 +659,35 @@ def standalone_group(args, workload):
         print(json.dumps({"metric": "groth16_prove_constraints_per_s", "value": None, "unit": "constraints/s", "n_gpus": args.gpus, "steps": args.steps,
                           "warmup": args.warmup, "higher_is_better": True, "error": "every device-group attempt failed", "config": {"attempts": attempts}}), flush=True)
         return 1
-    N, what = res["constraints"], res["what"]
+    # (an attempt killed while it wrote the inputs may have left them without their description: re-derive it)
+    N = res.get("constraints") or max(1, res["n_vars"] - 2)
+    what = res.get("what") or f"{workload} ({N} constraints; description lost with a failed attempt)"
     ms_per_step = max(res["parent_ms_per_step"], res["child_ms_per_step"])
     desc = res.get("describe") or {}
     fell_back = res["shards"] == 0
+    # GPUs that really took part: a fallback is ONE; several shards aliased to one device (ICICLE_SNARK_BENCH_DEVICES=0,0) are one too —
+    # a driver that computes scaling from (n_gpus, value) must not read a one-GPU throughput as an N-GPU point (round-4 advisor)
+    used_gpus = 1 if fell_back else int(desc.get("distinct_devices") or 1)
+    # the OTHER exchange transports on the same group, a few proves each (so that the first run on N real GPUs answers "did RCCL
+    # see N ranks" without a second run): only with more than one distinct device — RCCL refuses duplicates
+    probes = {}
+    if not fell_back and used_gpus > 1 and not os.environ.get("ICICLE_SNARK_EXCHANGE") and os.environ.get("ICICLE_SNARK_BENCH_PROBE_TRANSPORTS", "1") != "0":
+        probes = transport_probes(dict(cfg, device=res["device"]), desc.get("transport"), timeout)
     if not res.get("standin"):
         S = importlib.import_module("icicle-snark_amd.synth")
         assert json.loads(res["public"]) == [str(pow(3, 1 << N, S.R_MOD))]
     assert json.loads(res["proof"])["protocol"] == "groth16"
-    roof = roofline_block(res["acc_geom"], res["acc_ms"], None, "not collected with --gpus > 1 (the N = 1 line carries the PMC traffic)", res["hbm_copy_gbps"], res["mad_tops"])
-    roof["kernel"] += " of shard 0"
+    roof = roofline_block(res.get("acc_geom"), res.get("acc_ms"), None, "not collected with --gpus > 1 (the N = 1 line carries the PMC traffic)", res["hbm_copy_gbps"], res["mad_tops"])
+    if roof:
+        roof["kernel"] += " of shard 0"
     out = {
         "metric": "groth16_prove_constraints_per_s", "value": N / (ms_per_step * 1e-3), "unit": "constraints/s",
-        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": used_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "fallback": fell_back,
         "config": {"workload": f"{what}, domain 2^{res['domain_size'].bit_length() - 1}, cached zkey, random r/s",
+                   "requested_gpus": args.gpus,
+                   **probes,
                    "timed_region": (f"the reference's own (src/lib.rs:41-58) on a device group: groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json, device = {res['device']!r}) "
                                     "with a warm cache — one process, one host thread per GPU, device-side exchanges (csrc/prover/multi.cpp); K proves between two device-wide synchronisations"),
                    "constraints": N, "msm_sharding": f"point-range x{res['shards']}" if not fell_back else "none (FALLBACK: every device-group attempt failed, this is the single-device prove)",
@@ -614,8 +705,41 @@ def standalone_group(args, workload):
                    "n_vars": res["n_vars"], "phase_ms": {"qap_ntt": res["qap_ms"], "msm": res["msm_ms"]}},
         "roofline": roof,
     }
+    et = out["config"].get("exchange_transports")
+    if et is not None and desc.get("transport"):
+        et[f"prove_ms_{desc['transport']}"] = ms_per_step
+        if desc.get("transport") == "rccl":
+            et["rccl_ranks"] = desc.get("rccl_ranks")
     print(json.dumps(out), flush=True)
-    return 0
+    return 3 if fell_back else 0   # the line is there either way; a fallback is not a success of `--gpus N`
+
+
+def transport_probes(cfg, ran, timeout, steps=5):
+    """the device group of `cfg` proved again with each exchange transport that did NOT carry the timed run forced
+    (ICICLE_SNARK_EXCHANGE) → {"prove_ms_pull": …, "prove_ms_rccl": …, "rccl_ranks": …, "transport_probe_errors": {…}}: the same
+    child process as the timed leg (synthesis skipped: the inputs are there), `steps` timed proves each.  The transports differ in
+    how the three exchanges of a prove move (a pull kernel over peer mappings, hipMemcpyPeerAsync, RCCL collectives); everything else
+    of the prove is identical, so the difference between two of these is the difference between their exchanges."""
+    out, errs = {}, {}
+    if ran:
+        out[f"prove_ms_{ran}"] = None   # filled by the caller's own timed run
+    for tr in ("pull", "rccl"):
+        if tr == ran:
+            continue
+        r = _group_attempt(dict(cfg, steps=steps, warmup=2), {"ICICLE_SNARK_EXCHANGE": tr}, timeout)
+        if "error" in r:
+            errs[tr] = r["error"]
+            continue
+        d = r.get("describe") or {}
+        if d.get("transport") != tr:
+            errs[tr] = f"the group came up with transport {d.get('transport')!r}"
+            continue
+        out[f"prove_ms_{tr}"] = max(r["parent_ms_per_step"], r["child_ms_per_step"])
+        if tr == "rccl":
+            out["rccl_ranks"] = d.get("rccl_ranks")
+    if errs:
+        out["transport_probe_errors"] = errs
+    return {"exchange_transports": out}
 
 
 def main():
@@ -670,6 +794,9 @@ def main():
     use_gloo = os.environ.get("ICICLE_SNARK_BENCH_EXCHANGE") == "gloo"
     rccl_hung = False
     K.set_device("HIP", local_rank)
+    # the prover host's CacheManager (src/cache.rs:110-115), created with the device current: it prewarms what the first cache load
+    # needs of the device (streams with their DMA queues, the pinned staging pool) on a helper thread
+    cm = K.CacheManager()
     if world > 1 and use_gloo:
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -726,15 +853,54 @@ def main():
     if world == 1:
         open(zkey_path, "wb").write(zkey)
         open(wtns_path, "wb").write(wtns)
-    cm = K.CacheManager()
     # single GPU: the cache key groth16_prove derives from the zkey path (src/lib.rs:44), so that the timed calls find it
     key = f"{zkey_path}_HIP" if world == 1 else f"bench{N}"
-    t0 = time.time()
-    cm.load(key, zkey, device_id=local_rank, shard_rank=rank, shard_count=world)
-    cold_ms = (time.time() - t0) * 1e3
+    cold = {}
+    if world == 1:
+        # ---- cold path (the reference's "without cache" figure): zkey FILE → proof.json with NOTHING cached —
+        # container parse, 0.8 GB of sections over PCIe, first proof in the classic bucket layout; the key's fixed-base tables are
+        # built behind that proof by a worker thread and adopted by a later prove (csrc/prover/cache.cpp: TableBuild).
+        # (a) first key of this process (the manager was created — and prewarmed streams / staging buffers — before the inputs
+        # were synthesised, like a worker process that waits for its first command), (b) proves beside the table build until the
+        # tables are adopted, (c) the same key evicted and proved from the file again (process warm)
+        K.check(K.lib().icicle_device_synchronize(), "sync")
+        t0 = time.perf_counter()
+        cm.prove_files(wtns_path, zkey_path, proof_path, public_path)
+        cold["cold_prove_ms_files"] = (time.perf_counter() - t0) * 1e3
+        cold_public = open(public_path).read()
+        during, t0 = [], time.perf_counter()
+        while not cm.tables_ready(key):
+            t1 = time.perf_counter()
+            cm.prove_files(wtns_path, zkey_path, proof_path, public_path)
+            during.append((time.perf_counter() - t1) * 1e3)
+        cold["tables_adopted_after_ms"] = (time.perf_counter() - t0) * 1e3
+        cold["proves_beside_table_build"] = len(during)
+        cold["prove_ms_beside_table_build"] = sorted(during)[len(during) // 2] if during else None
+        if not standin:
+            assert json.loads(cold_public) == [str(pow(3, 1 << N, S.R_MOD))]
+        cm.evict(key)
+        t0 = time.perf_counter()
+        cm.prove_files(wtns_path, zkey_path, proof_path, public_path)
+        cold["cold_prove_ms_files_process_warm"] = (time.perf_counter() - t0) * 1e3
+        cm.tables_ready(key, wait=True)
+        cm.evict(key)
+        # (d) the cache alone: until the key can prove, then until its tables are there with nothing running beside the build
+        t0 = time.perf_counter()
+        cm.load(key, zkey, device_id=local_rank, wait_tables=False)
+        cold_ms = (time.perf_counter() - t0) * 1e3
+        cm.tables_ready(key, wait=True)
+        cold["cold_tables_build_ms"] = (time.perf_counter() - t0) * 1e3 - cold_ms
+        cold["note"] = ("cold_prove_ms_files: groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json) with nothing cached (zkey in the page cache), first key of the "
+                        "process / again after an evict; cold_cache_build_ms: groth16_cache_load until the key can prove (classic layout); cold_tables_build_ms: "
+                        "the deferred fixed-base tables built alone; prove_ms_beside_table_build: median file-to-file prove while the worker builds them")
+        log("cold path:", json.dumps(cold))
+    else:
+        t0 = time.time()
+        cm.load(key, zkey, device_id=local_rank, shard_rank=rank, shard_count=world)
+        cold_ms = (time.time() - t0) * 1e3
 
     info = cm.info(key)
-    log(f"cache built in {time.time() - t0:.2f} s: n_vars={info.n_vars} domain={info.domain_size} n_coef={info.n_coef} "
+    log(f"cache usable after {cold_ms:.0f} ms: n_vars={info.n_vars} domain={info.domain_size} n_coef={info.n_coef} "
         f"device bytes={info.device_bytes / 1e6:.0f} MB (shard {rank}/{world})")
 
     def sync():
@@ -743,8 +909,8 @@ def main():
         K.check(K.lib().icicle_device_synchronize(), "sync")
 
     barrier = exch.barrier
-    acc_ms, sort_ms, phases = [], [], dict(qap=0.0, msm=0.0)
-    acc_geom, sort_geom = [None], [None]
+    acc_ms, sort_ms, head_sort_ms, phases = [], [], [], dict(qap=0.0, msm=0.0)
+    acc_geom, sort_geom, head_sort_L = [None], [None], [0]
 
     def collect_profiles():
         # HIP-event timings of the last prove's MSMs (their streams were synchronised inside the call)
@@ -759,6 +925,11 @@ def main():
                 sort_ms.append(ms[4])
                 sort_geom[0] = geom
                 break
+        # back = 5: the digit sort of the witness HEAD (L = 0 when this prove did not split its witness)
+        ms, geom = K.msm_profile(5)
+        if geom["L"] and ms[4] > 0:
+            head_sort_ms.append(ms[4])
+            head_sort_L[0] = geom["L"]
 
     def step(timed=False):
         if world == 1:
@@ -873,22 +1044,33 @@ def main():
             phases = dict(qap=group["qap_ms"] * args.steps, msm=group["msm_ms"] * args.steps)
         roof = roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops)
         if sort_ms:
-            sg = sort_geom[0]
+            sg = dict(sort_geom[0])
+            # the witness pass of a prove = the digit sort of the tail + (when the witness is split, prover.cpp) of the head
             s_ms = sum(sort_ms) / len(sort_ms)
+            h_ms = sum(head_sort_ms) / len(head_sort_ms) if head_sort_ms else 0.0
+            tail_L, head_L = sg["L"], (head_sort_L[0] or 0)
+            sg["L"] = tail_L + head_L
             # the bucket-scatter pass (north star; SURVEY.md §8d: "16·L·W B of index pairs" + the scalars): every scalar read
             # once per pass that needs it and (bucket, point) entries written / read — the formula the judge used in round 1
             s_bytes = 3 * 32 * sg["L"] + 16 * sg["L"] * sg["W"]
-            roof["scatter"] = {"bound": "hbm", "achieved": s_bytes / (s_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                               "frac": s_bytes / (s_ms * 1e-3) / 1e9 / 8000.0, "traffic": pmc.get("sort_w") if pmc else None,
-                               "kernel": "witness digit sort (recode + two-level counting sort: " + ", ".join(
-                                   k for k in SORT_KERNELS if not pmc or k in pmc.get("detail", {})) + ")",
-                               "launch_ms": s_ms, "algorithmic_bytes": s_bytes, "geometry": sg,
-                               "frac_of_measured_copy": s_bytes / (s_ms * 1e-3) / 1e9 / hbm_copy_gbps}
+            kernels = [k for k in SORT_KERNELS if pmc and k in pmc.get("detail", {})]
+            roof["scatter"] = {"bound": "hbm", "achieved": s_bytes / ((s_ms + h_ms) * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": s_bytes / ((s_ms + h_ms) * 1e-3) / 1e9 / 8000.0, "traffic": pmc.get("sort_w") if pmc else None,
+                               "traffic_calibration": "FETCH_SIZE x2 + WRITE_SIZE (coalesced streams: the guide's gfx950 correction), summed over the kernels of the witness sort(s) of one prove",
+                               "kernel": "witness digit sort" + (" (head + tail of the split witness)" if head_L else "") + ": " + ", ".join(kernels),
+                               "launch_ms": s_ms + h_ms, "launch_ms_tail": s_ms, "launch_ms_head": h_ms, "L_head": head_L, "L_tail": tail_L,
+                               "sort_instances_per_prove": pmc.get("sort_instances_per_prove") if pmc else None,
+                               "traffic_h_sort": pmc.get("sort_h") if pmc else None,
+                               "algorithmic_bytes": s_bytes, "geometry": sg,
+                               "frac_of_measured_copy": s_bytes / ((s_ms + h_ms) * 1e-3) / 1e9 / hbm_copy_gbps}
         if pmc:
             roof["pmc_detail"] = pmc.get("detail")
         out = {
             "metric": "groth16_prove_constraints_per_s", "value": N / (ms_per_step * 1e-3), "unit": "constraints/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            # GPUs that took part: the devices the group touched when `value` is the group's (ranks pinned to one GPU by the test
+            # hooks are ONE GPU), else the launcher's world size; the requested count is config.requested_gpus
+            "n_gpus": (int((group.get("describe") or {}).get("distinct_devices") or world) if use_group else world),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"{what}, domain 2^{info.domain_size.bit_length() - 1}, cached zkey, random r/s",
@@ -898,7 +1080,8 @@ def main():
                                         (f"the reference's own, on a device group: rank 0 calls groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json, device = {group['device']!r}) "
                                          "with a warm cache — one process, one host thread per GPU, device-side exchanges (csrc/prover/multi.cpp)" if use_group else
                                          "one process per GPU: host witness buffer -> commitments of this rank's shard -> all-gather -> sum -> blinding + JSON strings")),
-                       "constraints": N, "msm_sharding": f"point-range x{world}" if world > 1 else "none",
+                       "constraints": N, "msm_sharding": f"point-range x{world}" if world > 1 else "none", "requested_gpus": args.gpus,
+                       "exchange_transports": (group or {}).get("exchange_transports") if use_group else None,
                        # which transport moved the group's three exchanges, the devices it touched and the RCCL ranks that took part in them
                        # (0 for the pull / memcpy transports BY DESIGN: they do not go through RCCL)
                        "exchange": ((group.get("describe") or {}).get("transport") if use_group else type(exch).__name__),
@@ -920,6 +1103,7 @@ def main():
                        "prove_ms_dropin_sequence": dropin_ms, "dropin_sequence_detail": dropin_detail,
                        # cold path, reported separately: zkey bytes in host memory → device-resident cache
                        "cold_cache_build_ms": cold_ms, "cache_device_mb": info.device_bytes / 1e6,
+                       "cold_prove_ms_files": cold.get("cold_prove_ms_files"), "cold_path": cold or None,
                        "b_msm_bases": info.b_bases, "n_vars": info.n_vars,
                        "prove_ms_bit_heavy_witness_standin": skew_ms,
                        "phase_ms": {"qap_ntt": phases["qap"] / args.steps, "msm": phases["msm"] / args.steps}},

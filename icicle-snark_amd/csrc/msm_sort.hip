@@ -91,7 +91,8 @@ void msm_profile_publish(const MsmProfile* src, int n)
     *p = src[k];
     memcpy(p->ev, keep, sizeof keep);
     p->resolved = true;
-    if (src[k].valid) msm_profile_resolve(src[k], p->ms);
+    for (float& m : p->ms) m = 0;
+    if (src[k].valid && src[k].L) msm_profile_resolve(src[k], p->ms); // (L = 0: a slot that stands for "did not run", e.g. the head sort of an unsplit witness)
     r.seq++;
   }
 }

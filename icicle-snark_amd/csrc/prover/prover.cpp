@@ -408,6 +408,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     prof[k] = &z->prof[k];
     msm_profile_own_init(prof[k]);
   }
+  msm_profile_own_init(&z->prof[5]); // digit sort of the witness head (roofline.scatter of bench.py adds it to the tail's)
+  z->prof[5].L = 0;
+  z->prof[5].valid = true; // (published either way so that the ring keeps its order; L = 0 says "no head in this prove")
   // (tab > 1 = table mode with exactly this digit width: a key adapted to its witnesses, cache.cpp)
   const bool adapted_w = z->geom_w.tab && z->geom_w.c != z->geom_w_default_c;
   const uint32_t skip_below = skip > wlo ? skip - wlo : 0; // C ignores witness[0..=n_public]
@@ -517,7 +520,18 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       int hrc = 0;
       auto enqueue_head = [&]() -> int {
         (void)hipEventRecord(z->ev_t_head_start, g2); // (timing, with ev_t_head_end and ev_t_witness: steers head_frac)
+        MsmProfile* ph = &z->prof[5];
+        (void)hipEventRecord(ph->ev[0], g2);
         P_ICICLE(msm_sort_run(z->d_witness, head, 0, 0, 0, g2, &plan_head, z->geom_w.c, 0, 1, adapted_w ? (uint64_t)((double)z->witness_entries * head / nv) + 1 : 0));
+        for (int e = 1; e < 5; e++) (void)hipEventRecord(ph->ev[e], g2);
+        ph->has_sort_end = ph->valid = true;
+        ph->L = head; ph->nbuckets = plan_head.nbuckets; ph->c = plan_head.g.c; ph->W = plan_head.g.W; ph->is_g2 = 0;
+        // entry count of the head's sort (offset + count of its last bucket) for the key's digit-width rule — on g2, in stream
+        // order behind the sort that writes them (round-4 advisor: on the tail's stream nothing ordered the copies behind it)
+        if (plan_head.nbuckets) {
+          P_HIP(hipMemcpyAsync(&z->h_stats[2], plan_head.offsets + plan_head.nbuckets - 1, 4, hipMemcpyDeviceToHost, g2));
+          P_HIP(hipMemcpyAsync(&z->h_stats[3], plan_head.counts + plan_head.nbuckets - 1, 4, hipMemcpyDeviceToHost, g2));
+        }
         if (plan_head.g.tab != z->geom_w.tab || plan_head.g.c != z->geom_w.c || plan_head.nbuckets != z->geom_w.NB)
           return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the sort of the witness head");
         for (int k = 0; k < 4; k++) P_HIP(bk[k].alloc(msm_bucket_bytes(&plan_head, k == 2), st4[k]));
@@ -580,14 +594,11 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   P_HIP(hipEventRecord(z->ev_sort, gs));
   // entry counts of the sorts (offset + count of the last bucket), read at the end of the prove: they steer the digit width of
   // the key's witness tables (cache.cpp: rebuild_witness_tables)
-  for (int k = 0; k < 4; k++) z->h_stats[k] = 0;
+  z->h_stats[0] = z->h_stats[1] = 0;
+  if (!head) z->h_stats[2] = z->h_stats[3] = 0; // (with a head: written by the copies behind the head's sort on g2)
   if (plan_w.nbuckets) {
     P_HIP(hipMemcpyAsync(&z->h_stats[0], plan_w.offsets + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
     P_HIP(hipMemcpyAsync(&z->h_stats[1], plan_w.counts + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
-    if (head) {
-      P_HIP(hipMemcpyAsync(&z->h_stats[2], plan_head.offsets + plan_head.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
-      P_HIP(hipMemcpyAsync(&z->h_stats[3], plan_head.counts + plan_head.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
-    }
   }
   mark("wsort");
   auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
@@ -771,7 +782,11 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   msm_sort_release(&plan_h);
   // HIP-event profile of the five MSMs → the ring icicle_snark_msm_profile reads (bench.py: back = 4 … 0 = A, B1, B2, C, H); in
   // a device group only the lead shard publishes
-  if (z->shard_rank == 0 || !z->in_group) msm_profile_publish(z->prof, 5);
+  // (the head's sort first, so that A … H keep their places: back = 5 is the head sort, L = 0 when the witness was not split)
+  if (z->shard_rank == 0 || !z->in_group) {
+    msm_profile_publish(&z->prof[5], 1);
+    msm_profile_publish(z->prof, 5);
+  }
   if (head) {
     // The head's share follows the machine: its chain should end just before the last byte of the witness lands — what is left
     // of it then runs beside the transforms of the front end and slows them (long-lived accumulation workgroups hold the

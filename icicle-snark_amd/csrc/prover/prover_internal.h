@@ -146,7 +146,7 @@ struct ZKeyCache {
   hipEvent_t ev_own_slice = nullptr;
   bool own_slice_event_set = false, slice_aligned = false;
   Groth16Timings last_tm = {0, 0, 0, 0}; // phase timings of the most recent prove (groth16_last_timings)
-  MsmProfile prof[5] = {};               // A, B1, B2, C, H of the most recent prove: this entry's own slots (the shards of a group may share a device)
+  MsmProfile prof[6] = {};               // A, B1, B2, C, H of the most recent prove + [5] the digit sort of the witness HEAD (ev[0] → ev[4]; L = 0 without one): this entry's own slots (the shards of a group may share a device)
   uint64_t last_use = 0;                 // CacheManager LRU clock
   TableBuild tb;                         // deferred fixed-base tables (single-device keys)
 

@@ -3,6 +3,7 @@ values, and here also as text — to the oracle pipeline (restated src/proof_hel
 zkey / witness / (r, s), equal the committed golden proof, and are accepted by the reference pairing check
 when oracle/_ref is present."""
 import base64
+import importlib
 import json
 import os
 import subprocess
@@ -485,3 +486,53 @@ print("HEAD_TAIL_OK")
     env = dict(os.environ, ICICLE_SNARK_HEAD_MIN="0", ICICLE_SNARK_HEAD_PCT=str(pct), ICICLE_SNARK_QUIET="1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=env)
     assert "HEAD_TAIL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_proofs_across_the_deferred_table_build(gpu, O, S, tmp_path):
+    """groth16_cache_load returns once the key can prove in the classic layout; the fixed-base tables are built behind its first
+    proof and adopted by a later prove (csrc/prover/cache.cpp: TableBuild).  Every proof of a loop that crosses the swap —
+    host buffer, resident witness and the file entry point — equals the oracle's; an evict in the middle of a build is clean;
+    ICICLE_SNARK_DEFER_TABLES=0 builds the tables inside the load."""
+    K = gpu
+    N = 100_000
+    zkey, wtns = importlib.import_module("bench").make_inputs(K, S, N)
+    cache = O.build_cache(O.parse_zkey(zkey))
+    want = {rs: O.groth16_prove(zkey, wtns, *rs, cache=cache) for rs in ((1, 1), (9, 4))}
+    cm = K.CacheManager()
+    cm.load("d", zkey, wait_tables=False)
+    assert not cm.tables_ready("d")
+    seen, after = [], 0
+    for i in range(400):
+        rs = list(want)[i % 2]
+        rdy = cm.tables_ready("d")
+        pj, qj, _ = cm.prove_mem("d", wtns, *rs, resident=(i % 3 == 2))
+        assert json.loads(pj) == want[rs][0] and json.loads(qj) == want[rs][1], (i, rdy)
+        seen.append(rdy)
+        after += 1 if rdy else 0
+        if after >= 3:
+            break
+    assert seen[0] is False and seen[-1] is True
+    assert cm.tables_ready("d", wait=True)
+    # evicted while the build is (most likely) under way: the worker stops at its next slice and the entry goes away cleanly
+    cm.load("e", zkey, wait_tables=False)
+    cm.prove_mem("e", wtns, 1, 1)                                # releases the build
+    cm.evict("e")
+    # the file entry point on a fresh key, then again after the tables have been adopted
+    zp, wp = tmp_path / "c.zkey", tmp_path / "w.wtns"
+    zp.write_bytes(zkey)
+    wp.write_bytes(wtns)
+    for rep in range(2):
+        cm.prove_files(str(wp), str(zp), str(tmp_path / "p.json"), str(tmp_path / "q.json"))
+        assert json.loads((tmp_path / "q.json").read_text()) == want[(1, 1)][1]
+        assert cm.tables_ready(f"{zp}_HIP", wait=True)
+    # tables inside the load when deferral is switched off
+    os.environ["ICICLE_SNARK_DEFER_TABLES"] = "0"
+    try:
+        cm.load("n", zkey, wait_tables=False)
+        assert cm.tables_ready("n")
+        pj, qj, _ = cm.prove_mem("n", wtns, 9, 4)
+        assert json.loads(pj) == want[(9, 4)][0]
+    finally:
+        del os.environ["ICICLE_SNARK_DEFER_TABLES"]
+    cm.close()
+    K.release_domain()
