@@ -53,7 +53,10 @@ SORT_KERNELS = ("msm_zero_kernel", "msm_coarse_hist_kernel", "msm_part_scan_kern
                 "msm_fine_place_kernel", "sort2_tile_hist_kernel", "sort2_col_sum_kernel", "sort2_col_base_kernel", "sort2_col_apply_kernel",
                 "sort2_tile_partition_kernel", "sort2_chunk_hist_kernel", "sort2_bucket_scan_kernel", "sort2_chunk_place_kernel",
                 "msm_hist_kernel", "msm_scan_sums_kernel", "msm_scan_top_kernel", "msm_scan_finish_kernel", "msm_scan_apply_kernel",
-                "msm_scatter_kernel", "msm_order_hist_kernel", "msm_order_scatter_kernel")
+                "msm_scatter_kernel", "msm_order_hist_kernel", "msm_order_scatter_kernel", "sort2_order_scan_kernel", "sort2_order_scatter_kernel")
+# the kernel a digit sort begins with: the LDS-staged path starts with its tile histogram (which also zeroes the plan's counters),
+# the other paths with msm_zero_kernel (twice in a row)
+SORT_FIRST = ("sort2_tile_hist_kernel", "msm_zero_kernel")
 
 
 def log(*a):
@@ -199,14 +202,14 @@ def sort_family(name):
 
 
 def sort_instances(dispatches):
-    """the digit sorts of a dispatch stream: msm_sort_run enqueues all kernels of ONE sort back to back, beginning with
-    msm_zero_kernel (one or two of them) → a list of sorts, each a list of (family, value) in launch order"""
+    """the digit sorts of a dispatch stream: msm_sort_run enqueues all kernels of ONE sort back to back, beginning with a kernel of
+    SORT_FIRST (msm_zero_kernel may repeat) → a list of sorts, each a list of (family, value) in launch order"""
     inst, prev_zero = [], False
     for _, name, v in dispatches:
         fam = sort_family(name)
         if fam is None:
             continue
-        zero = fam == "msm_zero_kernel"
+        zero = fam in SORT_FIRST
         if zero and not prev_zero:
             inst.append([])
         if not inst:

@@ -542,24 +542,31 @@ __global__ __launch_bounds__(256) void msm_fine_place_kernel(const uint32_t* __r
 // PMC of the two-level scatter above on MI355X (profiles/r02_pmc_*): the partition pass WRITES 640 MB for 83 MB of entries
 // and the place pass 197 MB — a store instruction costs one 32-byte fabric write per sector it touches and the L2 does not
 // merge the 4-byte stores of different instructions, so entries must leave a workgroup as runs of consecutive lanes.  Here
-// both passes sort their tile in LDS first and copy it out linearly:
-//  A  a tile of 2048 scalars counts its digits per PARTITION (top bits of the bucket), a scan over tiles gives every
-//     (tile, partition) run its place (no atomics, deterministic), and the tile is written as ≤ P runs of ≈ 26 entries.  Entries
-//     carry the scalar's index WITHIN THE TILE (11 bits), which leaves room for up to 16 low bucket bits in 32 bits — P can be
-//     1024 instead of 8192, runs are 8× longer;
-//  B  a partition (≈ 25 K entries; chunks of 30 K when a skewed witness makes one larger) is counting-sorted by its low
-//     bucket bits in LDS and written out as ONE contiguous block; the tile of an entry — needed to restore the global scalar
-//     index — is found from its position in the partition (runs are in tile order) by a binary search in the partition's
-//     column of run offsets.  Per-bucket counts and offsets fall out of the chunk histograms.
+// both passes sort their tile in LDS first and copy it out run by run:
+//  A  a tile of 1024 scalars counts its digits per PARTITION (top bits of the bucket; sort2_tile_hist), a column scan over the
+//     tiles gives every (tile, partition) run its place (no atomics, deterministic), and the tile — ALL its windows, one recode —
+//     is staged in LDS sorted by partition and written as ≤ P runs of ≈ 13 entries (sort2_tile_partition).  Entries carry the
+//     scalar's index WITHIN THE TILE (10 bits), which leaves room for up to 17 low bucket bits in 32 bits;
+//  B  partitions are cut into chunks of 12 K entries; a chunk is counting-sorted by its low bucket bits in LDS and written out as
+//     runs of ≈ 23 entries per bucket.  A chunk is walked ROW BY ROW — the runs of the tiles that fed the partition, in tile
+//     order, whose first entries are the partition's column of `off` — so the tile of an entry (needed to restore the global
+//     scalar index) is known from the row being walked.  Per-bucket counts and offsets fall out of the chunk histograms.
+// Round 5: every scalar is read and recoded TWICE per sort (histogram, placement) instead of three times (the tile used to be
+// staged in two window groups), and no entry is located by binary search any more — rounds 2–4 searched the partition of every
+// entry in pass A's copy-out (10 steps), its tile (11 steps) and its bucket (9 steps) in pass B: 138 / 205 VALU instructions per
+// entry in the two big kernels (profiles/r04_pmc_kernels_1600k.txt).  The copy-outs are now run-cooperative: 16 lanes take one
+// run (of a partition, a row, a bucket), so the run is known by construction and consecutive lanes still write consecutive
+// words; runs longer than S2_LONG entries (the 0/1 wires of a real witness all land in one bucket) are left to the whole
+// workgroup.  Launches per sort: 14 → 9 (zeroing folded into the histogram, the column scan's middle kernel into its first,
+// the size order's histogram into the bucket scan, its three-kernel scan into one).
 // HBM bytes: scalars 2 × 32·L, entries 4·L·W written and read twice, 4·L·W written — each once, in full lines.
-// Every scalar is recoded once for the tile histogram and once per window group for the placement (the placement pass takes
-// its per-partition counts from the histogram: round 4; it used to recode a second time to count).
-constexpr int S2_TILE = 2048;    // scalars per tile (pass A)
-constexpr int S2_WGRP = 7;       // windows per row: a row = (tile, window group) stages ≤ 2048·7 entries = 56 KiB in LDS
+constexpr int S2_TILE = 1024;    // scalars per tile (pass A): a row = (tile, all W ≤ 16 windows) stages ≤ 64 KiB of entries in LDS
 constexpr int S2_CHUNK = 12288;  // entries per chunk (pass B): 48 KiB of LDS
-constexpr int S2_W_SHIFT = 11, S2_LOW_SHIFT = 15;
+constexpr int S2_LI_BITS = 10, S2_W_SHIFT = 10, S2_LOW_SHIFT = 14;
 constexpr int S2_THREADS = 512;
 constexpr int S2_RG = 32;        // row groups of the column scan
+constexpr int S2_GRP = 16;       // lanes that copy one run
+constexpr uint32_t S2_LONG = 192; // a run above this is copied by the whole workgroup
 constexpr size_t S2_LDS_MAX = 76 * 1024; // two workgroups per CU; ≤ 66 KiB at the benchmark sizes (room next to one NTT workgroup)
 
 // largest i < n with a[i] <= x (a non-decreasing, a[0] <= x)
@@ -595,13 +602,40 @@ __device__ __forceinline__ void s2_wave_scan(const uint32_t* in, uint32_t* out, 
     }
   if (threadIdx.x == 63) out[n] = incl;
 }
+// Copy-out of `nruns` runs staged back to back in LDS (`start[k]` … `start[k + 1]` = run k in src; delta[k] = its place in dst minus
+// start[k]): S2_GRP lanes per run, so that the run is known without a search and consecutive lanes write consecutive words;
+// a run above S2_LONG entries is listed and copied by all threads afterwards.  `nlong` / `longs`: LDS scratch (counter zeroed by the
+// caller before the barrier that precedes the call; ≤ S2_CHUNK / S2_LONG entries).
+__device__ __forceinline__ void s2_copy_runs(const uint32_t* src, const uint32_t* start, const uint32_t* delta, uint32_t nruns, uint32_t* __restrict__ dst, uint32_t* nlong, uint32_t* longs)
+{
+  const uint32_t grp = threadIdx.x / S2_GRP, l = threadIdx.x % S2_GRP, ngrp = blockDim.x / S2_GRP;
+  for (uint32_t k = grp; k < nruns; k += ngrp) {
+    const uint32_t b0 = start[k], b1 = start[k + 1], d = delta[k];
+    if (b1 - b0 > S2_LONG) {
+      if (l == 0) longs[atomicAdd(nlong, 1u)] = k;
+      continue;
+    }
+    for (uint32_t e = b0 + l; e < b1; e += S2_GRP) dst[e + d] = src[e];
+  }
+  __syncthreads();
+  const uint32_t nl = *nlong;
+  for (uint32_t j = 0; j < nl; j++) {
+    const uint32_t k = longs[j], b0 = start[k], b1 = start[k + 1], d = delta[k];
+    for (uint32_t e = b0 + threadIdx.x; e < b1; e += blockDim.x) dst[e + d] = src[e];
+  }
+}
+constexpr uint32_t S2_MAXLONG = 1024 * 16 / S2_LONG + 2; // runs above S2_LONG that 16 K staged entries can hold
 
-// pass A, step 1: digits of a tile counted per (window group, partition): cnt[(tile·HS + h)·P + p]
-__global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t HS, uint32_t* __restrict__ cnt)
+// pass A, step 1: digits of a tile counted per partition: cnt[tile·P + p].  Workgroup 0 also zeroes the plan's counters
+// (n_large | tickets | the column scan's ticket): one launch less on a latency chain.
+__global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t* __restrict__ cnt,
+                                                              uint32_t* __restrict__ zero_p, uint32_t zero_n)
 {
   ISNARK_CRITICAL_CHAIN_KERNEL();
-  extern __shared__ uint32_t sh[]; // [HS][P]
-  for (uint32_t p = threadIdx.x; p < HS * P; p += 256) sh[p] = 0;
+  extern __shared__ uint32_t sh[]; // [P]
+  if (blockIdx.x == 0)
+    for (uint32_t k = threadIdx.x; k < zero_n; k += 256) zero_p[k] = 0;
+  for (uint32_t p = threadIdx.x; p < P; p += 256) sh[p] = 0;
   __syncthreads();
   const uint32_t first = blockIdx.x * S2_TILE;
   for (int u = 0; u < S2_TILE / 256; u++) {
@@ -611,47 +645,56 @@ __global__ __launch_bounds__(256) void sort2_tile_hist_kernel(const fe* __restri
       recode(scalars, i, g, mont, t, neg);
       for (int w = 0; w < g.W; w++) {
         const uint32_t d = digit(t, w, g);
-        if (d) atomicAdd(&sh[(uint32_t)(w / S2_WGRP) * P + (((d & 0x7fffffffu) - 1) >> low_b)], 1u);
+        if (d) atomicAdd(&sh[((d & 0x7fffffffu) - 1) >> low_b], 1u);
       }
     }
   }
   __syncthreads();
-  for (uint32_t p = threadIdx.x; p < HS * P; p += 256) cnt[(size_t)blockIdx.x * HS * P + p] = sh[p];
+  for (uint32_t p = threadIdx.x; p < P; p += 256) cnt[(size_t)blockIdx.x * P + p] = sh[p];
 }
-// column scan of cnt[R][P] over the rows, three short kernels: sums per row group, scan of the group sums (+ partition starts
-// and chunk numbering), running offsets written back — every load and store coalesced over p
-__global__ __launch_bounds__(256) void sort2_col_sum_kernel(const uint32_t* __restrict__ cnt, uint32_t R, uint32_t P, uint32_t* __restrict__ partial)
+// column scan of cnt[R][P] over the rows, two short kernels: (1) sums per row group — and, in the workgroup that finishes last,
+// the scan of the group sums, the partition starts and the chunk numbering — (2) running offsets written back.  Every load and
+// store coalesced over p.
+__global__ __launch_bounds__(256) void sort2_col_sum_kernel(const uint32_t* __restrict__ cnt, uint32_t R, uint32_t P, uint32_t* __restrict__ partial, uint32_t* __restrict__ ticket,
+                                                            uint32_t* __restrict__ part_start, uint32_t* __restrict__ chunk_first)
 {
   ISNARK_CRITICAL_CHAIN_KERNEL();
+  __shared__ uint32_t ps[4097], cf[4097]; // totals / chunk counts, scanned in place (last workgroup only)
+  __shared__ uint32_t s_last;
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  const uint32_t rpg = (R + S2_RG - 1) / S2_RG, r0 = blockIdx.y * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
-  uint32_t s = 0;
-  for (uint32_t r = r0; r < r1; r++) s += cnt[(size_t)r * P + p];
-  partial[(size_t)blockIdx.y * P + p] = s;
-}
-__global__ __launch_bounds__(1024) void sort2_col_base_kernel(uint32_t* __restrict__ partial, uint32_t P, uint32_t* __restrict__ part_start, uint32_t* __restrict__ chunk_first)
-{
-  ISNARK_CRITICAL_CHAIN_KERNEL();
-  __shared__ uint32_t ps[4097], cf[4097]; // totals / chunk counts, scanned in place
-  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+  if (p < P) {
+    const uint32_t rpg = (R + S2_RG - 1) / S2_RG, r0 = blockIdx.y * rpg, r1 = r0 + rpg < R ? r0 + rpg : R;
+    uint32_t s = 0;
+    for (uint32_t r = r0; r < r1; r++) s += cnt[(size_t)r * P + p];
+    partial[(size_t)blockIdx.y * P + p] = s;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (uint32_t q = threadIdx.x; q < P; q += 256) {
+    uint32_t t[S2_RG]; // all loads first: a load behind each store of the running sum would make this a chain of 32 round trips
+#pragma unroll
+    for (int gidx = 0; gidx < S2_RG; gidx++) t[gidx] = partial[(size_t)gidx * P + q];
     uint32_t run = 0;
-    for (uint32_t gidx = 0; gidx < (uint32_t)S2_RG; gidx++) {
-      const uint32_t t = partial[(size_t)gidx * P + p];
-      partial[(size_t)gidx * P + p] = run;
-      run += t;
+#pragma unroll
+    for (int gidx = 0; gidx < S2_RG; gidx++) {
+      partial[(size_t)gidx * P + q] = run;
+      run += t[gidx];
     }
-    ps[p] = run;
-    cf[p] = (run + S2_CHUNK - 1) / S2_CHUNK;
+    ps[q] = run;
+    cf[q] = (run + S2_CHUNK - 1) / S2_CHUNK;
   }
   __syncthreads();
   s2_wave_scan(ps, ps, P);
   __syncthreads();
   s2_wave_scan(cf, cf, P);
   __syncthreads();
-  for (uint32_t p = threadIdx.x; p <= P; p += blockDim.x) {
-    part_start[p] = ps[p];
-    chunk_first[p] = cf[p];
+  for (uint32_t q = threadIdx.x; q <= P; q += 256) {
+    part_start[q] = ps[q];
+    chunk_first[q] = cf[q];
   }
 }
 // (out of place: the counts stay — the partition pass loads its row of them instead of recoding its scalars once more to count)
@@ -667,22 +710,22 @@ __global__ __launch_bounds__(256) void sort2_col_apply_kernel(const uint32_t* __
     run += cnt[(size_t)r * P + p];
   }
 }
-// pass A, step 2: the row's entries (one tile, one window group) sorted by partition in LDS, then copied out run by run
-__global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P, uint32_t HS,
+// pass A, step 2: the tile's entries — every window, one recode — sorted by partition in LDS, then copied out run by run
+__global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P,
                                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ part_start,
                                                                            uint32_t* __restrict__ tmp)
 {
   ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[];
+  __shared__ uint32_t nlong, longs[S2_MAXLONG];
   uint32_t* base = sh;          // [P + 1] exclusive prefix of the row's partition counts
   uint32_t* cur = sh + P + 1;   // [P] counts / rank counters, then the global position minus the local one
-  uint32_t* buf = cur + P;      // [S2_TILE · S2_WGRP]
-  const uint32_t row = blockIdx.x, tile = row / HS, h = row % HS;
-  const int w0 = (int)h * S2_WGRP, w1 = w0 + S2_WGRP < g.W ? w0 + S2_WGRP : g.W;
-  const uint32_t first = tile * S2_TILE;
+  uint32_t* buf = cur + P;      // [S2_TILE · W]
+  const uint32_t row = blockIdx.x, first = row * S2_TILE;
   const uint32_t low_mask = (1u << low_b) - 1;
-  // the row's digit counts per partition: what sort2_tile_hist_kernel counted for it (one recode pass less per row)
+  // the row's digit counts per partition: what sort2_tile_hist_kernel counted for it
   for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = cnt[(size_t)row * P + p];
+  if (threadIdx.x == 0) nlong = 0;
   __syncthreads();
   s2_wave_scan(cur, base, P);
   __syncthreads();
@@ -693,7 +736,7 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const 
     if (i < L) {
       uint32_t t[9], neg;
       recode(scalars, i, g, mont, t, neg);
-      for (int w = w0; w < w1; w++) {
+      for (int w = 0; w < g.W; w++) {
         const uint32_t d = digit(t, w, g);
         if (d) {
           const uint32_t bk = (d & 0x7fffffffu) - 1, p = bk >> low_b;
@@ -707,11 +750,7 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const 
   // cur[p] ← where the run of partition p starts in tmp, minus its start in buf
   for (uint32_t p = threadIdx.x; p < P; p += S2_THREADS) cur[p] = part_start[p] + off[(size_t)row * P + p] - base[p];
   __syncthreads();
-  const uint32_t total = base[P];
-  for (uint32_t e = threadIdx.x; e < total; e += S2_THREADS) {
-    const uint32_t p = s2_upper(base, P, e);
-    tmp[e + cur[p]] = buf[e];
-  }
+  s2_copy_runs(buf, base, cur, P, tmp, &nlong, longs);
 }
 // the chunk a workgroup owns: partition, first entry, number of entries (false: beyond the last chunk)
 __device__ __forceinline__ bool s2_chunk_of(uint32_t c, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, uint32_t& p, uint32_t& start, uint32_t& n)
@@ -743,15 +782,17 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_hist_kernel(const uint
   for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) chunk_hist[(size_t)blockIdx.x * NL + b] = hist[b];
 }
 // pass B, step 2: one workgroup per partition, one thread per bucket: counts, offsets, the chunk's place inside each bucket,
-// large buckets registered (as msm_fine_place_kernel does)
+// large buckets registered (as msm_fine_place_kernel does) — and the partition's histogram of bucket SIZES for the order by
+// decreasing size (blockhist[key·P + p]: what msm_order_hist_kernel computes per 256 buckets in the other paths)
 __global__ __launch_bounds__(1024) void sort2_bucket_scan_kernel(const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ part_start,
                                                                   const uint32_t* __restrict__ chunk_first, int low_b, uint32_t thr, uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
                                                                   uint32_t* __restrict__ n_large, uint32_t* __restrict__ large_list, uint32_t* __restrict__ large_first, uint2* __restrict__ large_items,
-                                                                  uint32_t item_cap)
+                                                                  uint32_t item_cap, uint32_t* __restrict__ blockhist)
 {
   ISNARK_CRITICAL_CHAIN_KERNEL();
-  __shared__ uint32_t sc[1024];
-  const uint32_t NL = 1u << low_b, p = blockIdx.x, b = threadIdx.x;
+  __shared__ uint32_t sc[1024], oh[ORDER_BINS];
+  const uint32_t NL = 1u << low_b, p = blockIdx.x, b = threadIdx.x, P = gridDim.x;
+  for (uint32_t k = b; k < (uint32_t)ORDER_BINS; k += NL) oh[k] = 0;
   const uint32_t c0 = chunk_first[p], c1 = chunk_first[p + 1];
   uint32_t run = 0;
   for (uint32_t c = c0; c < c1; c++) {
@@ -761,12 +802,15 @@ __global__ __launch_bounds__(1024) void sort2_bucket_scan_kernel(const uint32_t*
   }
   sc[b] = run;
   __syncthreads();
+  atomicAdd(&oh[order_key(run)], 1u);
   for (uint32_t d = 1; d < NL; d <<= 1) { // inclusive scan over the partition's buckets
     const uint32_t x = b >= d ? sc[b - d] : 0;
     __syncthreads();
     sc[b] += x;
     __syncthreads();
   }
+  __syncthreads();
+  for (uint32_t k = b; k < (uint32_t)ORDER_BINS; k += NL) blockhist[(size_t)k * P + p] = oh[k];
   const uint32_t bucket = (p << low_b) + b;
   counts[bucket] = run;
   offsets[bucket] = part_start[p] + sc[b] - run;
@@ -779,15 +823,16 @@ __global__ __launch_bounds__(1024) void sort2_bucket_scan_kernel(const uint32_t*
     for (uint32_t q = 0; q < nch && firsti + q < item_cap; q++) large_items[firsti + q] = make_uint2(bucket, q);
   }
 }
-// pass B, step 3: the chunk counting-sorted by bucket in LDS (entries rewritten with the global scalar index), copied out.
-// The tile of an entry follows from its position inside the partition: the partition's column of cnt (first entry of every
-// row's run) is searched; row = tile·HS + window group.
+// pass B, step 3: the chunk counting-sorted by bucket in LDS (entries rewritten with the global scalar index), copied out run
+// by run.  The chunk is walked row by row: col[r] = first entry of row r's run inside the partition (the partition's column of
+// `off`), 16 lanes per row — the tile of an entry is the row it is read from.
 __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_place_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, int low_b,
                                                                         const uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ offsets,
-                                                                        const uint32_t* __restrict__ cnt, uint32_t R, uint32_t HS, MsmGeom g, uint32_t* __restrict__ sorted)
+                                                                        const uint32_t* __restrict__ off, uint32_t R, MsmGeom g, uint32_t* __restrict__ sorted)
 {
   ISNARK_CRITICAL_CHAIN_KERNEL();
   extern __shared__ uint32_t sh[];
+  __shared__ uint32_t nlong, longs[S2_MAXLONG], s_rows[2];
   const uint32_t NL = 1u << low_b;
   uint32_t* lbase = sh;             // [NL + 1]
   uint32_t* lcur = sh + NL + 1;     // [NL] counts / rank counters, then global position minus local one
@@ -795,30 +840,94 @@ __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_place_kernel(const uin
   uint32_t* buf = col + R + 1;      // [S2_CHUNK]
   uint32_t p, start, n;
   if (!s2_chunk_of(blockIdx.x, part_start, chunk_first, P, p, start, n)) return;
-  const uint32_t in_part = start - part_start[p]; // position of the chunk inside its partition
-  for (uint32_t r = threadIdx.x; r <= R; r += S2_THREADS) col[r] = r < R ? cnt[(size_t)r * P + p] : 0xffffffffu;
+  const uint32_t pstart = part_start[p], in_part = start - pstart; // position of the chunk inside its partition
+  for (uint32_t r = threadIdx.x; r <= R; r += S2_THREADS) col[r] = r < R ? off[(size_t)r * P + p] : 0xffffffffu;
   for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) lcur[b] = chunk_hist[(size_t)blockIdx.x * NL + b];
+  if (threadIdx.x == 0) nlong = 0;
   __syncthreads();
   s2_wave_scan(lcur, lbase, NL);
+  // rows the chunk touches (empty rows share their neighbour's value: the largest index wins, which is a row that holds the entry)
+  if (threadIdx.x == 64) s_rows[0] = s2_upper(col, R, in_part);
+  if (threadIdx.x == 128) s_rows[1] = s2_upper(col, R, in_part + n - 1);
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) lcur[b] = 0;
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < n; q += S2_THREADS) {
-    const uint32_t v = tmp[start + q];
-    const uint32_t b = (v >> S2_LOW_SHIFT) & (NL - 1);
-    const uint32_t row = s2_upper(col, R, in_part + q);
-    const uint32_t i = (row / HS) * S2_TILE + (v & ((1u << S2_W_SHIFT) - 1));
-    const uint32_t w = (v >> S2_W_SHIFT) & 15u;
-    const uint32_t r = atomicAdd(&lcur[b], 1u);
-    buf[lbase[b] + r] = entry_idx(g, (int)w, i) | (v & 0x80000000u);
+  {
+    const uint32_t r_first = s_rows[0], r_last = s_rows[1], c_end = in_part + n;
+    const uint32_t grp = threadIdx.x / S2_GRP, l = threadIdx.x % S2_GRP, ngrp = S2_THREADS / S2_GRP;
+    auto place = [&](uint32_t r, uint32_t q) {
+      const uint32_t v = tmp[pstart + q];
+      const uint32_t b = (v >> S2_LOW_SHIFT) & (NL - 1);
+      const uint32_t i = r * S2_TILE + (v & ((1u << S2_LI_BITS) - 1));
+      const uint32_t w = (v >> S2_W_SHIFT) & 15u;
+      const uint32_t rk = atomicAdd(&lcur[b], 1u);
+      buf[lbase[b] + rk] = entry_idx(g, (int)w, i) | (v & 0x80000000u);
+    };
+    for (uint32_t r = r_first + grp; r <= r_last; r += ngrp) {
+      const uint32_t lo = col[r] > in_part ? col[r] : in_part, hi = col[r + 1] < c_end ? col[r + 1] : c_end;
+      if (hi > lo && hi - lo > S2_LONG) { // (a tile of 0/1 wires: hundreds of entries of one row in one partition)
+        if (l == 0) longs[atomicAdd(&nlong, 1u)] = r;
+        continue;
+      }
+      for (uint32_t q = lo + l; q < hi; q += S2_GRP) place(r, q);
+    }
+    __syncthreads();
+    const uint32_t nl = nlong;
+    for (uint32_t j = 0; j < nl; j++) {
+      const uint32_t r = longs[j];
+      const uint32_t lo = col[r] > in_part ? col[r] : in_part, hi = col[r + 1] < c_end ? col[r + 1] : c_end;
+      for (uint32_t q = lo + threadIdx.x; q < hi; q += S2_THREADS) place(r, q);
+    }
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < NL; b += S2_THREADS) lcur[b] = offsets[(p << low_b) + b] + chunk_off[(size_t)blockIdx.x * NL + b] - lbase[b];
+  if (threadIdx.x == 0) nlong = 0;
   __syncthreads();
-  for (uint32_t e = threadIdx.x; e < n; e += S2_THREADS) {
-    const uint32_t b = s2_upper(lbase, NL, e);
-    sorted[e + lcur[b]] = buf[e];
-  }
+  s2_copy_runs(buf, lbase, lcur, NL, sorted, &nlong, longs);
+}
+// ---- order by decreasing size for the LDS-staged path: blockhist[key][P] (sort2_bucket_scan_kernel) → per key the exclusive
+// prefix over the partitions (in place), and in the workgroup that finishes last the exclusive prefix of the key totals
+__global__ __launch_bounds__(256) void sort2_order_scan_kernel(uint32_t* __restrict__ blockhist, uint32_t P, uint32_t* __restrict__ keytot, uint32_t* __restrict__ ticket)
+{
+  ISNARK_CRITICAL_CHAIN_KERNEL();
+  __shared__ uint32_t sh[SCAN_T];
+  __shared__ uint32_t s_last;
+  const uint32_t key = blockIdx.x, per = (P + 255) / 256, lo = threadIdx.x * per;
+  uint32_t* row = blockhist + (size_t)key * P;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < per; k++)
+    if (lo + k < P) s += row[lo + k];
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(s, sh, &total);
+  for (uint32_t k = 0; k < per; k++)
+    if (lo + k < P) {
+      const uint32_t v = row[lo + k];
+      row[lo + k] = run;
+      run += v;
+    }
+  if (threadIdx.x == 0) keytot[key] = total;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const uint32_t v = threadIdx.x < gridDim.x ? keytot[threadIdx.x] : 0; // ORDER_BINS = 256 keys = one per thread
+  const uint32_t ex = block_exclusive_scan(v, sh, nullptr);
+  if (threadIdx.x < gridDim.x) keytot[threadIdx.x] = ex;
+}
+__global__ __launch_bounds__(1024) void sort2_order_scatter_kernel(const uint32_t* __restrict__ counts, int low_b, const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ keybase,
+                                                                   uint32_t* __restrict__ order)
+{
+  ISNARK_CRITICAL_CHAIN_KERNEL();
+  __shared__ uint32_t h[ORDER_BINS];
+  const uint32_t NL = 1u << low_b, p = blockIdx.x, P = gridDim.x;
+  for (uint32_t k = threadIdx.x; k < (uint32_t)ORDER_BINS; k += NL) h[k] = 0;
+  __syncthreads();
+  const uint32_t b = (p << low_b) + threadIdx.x;
+  const uint32_t key = order_key(counts[b]);
+  const uint32_t r = atomicAdd(&h[key], 1u);
+  order[keybase[key] + scanned[(size_t)key * P + p] + r] = b;
 }
 
 int ilog2_ceil(uint64_t x)
@@ -955,7 +1064,8 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   // layout: counts | offsets | cursor | large_list | order | large_first | n_large[4] | tickets[TK] | bsum[nblocks] | part_count[nparts] | part_start[nparts+1] |
   //         part_cursor[nparts] | blockhist[om] | obsum[oscan] | large_items[2·item_cap]
   constexpr uint32_t TK = MSM_TICKET_SLOTS * 64;
-  const size_t head = (size_t)nb * 6 + 4 + TK + nblocks + 3 * (size_t)nparts + 1 + om + oscan;
+  constexpr uint32_t S2TK = 4; // tickets of the LDS-staged path's own last-workgroup steps (column scan, order scan)
+  const size_t head = (size_t)nb * 6 + 4 + TK + S2TK + nblocks + 3 * (size_t)nparts + 1 + om + oscan;
   HIP_TRY(ws_alloc((void**)&pl->ws, (head + 2 * (size_t)pl->item_cap + 2) * 4, s), ICICLE_ALLOCATION_FAILED);
   pl->counts = pl->ws;
   pl->offsets = pl->counts + nb;
@@ -965,7 +1075,8 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
   pl->large_first = pl->order + nb;
   pl->n_large = pl->large_first + nb;
   pl->tickets = pl->n_large + 4;
-  uint32_t* bsum = pl->tickets + TK;
+  uint32_t* s2tickets = pl->tickets + TK;
+  uint32_t* bsum = s2tickets + S2TK;
   uint32_t* part_count = bsum + nblocks;
   uint32_t* part_start = part_count + nparts;
   uint32_t* part_cursor = part_start + nparts + 1;
@@ -980,13 +1091,12 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     tmp = tmp_block;
   }
 
-  // LDS-staged path (table mode, ≥ 2^20 entries): partitions of ≈ 25 K entries, ≤ 1024 buckets each
+  // LDS-staged path (table mode, ≥ 2^17 entries): partitions of ≤ 28 K entries, ≤ 1024 buckets each
   bool lds_sort = false;
   int s2_pb = 0, s2_low = 0;
   uint32_t s2_ntiles = 0, s2_maxchunks = 0;
   size_t s2_lds_a = 0, s2_lds_b = 0;
-  uint32_t s2_hs = 1, s2_rows = 0;
-  if (g.tab && nentries >= (1u << 20) && g.W <= 16) {
+  if (g.tab && nentries >= (1u << 17) && g.W <= 16) { // (2^20 until round 5: with nine launches the staged path is no slower than the two-level one down to the witness heads and 8-way shards)
     while ((nentries >> s2_pb) > 28000) s2_pb++;
     s2_low = (g.c - 1) - s2_pb;
     if (s2_low > 10) {
@@ -994,19 +1104,18 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
       s2_low = 10;
     }
     s2_ntiles = (L + S2_TILE - 1) / S2_TILE;
-    s2_hs = (uint32_t)((g.W + S2_WGRP - 1) / S2_WGRP);
-    s2_rows = s2_ntiles * s2_hs;
     s2_maxchunks = (uint32_t)(nentries / S2_CHUNK) + (1u << s2_pb);
-    s2_lds_a = ((size_t)2 * (1u << s2_pb) + 1 + (size_t)S2_TILE * S2_WGRP) * 4;
-    s2_lds_b = ((size_t)2 * (1u << (s2_low > 0 ? s2_low : 0)) + 1 + s2_rows + 1 + S2_CHUNK) * 4;
-    lds_sort = s2_low >= 0 && s2_pb <= 12 && (1u << s2_pb) * (uint64_t)(1u << s2_low) == nb && s2_lds_a <= S2_LDS_MAX && s2_lds_b <= S2_LDS_MAX && (size_t)s2_hs * (1u << s2_pb) * 4 <= 64 * 1024;
+    s2_lds_a = ((size_t)2 * (1u << s2_pb) + 1 + (size_t)S2_TILE * g.W) * 4;
+    s2_lds_b = ((size_t)2 * (1u << (s2_low > 0 ? s2_low : 0)) + 1 + s2_ntiles + 1 + S2_CHUNK) * 4;
+    lds_sort = s2_low >= 0 && s2_pb <= 12 && (1u << s2_pb) * (uint64_t)(1u << s2_low) == nb && s2_lds_a <= S2_LDS_MAX && s2_lds_b <= S2_LDS_MAX && S2_LOW_SHIFT + s2_low <= 31 &&
+               (size_t)(1u << s2_pb) * 4 <= 64 * 1024;
   }
   if (lds_sort) {
-    const uint32_t P = 1u << s2_pb, NL = 1u << s2_low, R = s2_rows, HS = s2_hs;
-    // workspace: cnt[R][P] | off[R][P] | partial[S2_RG][P] | part_start[P + 1] | chunk_first[P + 1] | chunk_hist | chunk_off [maxchunks][NL]
+    const uint32_t P = 1u << s2_pb, NL = 1u << s2_low, R = s2_ntiles;
+    // workspace: cnt[R][P] | off[R][P] | partial[S2_RG][P] | part_start[P + 1] | chunk_first[P + 1] | chunk_hist | chunk_off [maxchunks][NL] | order hist [256][P] | keytot[256]
     WsScoped<uint32_t> s2ws;
-    const size_t n_cnt = (size_t)R * P, n_part = (size_t)S2_RG * P, n_ch = (size_t)s2_maxchunks * NL;
-    HIP_TRY(s2ws.alloc(2 * n_cnt + n_part + 2 * (size_t)P + 2 + 2 * n_ch, s), ICICLE_ALLOCATION_FAILED);
+    const size_t n_cnt = (size_t)R * P, n_part = (size_t)S2_RG * P, n_ch = (size_t)s2_maxchunks * NL, n_bh = (size_t)ORDER_BINS * P;
+    HIP_TRY(s2ws.alloc(2 * n_cnt + n_part + 2 * (size_t)P + 2 + 2 * n_ch + n_bh + ORDER_BINS, s), ICICLE_ALLOCATION_FAILED);
     uint32_t* cnt = s2ws.p;
     uint32_t* off = cnt + n_cnt;      // first entry of every (row, partition) run inside its partition
     uint32_t* partial = off + n_cnt;
@@ -1014,6 +1123,8 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     uint32_t* cfirst = pstart + P + 1;
     uint32_t* chist = cfirst + P + 1;
     uint32_t* coff = chist + n_ch;
+    uint32_t* s2bh = coff + n_ch;
+    uint32_t* keytot = s2bh + n_bh;
     WsScoped<uint32_t> s2tmp_own;
     uint32_t* s2tmp = tmp; // the scatter buffer of the two-level path when that one was set up as well
     if (!s2tmp) {
@@ -1029,22 +1140,24 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
       attr_dev_mask.fetch_or(1 << (dev & 31));
     }
     const dim3 cgrid((P + 255) / 256, S2_RG);
-    hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + TK); // n_large | tickets
-    hipLaunchKernelGGL(sort2_tile_hist_kernel, dim3(s2_ntiles), dim3(256), (size_t)HS * P * 4, s, d_scalars, L, g, mont_sc, s2_low, P, HS, cnt);
-    hipLaunchKernelGGL(sort2_col_sum_kernel, cgrid, dim3(256), 0, s, cnt, R, P, partial);
-    hipLaunchKernelGGL(sort2_col_base_kernel, dim3(1), dim3(1024), 0, s, partial, P, pstart, cfirst);
+    // nine launches: histogram (+ zeroing of n_large | tickets | this path's tickets), column scan (2), partition, chunk histogram,
+    // bucket scan (+ histogram of the bucket sizes), placement, size order (2)
+    hipLaunchKernelGGL(sort2_tile_hist_kernel, dim3(s2_ntiles), dim3(256), (size_t)P * 4, s, d_scalars, L, g, mont_sc, s2_low, P, cnt, pl->n_large, 4u + TK + S2TK);
+    hipLaunchKernelGGL(sort2_col_sum_kernel, cgrid, dim3(256), 0, s, cnt, R, P, partial, s2tickets, pstart, cfirst);
     hipLaunchKernelGGL(sort2_col_apply_kernel, cgrid, dim3(256), 0, s, cnt, off, R, P, partial);
-    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(R), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, HS, cnt, off, pstart, s2tmp);
+    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(R), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, cnt, off, pstart, s2tmp);
     hipLaunchKernelGGL(sort2_chunk_hist_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), 0, s, s2tmp, pstart, cfirst, P, s2_low, chist);
     hipLaunchKernelGGL(sort2_bucket_scan_kernel, dim3(P), dim3(NL), 0, s, chist, coff, pstart, cfirst, s2_low, thr, pl->counts, pl->offsets, pl->n_large, pl->large_list, pl->large_first,
-                       pl->large_items, pl->item_cap);
-    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, off, R, HS, g, pl->sorted);
-    ICICLE_TRY(check_launch("msm_sort (LDS-staged)"));
+                       pl->large_items, pl->item_cap, s2bh);
+    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, off, R, g, pl->sorted);
+    hipLaunchKernelGGL(sort2_order_scan_kernel, dim3(ORDER_BINS), dim3(256), 0, s, s2bh, P, keytot, s2tickets + 1);
+    hipLaunchKernelGGL(sort2_order_scatter_kernel, dim3(P), dim3(NL), 0, s, pl->counts, s2_low, s2bh, keytot, pl->order);
+    return check_launch("msm_sort (LDS-staged)");
   } else {
   unsigned zb = (3 * nb + 255) / 256;
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(msm_zero_kernel, dim3(zb), dim3(256), 0, s, pl->counts, 3 * nb); // counts | offsets | cursor
-  hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + TK + nblocks + nparts); // n_large | tickets | bsum | part_count
+  hipLaunchKernelGGL(msm_zero_kernel, dim3(8), dim3(256), 0, s, pl->n_large, 4u + TK + S2TK + nblocks + nparts); // n_large | tickets | bsum | part_count
   const unsigned lgrid = (L + 255) / 256;
   if (two_level) {
     // counts and offsets come out of the partitions: no per-digit global atomics

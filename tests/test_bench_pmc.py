@@ -11,9 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 bench = importlib.import_module("bench")
 
-LDS_SORT = ["msm_zero_kernel", "sort2_tile_hist_kernel", "sort2_col_sum_kernel", "sort2_col_base_kernel", "sort2_col_apply_kernel",
-            "sort2_tile_partition_kernel", "sort2_chunk_hist_kernel", "sort2_bucket_scan_kernel", "sort2_chunk_place_kernel",
-            "msm_order_hist_kernel", "msm_scan_sums_kernel", "msm_scan_top_kernel", "msm_scan_apply_kernel", "msm_order_scatter_kernel"]
+LDS_SORT = ["sort2_tile_hist_kernel", "sort2_col_sum_kernel", "sort2_col_apply_kernel", "sort2_tile_partition_kernel", "sort2_chunk_hist_kernel",
+            "sort2_bucket_scan_kernel", "sort2_chunk_place_kernel", "sort2_order_scan_kernel", "sort2_order_scatter_kernel"]
+LDS_SORT_R4 = ["msm_zero_kernel", "sort2_tile_hist_kernel", "sort2_col_sum_kernel", "sort2_col_base_kernel", "sort2_col_apply_kernel",
+               "sort2_tile_partition_kernel", "sort2_chunk_hist_kernel", "sort2_bucket_scan_kernel", "sort2_chunk_place_kernel",
+               "msm_order_hist_kernel", "msm_scan_sums_kernel", "msm_scan_top_kernel", "msm_scan_apply_kernel", "msm_order_scatter_kernel"]
 CLASSIC_SORT = ["msm_zero_kernel", "msm_zero_kernel", "msm_coarse_hist_kernel", "msm_part_scan_kernel", "msm_partition_kernel", "msm_fine_count_kernel",
                 "msm_fine_place_kernel", "msm_order_hist_kernel", "msm_scan_sums_kernel", "msm_scan_top_kernel", "msm_scan_apply_kernel", "msm_order_scatter_kernel"]
 ACC_G1 = "void (anonymous namespace)::msm_accumulate_kernel<bn254::G1, false, false>(bn254::G1::A const*, unsigned int const*)"
@@ -58,13 +60,14 @@ def values(scale):
 
 
 @pytest.mark.parametrize("sorts_per_prove", [2, 3])
-@pytest.mark.parametrize("kernels", [LDS_SORT, CLASSIC_SORT])
+@pytest.mark.parametrize("kernels", [LDS_SORT, CLASSIC_SORT, LDS_SORT_R4])
 def test_sorts_of_a_prove_are_grouped_by_instance(sorts_per_prove, kernels):
     fetch = canned("FETCH_SIZE", sorts_per_prove, values(1.0), sort_kernels=kernels)
     write = canned("WRITE_SIZE", sorts_per_prove, values(0.25), sort_kernels=kernels)
     s = bench.pmc_summary(fetch, write)
     assert s["sort_instances_per_prove"] == sorts_per_prove
     nz = sum(1 for k in kernels if "zero" in k)
+    first = kernels[0]
     last = 3                                           # values of the last prove are 3 × base
     per_sort = lambda base, scale: scale * base * last * len(kernels) + 0.5 * nz
     f_w = per_sort(100.0, 1.0) + (per_sort(10.0, 1.0) if sorts_per_prove == 3 else 0.0)
@@ -74,7 +77,7 @@ def test_sorts_of_a_prove_are_grouped_by_instance(sorts_per_prove, kernels):
     det = s["detail"]
     assert set(det) - {"acc_h"} == set(kernels)
     runs = sorts_per_prove - 1
-    assert det["msm_zero_kernel"]["launches"] == nz * runs and det[kernels[-1]]["launches"] == runs
+    assert det[first]["launches"] == (nz if "zero" in first else 1) * runs and det[kernels[-1]]["launches"] == runs
     # the H accumulation: the G1 launch with the most bytes among the last four, FETCH_SIZE / 1.494 (64-byte gathers) + WRITE_SIZE
     assert det["acc_h"] == {"FETCH_SIZE_KB": 2000.0 * 3, "WRITE_SIZE_KB": 500.0 * 3}
     assert s["acc_h"] == pytest.approx(6000.0 * 1024 / 1.494 + 1500.0 * 1024)
