@@ -1,7 +1,9 @@
 // common.h — shared plumbing of the C-ABI implementation (error handling, staging of host operands).
 #pragma once
 #include <atomic>
+#include <condition_variable>
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -66,6 +68,23 @@ struct StagedProgress {
   std::atomic<int> lanes_total{-1}; // set before the workers start
   std::atomic<int> lanes_reported{0};
   std::atomic<bool> done{false};    // set by whoever ran staged_copy, after it returned (error paths included)
+  // the caller BLOCKS until the head's records are in (a yield() spin until round 4: it held a CPU of the container's quota that
+  // the staging lanes and the runtime's own threads compete for)
+  std::mutex m;
+  std::condition_variable cv;
+  void notify()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    cv.notify_all();
+  }
+  void wait_head()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] {
+      const int tot = lanes_total.load(std::memory_order_acquire);
+      return (tot >= 0 && lanes_reported.load(std::memory_order_acquire) >= tot) || done.load(std::memory_order_acquire);
+    });
+  }
 };
 hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to_device, const hipStream_t* lanes = nullptr, int n_lanes = 0, bool own_temp_streams = false,
                        StagedProgress* progress = nullptr);

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include "prover_internal.h"
+#include "../workers.h"
 
 using namespace bn254;
 using namespace isnark;
@@ -480,8 +481,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       const hipStream_t lanes[3] = {gq, g3, z->s_g5}; // (two to five lanes measure the same: profiles/r04_upload_lanes.txt)
       StagedProgress prog;
       prog.head_bytes = (size_t)head * 32;
-      int up_rc = 0, wait_rc = 0; // up_rc belongs to the uploader thread until it is joined
-      std::thread uploader;
+      int up_rc = 0, wait_rc = 0; // up_rc and up_err belong to the uploader task until it has been waited for
+      std::string up_err;
+      HostTask uploader; // (a pooled worker, workers.h; waited for on every path below)
+      bool uploader_started = false;
       const void* hint_base;
       size_t hint_len;
       int hint_fd;
@@ -493,19 +496,18 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
         P_HIP(hipMemcpyAsync(z->d_witness + head, (const uint8_t*)w.values + (size_t)head * 32, (size_t)(nv - head) * 32, hipMemcpyHostToDevice, gq));
         P_HIP(hipStreamWaitEvent(g2, z->ev_head_in, 0));
       } else {
-        uploader = std::thread([&] {
+        uploader.fn = [&] {
           staged_copy_file_hint(hint_base, hint_len, hint_fd);
           up_rc = staged_upload(z->device_id, {{z->d_witness, (const uint8_t*)w.values, (size_t)nv * 32}}, lanes, 3, &prog);
+          if (up_rc) up_err = last_error_text(); // (the text lives in this worker's thread-local slot: hand it to the caller)
           staged_copy_file_hint(nullptr, 0, -1);
           prog.done.store(true, std::memory_order_release);
-        });
-        // (joined on every path below; an exception cannot occur between here and there)
-        for (;;) {
-          const int tot = prog.lanes_total.load(std::memory_order_acquire);
-          if (tot >= 0 && prog.lanes_reported.load(std::memory_order_acquire) >= tot) break;
-          if (prog.done.load(std::memory_order_acquire)) break;
-          std::this_thread::yield();
-        }
+          prog.notify();
+        };
+        // no worker to be had (thread limit of the container): the upload runs here, the head follows it instead of overlapping it
+        WorkerPool::get().run_or_inline(&uploader);
+        uploader_started = true;
+        prog.wait_head(); // blocks (condition variable) until every lane has recorded the event behind its last chunk of the head
         mark("head in");
         const int tot = prog.lanes_total.load(std::memory_order_acquire);
         for (int t = 0; t < tot; t++)
@@ -543,9 +545,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       };
       if (!wait_rc) hrc = enqueue_head();
       mark("head enq");
-      if (uploader.joinable()) uploader.join();
+      if (uploader_started && uploader.queued) WorkerPool::wait(&uploader);
       mark("upload");
-      if (up_rc) return up_rc;
+      if (up_rc) return fail(up_rc, "%s", up_err.c_str());
       if (wait_rc) return wait_rc;
       if (hrc) return hrc;
       if (pinned_src) P_HIP(hipEventRecord(z->ev_witness, gq));
@@ -756,17 +758,24 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
         et->done.fetch_add(1, std::memory_order_release);
       }
     };
-    std::thread t0(g1tail, 0, Ww, bw1, cw, (size_t)0);
-    std::thread t1(g1tail, 1, Ww, bw1, cw, (size_t)96);
-    std::thread t3(g1tail, 3, Ww, bw1, cw, (size_t)384);
-    std::thread t2([&] {
+    // the four other tails on pooled workers (workers.h), H's — the last to arrive — on this thread
+    HostTask tt[4];
+    tt[0].fn = [&] { g1tail(0, Ww, bw1, cw, (size_t)0); };
+    tt[1].fn = [&] { g1tail(1, Ww, bw1, cw, (size_t)96); };
+    tt[3].fn = [&] { g1tail(3, Ww, bw1, cw, (size_t)384); };
+    tt[2].fn = [&] {
       (void)hipSetDevice(dev);
       (void)hipEventSynchronize(evd[2]);
       if (gw.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Wb, (bn254_g2_projective_t*)(out_points + 192));
       else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Wb, 1, cw, gw.wide, (bn254_g2_projective_t*)(out_points + 192));
-    });
+    };
+    bool pooled[4];
+    for (int k = 0; k < 4; k++) pooled[k] = WorkerPool::get().submit(&tt[k]);
     g1tail(4, Wh, bh, ch, 480);
-    t0.join(); t1.join(); t2.join(); t3.join();
+    for (int k = 0; k < 4; k++) {
+      if (pooled[k]) WorkerPool::wait(&tt[k]);
+      else tt[k].fn(); // (no worker was to be had: after H's, on this thread)
+    }
   }
   mark("tails");
   // every tail thread has waited for its MSM's ev_done (recorded behind the last operation of that MSM's chain), so all six
@@ -1042,10 +1051,14 @@ __attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheMa
   EarlyTerms et;
   et.bl = &bl;
   int bl_rc = 0;
-  std::thread th([&] {
+  std::string bl_err;
+  HostTask bt;
+  bt.fn = [&] {
     bl_rc = compute_blinding(z, r, s, &bl);
+    if (bl_rc) bl_err = last_error_text();
     et.bl_ready.store(true, std::memory_order_release);
-  });
+  };
+  WorkerPool::get().run_or_inline(&bt); // (inline when no worker is to be had: before the commitments instead of beside them)
   int rc;
   {
     std::lock_guard<std::mutex> lk(cm->mu);
@@ -1053,9 +1066,9 @@ __attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheMa
     rc = grp ? group_commitments(cm, grp.get(), wtns_resident ? nullptr : wtns, wtns_len, pts, tm)
              : shard_commitments(cm, zp.get(), wtns_resident ? nullptr : wtns, wtns_len, pts, tm, &et);
   }
-  th.join();
+  if (bt.queued) WorkerPool::wait(&bt);
   if (rc) return rc;
-  if (bl_rc) return fail(bl_rc, "no entropy source for the blinding scalars"); // (the message was set on the helper thread)
+  if (bl_rc) return fail(bl_rc, "%s", bl_err.empty() ? "no entropy source for the blinding scalars" : bl_err.c_str());
   const auto ta = std::chrono::steady_clock::now();
   rc = assemble_impl(z, wtns, wtns_len, pts, bl, proof_json, proof_cap, public_json, public_cap, grp ? nullptr : &et);
   if (getenv("ICICLE_SNARK_TRACE_HOST")) fprintf(stderr, "[host] assemble %8.1f us (after %8.1f us)\n", ms_since(ta) * 1e3, std::chrono::duration<double, std::micro>(ta - t0).count());

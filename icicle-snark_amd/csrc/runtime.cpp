@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "msm_plan.h"
+#include "workers.h"
 
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share
 // a queue serialise.  The prover overlaps five streams; with four queues two of them collide and a
@@ -237,6 +238,7 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
       if (hipEventRecord(P.head_ev[t], streams[t]) != hipSuccess) err = (int)hipErrorUnknown;
       progress->ev[t] = P.head_ev[t];
       progress->lanes_reported.fetch_add(1, std::memory_order_release);
+      progress->notify();
     };
     struct ReportOnExit {
       decltype(report_head)& f;
@@ -308,11 +310,21 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
     if (e != hipSuccess) err = (int)e;
   };
   const int nt = chunks.size() < (size_t)max_lanes ? (int)chunks.size() : max_lanes;
-  if (progress) progress->lanes_total.store(nt, std::memory_order_release);
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
+  if (progress) {
+    progress->lanes_total.store(nt, std::memory_order_release);
+    progress->notify();
+  }
+  // lanes 1 … nt − 1 on pooled workers (workers.h; a lane the pool cannot take runs here, after lane 0), lane 0 on this thread
+  HostTask tasks[STAGED_LANES];
+  for (int t = 1; t < nt; t++) {
+    tasks[t].fn = [&worker, t] { worker(t); };
+    if (!WorkerPool::get().submit(&tasks[t])) tasks[t].queued = false;
+  }
   if (nt > 0) worker(0);
-  for (auto& x : th) x.join();
+  for (int t = 1; t < nt; t++) {
+    if (tasks[t].queued) WorkerPool::wait(&tasks[t]);
+    else worker(t);
+  }
   for (hipStream_t x : temp) (void)hipStreamDestroy(x);
   return (hipError_t)err.load();
 }

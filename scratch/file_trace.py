@@ -13,6 +13,8 @@ zp, wp = d + "/c.zkey", d + "/w.wtns"
 open(zp, "wb").write(zkey); open(wp, "wb").write(wtns)
 cm = K.CacheManager()
 for i in range(8):
+    if i == 1:
+        cm.tables_ready(zp + "_HIP", wait=True)
     t = time.perf_counter()
     cm.prove_files(wp, zp, d + "/p.json", d + "/q.json")
     print(f"call {i}: {1e3 * (time.perf_counter() - t):.3f} ms", file=sys.stderr, flush=True)
