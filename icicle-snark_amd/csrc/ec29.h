@@ -2,7 +2,7 @@
 //
 // Same formulas as ec.h (EFD madd-2008-s / add-2008-s / dbl-2008-s-1, a = 0), re-stated with explicit bounds.
 // INVARIANT of every stored coordinate (accumulator X, Y, ZZ, ZZZ; per Fq2 component for G2):
-//      limbs N (l[0..7] < 2^29),  value < 2·p,  Montgomery form with R' = 2^261.
+//      limbs N (l[0..7] < 2^29),  value < 2·p (G1's X: < 7·p, see below),  Montgomery form with R' = 2^261.
 // The identity is the all-zero tuple (a live ZZ is a product of non-zero field elements: never ≡ 0, so its limbs
 // are never all zero).  Affine inputs obey the same invariant (canonical values from memory, or mul outputs).
 //
@@ -16,6 +16,13 @@
 //   D = Q + 3p − X3   sub<3,1>                                              → limbs < 2^29 + 2^30, <5
 //   Y3 = Rn·D + (3p − Y1)·PPP   one reduction (G1: mul2; G2: mul4 on normalised operands) → N, <2
 //   ZZ3 = ZZ1·PP, ZZZ3 = ZZZ1·PPP                                           → N, <2
+// G1 since round 5: X is the one coordinate that is not a product, and the two conditional subtractions that brought it back
+// below 2p (reduce_lt2p: 90 of the ≈ 740 non-multiplier instructions of a mixed addition) are gone — an X is N and < 7·p
+// (XBOUND), and whoever subtracts an X does it against 8p (subx):
+//   P = U2 + 8p − X1  <10 → Pn;  PP = Pn² (100 p² < 147 p²), PPP = Pn·PP (20 p²), Q = X1·PP (14 p²)
+//   X3 = RR + 5p − T  <6.75 → norm → N, <7          D = Q + 8p − X3  <10, limbs < 2^29 + 2^30
+//   Y3 = Rn·D + (3p − Y1)·PPP: 50 p² + 3.5 p²; columns 9·(2^29·3·2^29 + 2^30·2^29 + 2^58) = 54·2^58 < 2^64 as before
+// G2 keeps the reduction: its Fq2 square (a0 + a1)(a0 + 6p − a1) has no room for components beyond 5p.
 // Fq2 products are formed as  c0 = a0·b0 + a1·(3p − b1),  c1 = a0·b1 + a1·b0  (mul2, one reduction each) and squares
 // as  c0 = (a0 + a1)(a0 + 6p − a1),  c1 = a0·(2·a1)  with a <5 N:  (a0+a1) <10 normalised, (a0 + 6p − a1) <11 → 110 p² < 147 p².
 // `F29_CHECK` host builds assert every limb/column/value condition (tests/test_f29.py drives them, incl. extremal inputs).
@@ -45,13 +52,18 @@ struct Fq29 {
   static FF_HD T mul(const T& a, const T& b) { return f29::mul(a, b); }
   static FF_HD T sqr_n(const T& a) { return f29::sqr(a); }                        // a N, <12
   static FF_HD T sub3(const T& a, const T& b) { return f29::sub<3, 1>(a, b); }    // a + 3p − b, b N <2
+  static FF_HD T subx(const T& a, const T& x) { return f29::sub<8, 1>(a, x); }    // a + 8p − x, x an X coordinate: N, <7
   static FF_HD T norm(const T& a) { return f29::norm(a); }
   static FF_HD T dbl(const T& a) { return f29::dbl(a); }
   static FF_HD T tripled(const T& a) { return f29::add(f29::dbl(a), a); }         // a N → limbs < 3·2^29, <6
   static FF_HD T lt2p(const T& a) { return f29::reduce_lt2p(f29::norm(a)); }      // a <8 → N, <2
-  static FF_HD T x3(const T& RR, const T& PPP, const T& Q)                         // RR − PPP − 2Q → N, <2
+  static FF_HD T x3(const T& RR, const T& PPP, const T& Q)                         // RR − PPP − 2Q → N, <7 (RR <2 + 5p): no reduction
   {
-    return f29::reduce_lt2p(f29::norm(f29::sub<5, 3>(RR, f29::add(PPP, f29::dbl(Q)))));
+    const T r = f29::norm(f29::sub<5, 3>(RR, f29::add(PPP, f29::dbl(Q))));
+#if defined(F29_CHECK)
+    F29_ASSERT(f29::approx_over_p(r) < 7.0L, "f29: X3 not below 7p");
+#endif
+    return r;
   }
   static FF_HD T y3(const T& Rn, const T& D, const T& Y1, const T& PPP) { return f29::mul2(Rn, D, f29::neg<3, 1>(Y1), PPP); }
   static FF_HD bool maybe_zero(const T& an) { return f29::maybe_zero_mod_p(an); }  // an N, <16
@@ -89,11 +101,15 @@ struct Fq2_29 {
     return {f29::mul(s, d), f29::mul(a.c0, f29::dbl(a.c1))};
   }
   static FF_HD T sub3(const T& a, const T& b) { return {f29::sub<3, 1>(a.c0, b.c0), f29::sub<3, 1>(a.c1, b.c1)}; }
+  static FF_HD T subx(const T& a, const T& x) { return sub3(a, x); } // (an Fq2 X is reduced below 2p: see x3)
   static FF_HD T norm(const T& a) { return {f29::norm(a.c0), f29::norm(a.c1)}; }
   static FF_HD T dbl(const T& a) { return {f29::dbl(a.c0), f29::dbl(a.c1)}; }
   static FF_HD T tripled(const T& a) { return {Fq29::tripled(a.c0), Fq29::tripled(a.c1)}; }
   static FF_HD T lt2p(const T& a) { return {Fq29::lt2p(a.c0), Fq29::lt2p(a.c1)}; }
-  static FF_HD T x3(const T& RR, const T& PPP, const T& Q) { return {Fq29::x3(RR.c0, PPP.c0, Q.c0), Fq29::x3(RR.c1, PPP.c1, Q.c1)}; }
+  static FF_HD T x3(const T& RR, const T& PPP, const T& Q) // per component RR − PPP − 2Q → N, <2
+  {
+    return {f29::reduce_lt2p(Fq29::x3(RR.c0, PPP.c0, Q.c0)), f29::reduce_lt2p(Fq29::x3(RR.c1, PPP.c1, Q.c1))};
+  }
   // Y3 = R·D − Y1·PPP, four products per component in one reduction; D is normalised first (column bound 36·2^58)
   static FF_HD T y3(const T& Rn, const T& D, const T& Y1, const T& PPP)
   {
@@ -178,7 +194,7 @@ struct CurveL {
     }
     const T U2 = F::mul(b.x, acc.zz);
     const T S2 = F::mul(b.y, acc.zzz);
-    const T Pn = F::norm(F::sub3(U2, acc.x));
+    const T Pn = F::norm(F::subx(U2, acc.x));
     const T Rn = F::norm(F::sub3(S2, acc.y));
     if (F::maybe_zero(Pn) && F::is_zero_full(Pn)) { // same x: doubling or cancellation
       if (F::is_zero_full(Rn)) acc = x_dbl_affine_exact(b);
@@ -190,7 +206,7 @@ struct CurveL {
     const T Q = F::mul(acc.x, PP);
     const T RR = F::sqr_n(Rn);
     const T X3 = F::x3(RR, PPP, Q);
-    const T D = F::sub3(Q, X3);
+    const T D = F::subx(Q, X3);
     acc.y = F::y3(Rn, D, acc.y, PPP);
     acc.x = X3;
     acc.zz = F::mul(acc.zz, PP);
@@ -210,7 +226,7 @@ struct CurveL {
     const T Mn = F::lt2p(F::tripled(XX)); // 3·XX <6, normalised and reduced: N, <2
     const T MM = F::sqr_n(Mn);
     const T X3 = F::x3(MM, F::zero(), S);
-    const T D = F::sub3(S, X3);
+    const T D = F::subx(S, X3);
     return {X3, F::y3(Mn, D, p.y, W), F::mul(V, p.zz), F::mul(W, p.zzz)};
   }
 
@@ -234,7 +250,7 @@ struct CurveL {
     const T Q = F::mul(U1, PP);
     const T RR = F::sqr_n(Rn);
     const T X3 = F::x3(RR, PPP, Q);
-    const T D = F::sub3(Q, X3);
+    const T D = F::subx(Q, X3);
     return {X3, F::y3(Rn, D, S1, PPP), F::mul(F::mul(a.zz, b.zz), PP), F::mul(F::mul(a.zzz, b.zzz), PPP)};
   }
 

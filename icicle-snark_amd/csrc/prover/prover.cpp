@@ -578,35 +578,38 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   (void)hipEventRecord(z->ev_t_witness, gq);
 
   // ---- ONE digit sort of the witness range (shared by A, B1, B2, C) — of its tail when the head was sorted above — on g2
-  // without a head (the G2 bucket stages follow it there) and on g3 with one (g2 still carries B2's head accumulation)
+  // without a head (the G2 bucket stages follow it there) and on g3 with one (g2 still carries B2's head accumulation).
+  // Enqueued BEHIND the front end for the large circuits (round 5): the front end is their critical chain and its first kernel
+  // used to sit behind the nine launches of the sort on the host, ≈ 50 µs after the last byte of the witness had landed; the
+  // small circuits and the shards that start from their own slice begin their accumulations right behind the sort: sort first.
   hipStream_t gs = head ? g3 : g2;
-  P_HIP(hipStreamWaitEvent(gs, own_slice_first ? z->ev_own_slice : z->ev_witness, 0));
-  // the witness sort is timed with the profile of the G2 MSM
-  MsmProfile* psort = prof[2];
-  (void)hipEventRecord(psort->ev[0], gs);
-  {
-    const uint32_t tail_len = wlen - head;
-    const uint64_t hint = adapted_w ? (uint64_t)((double)z->witness_entries * tail_len / wlen) + 1 : 0;
-    P_ICICLE(msm_sort_run(z->d_witness + wlo + head, tail_len, 0, 0, 0, gs, &plan_w, head || adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, hint));
-  }
-  if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c || (head && plan_w.nbuckets != plan_head.nbuckets))
-    return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
-  (void)hipEventRecord(psort->ev[4], gs); // end of the witness digit sort (roofline.scatter)
-  psort->has_sort_end = true;
-  P_HIP(hipEventRecord(z->ev_sort, gs));
-  // entry counts of the sorts (offset + count of the last bucket), read at the end of the prove: they steer the digit width of
-  // the key's witness tables (cache.cpp: rebuild_witness_tables)
-  z->h_stats[0] = z->h_stats[1] = 0;
-  if (!head) z->h_stats[2] = z->h_stats[3] = 0; // (with a head: written by the copies behind the head's sort on g2)
-  if (plan_w.nbuckets) {
-    P_HIP(hipMemcpyAsync(&z->h_stats[0], plan_w.offsets + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
-    P_HIP(hipMemcpyAsync(&z->h_stats[1], plan_w.counts + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
-  }
-  mark("wsort");
-  auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
-    p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
+  MsmProfile* psort = prof[2]; // the witness sort is timed with the profile of the G2 MSM
+  auto enqueue_witness_sort = [&]() -> int {
+    P_HIP(hipStreamWaitEvent(gs, own_slice_first ? z->ev_own_slice : z->ev_witness, 0));
+    (void)hipEventRecord(psort->ev[0], gs);
+    {
+      const uint32_t tail_len = wlen - head;
+      const uint64_t hint = adapted_w ? (uint64_t)((double)z->witness_entries * tail_len / wlen) + 1 : 0;
+      P_ICICLE(msm_sort_run(z->d_witness + wlo + head, tail_len, 0, 0, 0, gs, &plan_w, head || adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, hint));
+    }
+    if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c || (head && plan_w.nbuckets != plan_head.nbuckets))
+      return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
+    (void)hipEventRecord(psort->ev[4], gs); // end of the witness digit sort (roofline.scatter)
+    psort->has_sort_end = true;
+    P_HIP(hipEventRecord(z->ev_sort, gs));
+    // entry counts of the sorts (offset + count of the last bucket), read at the end of the prove: they steer the digit width of
+    // the key's witness tables (cache.cpp: rebuild_witness_tables)
+    z->h_stats[0] = z->h_stats[1] = 0;
+    if (!head) z->h_stats[2] = z->h_stats[3] = 0; // (with a head: written by the copies behind the head's sort on g2)
+    if (plan_w.nbuckets) {
+      P_HIP(hipMemcpyAsync(&z->h_stats[0], plan_w.offsets + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
+      P_HIP(hipMemcpyAsync(&z->h_stats[1], plan_w.counts + plan_w.nbuckets - 1, 4, hipMemcpyDeviceToHost, gs));
+    }
+    mark("wsort");
+    return 0;
   };
-  uint8_t* DP = z->d_partials;
+  if (early)
+    if (int rc = enqueue_witness_sort()) return rc;
 
   // ---- stream gq: construct_r1cs (src/proof_helper.rs:31-170) on the device
   P_HIP(hipStreamWaitEvent(gq, z->ev_witness, 0));
@@ -664,6 +667,14 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   }
   P_HIP(hipEventRecord(z->ev[2], gq));
   mark("qap");
+
+  if (!early)
+    if (int rc = enqueue_witness_sort()) return rc;
+  auto fill = [](MsmProfile* p, const SortPlan& pl, int g2flag) {
+    p->L = pl.L; p->nbuckets = pl.nbuckets; p->c = pl.g.c; p->W = pl.g.W; p->is_g2 = g2flag;
+  };
+  uint8_t* DP = z->d_partials;
+
 
   // ---- groth16_commitments — src/proof_helper.rs:198-206.  A, B1, B2, C share the witness sort and run on four streams.
   // Held back until the QAP front end is done (large circuits): the accumulations fill every CU with milliseconds-long
