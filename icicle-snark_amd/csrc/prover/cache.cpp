@@ -346,7 +346,14 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   // (msm_plan.h; ICICLE_SNARK_TABLES=0 disables it): every base array becomes W rows 2^(c·w)·P so that all digits of a
   // scalar share one bucket set — 13 instead of 16 mixed additions per scalar at 1.6 M constraints for 13× the base memory.
   {
-    bool tables = !(getenv("ICICLE_SNARK_TABLES") && atoi(getenv("ICICLE_SNARK_TABLES")) == 0);
+    const int tables_env = getenv("ICICLE_SNARK_TABLES") ? atoi(getenv("ICICLE_SNARK_TABLES")) : 1;
+    bool tables = tables_env != 0;
+    // Above 2^22 points the 32-bit sort entry has no room for 20-bit digits beside the point index (msm_sort.hip: tab_low_bits):
+    // the tables would fall back to c = 19 / 14 digits, and measured at 6.4 M constraints (domain 2^23) that is no faster than the
+    // classic layout with c = 16 / 16 digits — 65.4 against 64.3 ms resident — for 37.7 instead of 4.4 GB of device memory and a
+    // second of table build (tests/test_gpu_fullsize.py::test_prove_at_domain_2p23_…): such keys stay classic
+    // (ICICLE_SNARK_TABLES=2 builds the tables all the same).
+    if (tables_env < 2 && (z->A.len() > (1u << 22) || z->H.len() > (1u << 22))) tables = false;
     z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
     z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
     if (tables) {

@@ -400,3 +400,56 @@ def test_benchmark_3200k_sharded_commitments(gpu, O):
         assert R.groth16_verify(json.loads(want), json.loads(public), vk)
     cm.close()
     K.release_domain()
+
+
+def test_prove_at_domain_2p23_table_and_classic_layouts(gpu, O, monkeypatch):
+    """Above every BASELINE size: a squaring chain of 6.4 M constraints (domain 2^23, 3.1 GB zkey, 205 MB witness).  The 32-bit
+    sort entry has no room for a 23-bit point index beside 20-bit digits: tables would fall back to narrower digits, which is no
+    faster than the classic layout with one bucket set per window (what the reference's bucket method does when it lowers c,
+    cuda_msm.cuh:1204-1254), so a key of this size stays classic by default; ICICLE_SNARK_TABLES=2 forces the tables.  No oracle at this size: the checks are the size-independent ones — the public
+    signal 3^(2^N), determinism under fixed (r, s), the table-mode and the classic-layout provers agreeing bit for bit, the
+    library's pairing check and the reference's (when oracle/_ref is present)."""
+    K = gpu
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    S = importlib.import_module("icicle-snark_amd.synth")
+    N = 6_400_000
+    zkey, wtns = bench.make_inputs(K, S, N)
+    cm = K.CacheManager()
+    monkeypatch.setenv("ICICLE_SNARK_TABLES", "2")     # tables although the key is above the size where they pay (cache.cpp)
+    cm.load("big", zkey)
+    info = cm.info("big")
+    assert (info.n_vars, info.domain_size) == (N + 2, 1 << 23)
+    import time
+    t0 = time.perf_counter()
+    p1, q1, tm = cm.prove_mem("big", wtns, 5, 9)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        p2, q2, tm = cm.prove_mem("big", wtns, 5, 9, resident=True)
+        ts.append((time.perf_counter() - t0) * 1e3)
+        assert p2 == p1 and q2 == q1
+    geom = K.msm_profile(0)[1]
+    print(f"[2^23] table layout: c = {geom['c']}, W = {geom['W']}, {info.device_bytes / 1e9:.1f} GB; first prove {first_ms:.1f} ms, resident {sorted(ts)[1]:.1f} ms (qap {tm.qap_ms:.1f}, msm {tm.msm_ms:.1f})")
+    assert json.loads(q1) == [str(pow(3, 1 << N, S.R_MOD))]
+    vk = _vk_of(O, zkey)
+    assert K.groth16_verify_json(p1, q1, S.vk_to_json(vk))
+    import ref as R
+    if R.available():
+        assert R.groth16_verify(json.loads(p1), json.loads(q1), vk)
+    cm.evict("big")
+    # the classic layout (one bucket set per window, 16-bit digits) — what a key of this size gets by default: the same proof
+    monkeypatch.delenv("ICICLE_SNARK_TABLES")
+    cm.load("classic", zkey)
+    assert cm.info("classic").device_bytes < 6e9
+    t0 = time.perf_counter()
+    p3, q3, _ = cm.prove_mem("classic", wtns, 5, 9)
+    t0 = time.perf_counter()
+    p3b, _, tm3 = cm.prove_mem("classic", wtns, 5, 9, resident=True)
+    classic_ms = (time.perf_counter() - t0) * 1e3
+    geom3 = K.msm_profile(0)[1]
+    print(f"[2^23] classic layout: c = {geom3['c']}, W = {geom3['W']}, {cm.info('classic').device_bytes / 1e9:.1f} GB; resident {classic_ms:.1f} ms (qap {tm3.qap_ms:.1f}, msm {tm3.msm_ms:.1f})")
+    assert p3 == p1 and q3 == q1 and p3b == p1
+    cm.close()
+    K.release_domain()
