@@ -1098,8 +1098,10 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
   bool use_table = false;
   struct Unpin {
     uint64_t id = 0;
-    ~Unpin() { base_table_unpin(id); } // after the last kernel of this call has been enqueued (hipFree waits for enqueued work)
+    hipStream_t s = nullptr;
+    ~Unpin() { base_table_unpin(id, s); } // after the last kernel of this call has been enqueued (hipFree waits for enqueued work)
   } unpin;
+  unpin.s = s;
   WsScoped<unsigned long long> cur_sum;
   if (batch == 1 && stride == 1 && cfg->c <= 0 && (cfg->bitsize == 0 || cfg->bitsize == 254) && cfg->are_points_on_device && L >= MSM_AUTO_TABLE_MIN_L &&
       is_tracked_device_ptr(bases)) {
@@ -1127,6 +1129,9 @@ eIcicleError msm_impl(const bn254_scalar_t* scalars, const AT* bases, int msm_si
         unpin.id = tref.id;
         use_table = true;
         if (tref.built) HIP_TRY(hipStreamWaitEvent(s, tref.built, 0), ICICLE_UNKNOWN_ERROR); // built on another stream, perhaps
+        // … and behind the kernels of the previous call that read the table, whatever stream they are on: the refresh below may
+        // rewrite rows in place (round-4 advisor: only the calling stream's own order protected them)
+        if (tref.used) HIP_TRY(hipStreamWaitEvent(s, tref.used, 0), ICICLE_UNKNOWN_ERROR);
         // the caller may have rewritten its bases by means this library does not see (own kernels, raw hipMemcpy): hash them
         // now, in stream order, and let the guarded refresh bring the table up to date when the sum has moved
         HIP_TRY(cur_sum.alloc(8, s), ICICLE_ALLOCATION_FAILED);

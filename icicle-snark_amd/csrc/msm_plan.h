@@ -69,8 +69,10 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab = 0, int bits = 0, int pf = 
 // run by ~SortPlan).
 // `entries_hint` > 0: the number of non-zero digits the caller expects (a witness-light key adapted to its witnesses, prover.cpp):
 // the large-bucket threshold is then 3 × that average instead of 3 × the dense one.
+// `crowded`: the sort will run beside kernels that keep every SIMD's wave slots and registers nearly full (the bucket accumulations):
+// its big kernels then use 256-thread workgroups, which find room where 512-thread ones wait for milliseconds (msm_sort.hip).
 eIcicleError msm_sort_run(const bn254::fe* d_scalars, uint32_t L, int c_cfg, int large_bucket_factor, int scalars_mont, hipStream_t s, SortPlan* pl, int tab = 0, int bits = 0, int pf = 1,
-                          uint64_t entries_hint = 0);
+                          uint64_t entries_hint = 0, bool crowded = false);
 void msm_sort_release(SortPlan* pl);
 
 // ring of the most recent MSM launches of this process: HIP events (recorded on the MSM's own stream,
@@ -162,13 +164,14 @@ struct BaseTableRef {
   hipEvent_t built = nullptr;        // recorded behind the build on the building stream
   unsigned long long* sums = nullptr; // device: [0] hash sum of the bases the table was built from
   uint64_t id = 0;                    // pin to release with base_table_unpin once the call's kernels are enqueued (0: none)
+  hipEvent_t used = nullptr;          // behind the last kernel of the previous call that used the table (any stream); nullptr: none yet
 };
 enum BaseTableState { BASE_TABLE_NONE = 0, BASE_TABLE_BUILD = 1, BASE_TABLE_HIT = 2 };
 // NONE: run the classic layout (first sighting, not eligible, no memory); BUILD: the caller builds a table of geometry ref->g and
 // hands it to base_table_publish (which pins it: ref->id); HIT: *ref is valid and pinned
 BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bool g2, int form, size_t table_bytes, BaseTableRef* ref);
 void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, unsigned long long* sums, hipStream_t s, BaseTableRef* ref);
-void base_table_unpin(uint64_t id);
+void base_table_unpin(uint64_t id, hipStream_t s); // s: the stream the call's kernels went to (its last-use mark is recorded there)
 
 bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
 bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);

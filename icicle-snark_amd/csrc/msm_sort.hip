@@ -563,7 +563,14 @@ __global__ __launch_bounds__(256) void msm_fine_place_kernel(const uint32_t* __r
 constexpr int S2_TILE = 1024;    // scalars per tile (pass A): a row = (tile, all W ≤ 16 windows) stages ≤ 64 KiB of entries in LDS
 constexpr int S2_CHUNK = 12288;  // entries per chunk (pass B): 48 KiB of LDS
 constexpr int S2_LI_BITS = 10, S2_W_SHIFT = 10, S2_LOW_SHIFT = 14;
-constexpr int S2_THREADS = 512;
+// Workgroup size of the three big kernels (partition, chunk histogram, placement): 512 threads when the sort has the GPU to itself
+// or shares it with the transforms, 256 (`crowded`) when it runs beside the bucket accumulations — a 512-thread workgroup needs two
+// free wave slots with 64 registers each on ALL FOUR SIMDs of a CU at once, and beside three 136-register accumulation waves per
+// SIMD (104 registers left) that happens only when waves retire in step: H's sort took 9 ms beside the witness accumulations
+// (0.45 ms alone; its partition pass alone 4.9–5.3 ms) and had become what H's accumulation waits for.  One wave per SIMD fits the
+// gap: 2.9 ms (profiles/r05_ab_sort_wg256.txt).  The witness sort keeps 512: beside the transforms the smaller groups slow the
+// front end by 0.14 ms.
+constexpr int S2_THREADS_WIDE = 512, S2_THREADS_CROWDED = 256;
 constexpr int S2_RG = 32;        // row groups of the column scan
 constexpr int S2_GRP = 16;       // lanes that copy one run
 constexpr uint32_t S2_LONG = 192; // a run above this is copied by the whole workgroup
@@ -711,6 +718,7 @@ __global__ __launch_bounds__(256) void sort2_col_apply_kernel(const uint32_t* __
   }
 }
 // pass A, step 2: the tile's entries — every window, one recode — sorted by partition in LDS, then copied out run by run
+template <int S2_THREADS>
 __global__ __launch_bounds__(S2_THREADS) void sort2_tile_partition_kernel(const fe* __restrict__ scalars, uint32_t L, MsmGeom g, int mont, int low_b, uint32_t P,
                                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ part_start,
                                                                            uint32_t* __restrict__ tmp)
@@ -767,6 +775,7 @@ __device__ __forceinline__ bool s2_chunk_of(uint32_t c, const uint32_t* __restri
   return true;
 }
 // pass B, step 1: histogram of a chunk over the partition's 2^low_b buckets
+template <int S2_THREADS>
 __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_hist_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, int low_b,
                                                                        uint32_t* __restrict__ chunk_hist)
 {
@@ -826,6 +835,7 @@ __global__ __launch_bounds__(1024) void sort2_bucket_scan_kernel(const uint32_t*
 // pass B, step 3: the chunk counting-sorted by bucket in LDS (entries rewritten with the global scalar index), copied out run
 // by run.  The chunk is walked row by row: col[r] = first entry of row r's run inside the partition (the partition's column of
 // `off`), 16 lanes per row — the tile of an entry is the row it is read from.
+template <int S2_THREADS>
 __global__ __launch_bounds__(S2_THREADS) void sort2_chunk_place_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ chunk_first, uint32_t P, int low_b,
                                                                         const uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ offsets,
                                                                         const uint32_t* __restrict__ off, uint32_t R, MsmGeom g, uint32_t* __restrict__ sorted)
@@ -1021,7 +1031,7 @@ MsmGeom msm_geometry(uint32_t L, int c_cfg, int tab, int bits, int pf)
   return g;
 }
 
-eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl, int tab, int bits, int pf, uint64_t entries_hint)
+eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, int mont_sc, hipStream_t s, SortPlan* pl, int tab, int bits, int pf, uint64_t entries_hint, bool crowded)
 {
   pl->g = msm_geometry(L, c_cfg, tab, bits, pf);
   const MsmGeom& g = pl->g;
@@ -1135,8 +1145,10 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!(attr_dev_mask.load() & (1 << (dev & 31)))) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_chunk_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_tile_partition_kernel<S2_THREADS_WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_chunk_place_kernel<S2_THREADS_WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_tile_partition_kernel<S2_THREADS_CROWDED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort2_chunk_place_kernel<S2_THREADS_CROWDED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_MAX), ICICLE_UNKNOWN_ERROR);
       attr_dev_mask.fetch_or(1 << (dev & 31));
     }
     const dim3 cgrid((P + 255) / 256, S2_RG);
@@ -1145,11 +1157,18 @@ eIcicleError msm_sort_run(const fe* d_scalars, uint32_t L, int c_cfg, int lbf, i
     hipLaunchKernelGGL(sort2_tile_hist_kernel, dim3(s2_ntiles), dim3(256), (size_t)P * 4, s, d_scalars, L, g, mont_sc, s2_low, P, cnt, pl->n_large, 4u + TK + S2TK);
     hipLaunchKernelGGL(sort2_col_sum_kernel, cgrid, dim3(256), 0, s, cnt, R, P, partial, s2tickets, pstart, cfirst);
     hipLaunchKernelGGL(sort2_col_apply_kernel, cgrid, dim3(256), 0, s, cnt, off, R, P, partial);
-    hipLaunchKernelGGL(sort2_tile_partition_kernel, dim3(R), dim3(S2_THREADS), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, cnt, off, pstart, s2tmp);
-    hipLaunchKernelGGL(sort2_chunk_hist_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), 0, s, s2tmp, pstart, cfirst, P, s2_low, chist);
-    hipLaunchKernelGGL(sort2_bucket_scan_kernel, dim3(P), dim3(NL), 0, s, chist, coff, pstart, cfirst, s2_low, thr, pl->counts, pl->offsets, pl->n_large, pl->large_list, pl->large_first,
-                       pl->large_items, pl->item_cap, s2bh);
-    hipLaunchKernelGGL(sort2_chunk_place_kernel, dim3(s2_maxchunks), dim3(S2_THREADS), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, off, R, g, pl->sorted);
+#define ISNARK_S2_BIG(T)                                                                                                                                                                    \
+  hipLaunchKernelGGL(sort2_tile_partition_kernel<T>, dim3(R), dim3(T), s2_lds_a, s, d_scalars, L, g, mont_sc, s2_low, P, cnt, off, pstart, s2tmp);                                          \
+  hipLaunchKernelGGL(sort2_chunk_hist_kernel<T>, dim3(s2_maxchunks), dim3(T), 0, s, s2tmp, pstart, cfirst, P, s2_low, chist);                                                               \
+  hipLaunchKernelGGL(sort2_bucket_scan_kernel, dim3(P), dim3(NL), 0, s, chist, coff, pstart, cfirst, s2_low, thr, pl->counts, pl->offsets, pl->n_large, pl->large_list, pl->large_first,    \
+                     pl->large_items, pl->item_cap, s2bh);                                                                                                                                   \
+  hipLaunchKernelGGL(sort2_chunk_place_kernel<T>, dim3(s2_maxchunks), dim3(T), s2_lds_b, s, s2tmp, pstart, cfirst, P, s2_low, chist, coff, pl->offsets, off, R, g, pl->sorted)
+    if (crowded) {
+      ISNARK_S2_BIG(S2_THREADS_CROWDED);
+    } else {
+      ISNARK_S2_BIG(S2_THREADS_WIDE);
+    }
+#undef ISNARK_S2_BIG
     hipLaunchKernelGGL(sort2_order_scan_kernel, dim3(ORDER_BINS), dim3(256), 0, s, s2bh, P, keytot, s2tickets + 1);
     hipLaunchKernelGGL(sort2_order_scatter_kernel, dim3(P), dim3(NL), 0, s, pl->counts, s2_low, s2bh, keytot, pl->order);
     return check_launch("msm_sort (LDS-staged)");

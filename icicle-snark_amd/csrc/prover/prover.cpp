@@ -702,7 +702,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
   P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
   (void)hipEventRecord(prof[4]->ev[0], g3);
-  P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab));
+  // (`crowded`: H's sort runs beside the four witness accumulations of a large circuit)
+  P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab, 0, 1, 0, /*crowded=*/!early));
   if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
   (void)hipEventRecord(prof[4]->ev[4], g3);
   prof[4]->has_sort_end = true;

@@ -489,6 +489,8 @@ struct BaseTable {
   unsigned long long* sums; // device: hash sum of the bases at build time (msm_plan.h)
   int pins;                 // calls that hold the table between lookup and the end of their enqueueing
   uint64_t id;
+  hipEvent_t used = nullptr; // recorded behind the last kernel of the most recent call that used the table (base_table_unpin), on that call's
+                             // stream: a call on ANOTHER stream waits for it before its guarded refresh may rewrite rows those kernels read
 };
 static std::mutex g_bt_mu;
 static std::vector<BaseTable> g_bt;
@@ -512,10 +514,12 @@ static void base_table_free(BaseTable& t) // hipFree waits for whatever enqueued
   if (t.table) (void)hipFree(t.table);
   if (t.sums) (void)hipFree(t.sums);
   if (t.built) (void)hipEventDestroy(t.built);
+  if (t.used) (void)hipEventDestroy(t.used);
   if (cur != t.dev) (void)hipSetDevice(cur);
   t.table = nullptr;
   t.sums = nullptr;
   t.built = nullptr;
+  t.used = nullptr;
 }
 // caller holds g_bt_mu.  A pinned table (a call is between its lookup and the end of its enqueueing: kernels that read the
 // table may not be in any stream yet, so a free here could run before them) is parked and freed by the last unpin.
@@ -527,18 +531,22 @@ static void base_table_drop(BaseTable& t)
     t.table = nullptr;
     t.sums = nullptr;
     t.built = nullptr;
+    t.used = nullptr;
     t.pins = 0;
     t.id = g_bt_next_id++; // the parked copy keeps the id the pin holders know
     return;
   }
   base_table_free(t);
 }
-void base_table_unpin(uint64_t id)
+void base_table_unpin(uint64_t id, hipStream_t s)
 {
   if (!id) return;
   std::lock_guard<std::mutex> lk(g_bt_mu);
   for (BaseTable& t : g_bt)
     if (t.id == id) {
+      // the call's last kernel is enqueued: whoever refreshes the table from another stream orders itself behind this point
+      if (t.table && (t.used || hipEventCreateWithFlags(&t.used, hipEventDisableTiming) == hipSuccess)) (void)hipEventRecord(t.used, s);
+      (void)hipGetLastError();
       if (t.pins > 0) t.pins--;
       return;
     }
@@ -579,6 +587,7 @@ BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bo
       ref->built = t.built;
       ref->sums = t.sums;
       ref->id = t.id;
+      ref->used = t.used;
       t.pins++;
       return BASE_TABLE_HIT;
     }
@@ -608,7 +617,7 @@ BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bo
     if (old == (size_t)-1) return BASE_TABLE_NONE;
     g_bt.erase(g_bt.begin() + old);
   }
-  g_bt.push_back({dev, (uintptr_t)bases, bytes, n, g2, form, 1u, nullptr, 0, MsmGeom(), nullptr, ++g_bt_clock, nullptr, 0, g_bt_next_id++});
+  g_bt.push_back({dev, (uintptr_t)bases, bytes, n, g2, form, 1u, nullptr, 0, MsmGeom(), nullptr, ++g_bt_clock, nullptr, 0, g_bt_next_id++, nullptr});
   return BASE_TABLE_NONE;
 }
 // the table (and the hash sum of its bases in sums[0]) are complete in the order of stream s.  On return *ref names the table,
@@ -636,7 +645,7 @@ void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* 
     ref->id = t.id;
     return;
   }
-  BaseTable orphan = {dev, (uintptr_t)bases, 0, n, g2, form, 0u, table, table_bytes, g, ev, 0, sums, 1, g_bt_next_id++};
+  BaseTable orphan = {dev, (uintptr_t)bases, 0, n, g2, form, 0u, table, table_bytes, g, ev, 0, sums, 1, g_bt_next_id++, nullptr};
   ref->id = orphan.id;
   g_bt_parked.push_back(orphan);
 }

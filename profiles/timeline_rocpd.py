@@ -2,7 +2,7 @@
 """Timeline of ONE prove out of a rocprofv3 --kernel-trace [--memory-copy-trace] run (rocpd sqlite): start/end of every dispatch
 of one prove relative to its first event, grouped by stream (queue), plus the busy-union of the GPU; with a memory-copy trace the
 host→device copies of the witness upload are listed beside the kernels (merged into runs per engine queue).
-usage: timeline_rocpd.py <dir with *_results.db> [prove index, default 4 = inside bench.py's timed loop] [min dispatch ns to list, default 30000]"""
+usage: timeline_rocpd.py <dir with *_results.db> [prove index, default 4; negative = from the end] [min dispatch ns to list, default 30000]"""
 import glob
 import sqlite3
 import sys
@@ -21,7 +21,9 @@ def main():
     # (the digit sort of the witness — of the witness HEAD, milliseconds before the spmv, when the head / tail split is on)
     starts = [i for i, r in enumerate(rows) if "qap_spmv" in r[0]]
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    k = min(k, len(starts) - 2)
+    if k < 0:
+        k = len(starts) + k   # counted from the end (bench.py proves dozens of times before its timed loop since round 5)
+    k = max(0, min(k, len(starts) - 2))
 
     def first_of(i_spmv):
         lo = i_spmv

@@ -10,7 +10,7 @@ import bench
 K.set_device("HIP", 0)
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-zkey, wtns = bench.make_inputs(K, S, 1_600_000)
+zkey, wtns = bench.make_inputs(K, S, int(os.environ.get("LOOP_CONSTRAINTS", "1600000")))
 cm = K.CacheManager()
 cm.load("s", zkey, shard_rank=rank, shard_count=count)
 sync = lambda: K.check(K.lib().icicle_device_synchronize())
