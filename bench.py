@@ -724,6 +724,7 @@ def transport_probes(cfg, ran, timeout, steps=5):
     how the three exchanges of a prove move (a pull kernel over peer mappings, hipMemcpyPeerAsync, RCCL collectives); everything else
     of the prove is identical, so the difference between two of these is the difference between their exchanges."""
     out, errs = {}, {}
+    timeout = min(timeout, float(os.environ.get("ICICLE_SNARK_PROBE_TIMEOUT", "120")))   # a probe must never cost the run its line: two minutes per transport at most
     if ran:
         out[f"prove_ms_{ran}"] = None   # filled by the caller's own timed run
     for tr in ("pull", "rccl"):
