@@ -112,6 +112,20 @@ void table_build_thread(ZKeyCache* z)
   for (int waited = 0; waited < TABLE_BUILD_GRACE_MS && !tb.go.load(std::memory_order_acquire) && !tb.cancel.load(); waited++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   const auto t0 = std::chrono::steady_clock::now();
   bool ok = hipSetDevice(z->device_id) == hipSuccess;
+  // The key's first prove (classic layout) has counted the non-zero digits of its witness: a witness of 0 / 1 wires and small values
+  // wants narrower digits than the dense default (witness_digit_target) — build the four witness tables with that width
+  // at once instead of building the dense ones and rebuilding them INSIDE a later prove (0.1–0.3 s).  The classic count (16-bit digits)
+  // is an upper bound of the table-mode one, so the width chosen here is the rule's or one bit above it; the rule keeps following the
+  // witnesses afterwards.  (witness_entries was written before `go` was released.)
+  if (ok && tb.go.load(std::memory_order_acquire) && z->witness_entries) {
+    int lg = 0;
+    while (((uint64_t)1 << lg) * 32 < z->witness_entries) lg++;
+    int c_t = lg + 1 < 13 ? 13 : lg + 1;
+    if (c_t <= tb.gw.c - 2) {
+      const MsmGeom g = msm_geometry(z->A.len(), 0, c_t);
+      if (g.tab && g.c == c_t) tb.gw = g;
+    }
+  }
   hipStream_t s = nullptr;
   if (ok) {
     // the lowest stream priority: the build fills what the proves of the key (and of other keys) leave free
@@ -176,7 +190,7 @@ int adopt_tables(ZKeyCache* z, bool wait)
     }
     z->geom_w = tb.gw;
     z->geom_h = tb.gh;
-    z->geom_w_default_c = tb.gw.c;
+    z->geom_w_default_c = tb.dense_c; // (the witness tables may have been built narrower already: see table_build_thread)
     // what the classic proves measured (entries of 16-bit digits) says nothing about the table digits: the witness-driven
     // digit width (rebuild_witness_tables) starts over from the first table-mode prove
     z->witness_entries = 0;
@@ -378,6 +392,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
       // tables of these geometries; adopt_tables swaps them in
       z->tb.gw = z->geom_w;
       z->tb.gh = z->geom_h;
+      z->tb.dense_c = z->geom_w.c;
       z->geom_w = msm_geometry(z->A.len(), 0, 0);
       z->geom_h = msm_geometry(z->H.len(), 0, 0);
       z->tb.state.store(1);

@@ -97,6 +97,7 @@ struct TableBuild {
   std::atomic<bool> go{false}; // set at the end of the key's first prove: the build starts behind it, not beside it (or after TABLE_BUILD_GRACE_MS without one)
   void* fresh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // A, B1, B2, C, H
   MsmGeom gw, gh;            // the table geometries the build works towards
+  int dense_c = 0;           // digit width of the dense witness geometry (gw may be narrower: the first prove's witness was light)
   double build_ms = 0;       // wall clock of the build (beside whatever proves ran meanwhile)
 };
 

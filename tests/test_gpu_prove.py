@@ -525,6 +525,38 @@ def test_proofs_across_the_deferred_table_build(gpu, O, S, tmp_path):
         cm.prove_files(str(wp), str(zp), str(tmp_path / "p.json"), str(tmp_path / "q.json"))
         assert json.loads((tmp_path / "q.json").read_text()) == want[(1, 1)][1]
         assert cm.tables_ready(f"{zp}_HIP", wait=True)
+    # a witness of 0 / 1 wires and small values: the first (classic) prove counts its non-zero digits and the deferred build gives the
+    # four witness tables the narrower digits such a witness wants AT ONCE (no dense tables first, no rebuild inside a later prove)
+    rng = np.random.default_rng(3)
+    wb = np.frombuffer(wtns, dtype=np.uint8).copy()
+    body = wb[len(wb) - 32 * (N + 2):].view(np.uint64).reshape(-1, 4)
+    kind = rng.random(N + 2)
+    bits = kind < 0.7
+    body[bits] = 0
+    body[bits, 0] = rng.integers(0, 2, size=int(bits.sum()), dtype=np.uint64)
+    small = (kind >= 0.7) & (kind < 0.8)
+    body[small, 1:] = 0
+    body[0] = 0
+    body[0, 0] = 1
+    light = wb.tobytes()
+    want_light = O.groth16_prove(zkey, light, 3, 8, cache=cache)
+    cm.load("light", zkey, wait_tables=False)
+    pj, qj, _ = cm.prove_mem("light", light, 3, 8)                # classic layout; releases the build
+    assert json.loads(pj) == want_light[0] and json.loads(qj) == want_light[1]
+    assert cm.tables_ready("light", wait=True)
+    t0 = __import__("time").perf_counter()
+    pj, qj, _ = cm.prove_mem("light", light, 3, 8)                # first prove on the tables: no rebuild inside it
+    first_tab_ms = (__import__("time").perf_counter() - t0) * 1e3
+    assert json.loads(pj) == want_light[0]
+    c_light = K.msm_profile(4)[1]["c"]                            # A's geometry (back = 4)
+    cm.load("dense", zkey)
+    cm.prove_mem("dense", wtns, 3, 8)
+    c_dense = K.msm_profile(4)[1]["c"]
+    assert c_light <= c_dense - 2, (c_light, c_dense)
+    assert first_tab_ms < 60, first_tab_ms                        # (a rebuild of four tables inside the prove takes > 100 ms)
+    pj, qj, _ = cm.prove_mem("light", wtns, 1, 1)                 # … and a dense witness on the narrow tables is still right
+    assert json.loads(pj) == want[(1, 1)][0]
+    cm.evict("light"); cm.evict("dense")
     # tables inside the load when deferral is switched off
     os.environ["ICICLE_SNARK_DEFER_TABLES"] = "0"
     try:
