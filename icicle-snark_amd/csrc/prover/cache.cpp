@@ -109,7 +109,7 @@ void table_build_thread(ZKeyCache* z)
   TableBuild& tb = z->tb;
   // behind the key's first proof, not beside it: a prove next to the build takes 24 instead of 19 ms at 1.6 M constraints, and
   // the first one is the one a caller without a cache waits for.  A key nobody proves with gets its tables after the grace time.
-  for (int waited = 0; waited < TABLE_BUILD_GRACE_MS && !tb.go.load(std::memory_order_acquire) && !tb.cancel.load(); waited++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  for (int waited = 0; !tb.witness_only && waited < TABLE_BUILD_GRACE_MS && !tb.go.load(std::memory_order_acquire) && !tb.cancel.load(); waited++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   const auto t0 = std::chrono::steady_clock::now();
   bool ok = hipSetDevice(z->device_id) == hipSuccess;
   // The key's first prove (classic layout) has counted the non-zero digits of its witness: a witness of 0 / 1 wires and small values
@@ -117,7 +117,7 @@ void table_build_thread(ZKeyCache* z)
   // at once instead of building the dense ones and rebuilding them INSIDE a later prove (0.1–0.3 s).  The classic count (16-bit digits)
   // is an upper bound of the table-mode one, so the width chosen here is the rule's or one bit above it; the rule keeps following the
   // witnesses afterwards.  (witness_entries was written before `go` was released.)
-  if (ok && tb.go.load(std::memory_order_acquire) && z->witness_entries) {
+  if (ok && !tb.witness_only && tb.go.load(std::memory_order_acquire) && z->witness_entries) {
     int lg = 0;
     while (((uint64_t)1 << lg) * 32 < z->witness_entries) lg++;
     int c_t = lg + 1 < 13 ? 13 : lg + 1;
@@ -140,6 +140,7 @@ void table_build_thread(ZKeyCache* z)
   // H first: the longest of the five builds' G1 arrays; B2 (the G2 array, 60 % of the G1 four together) last
   const Job jobs[5] = {{&z->A, false, &tb.gw}, {&z->B1, false, &tb.gw}, {&z->B2, true, &tb.gw}, {&z->C, false, &tb.gw}, {&z->H, false, &tb.gh}};
   for (int k : {4, 0, 1, 3, 2}) {
+    if (k == 4 && tb.witness_only) continue; // (a re-build for another witness density: row 0 of the current tables is the source)
     if (!ok || tb.cancel.load()) {
       ok = false;
       break;
@@ -182,22 +183,56 @@ int adopt_tables(ZKeyCache* z, bool wait)
     // (synchronising frees: the caller holds the manager's mutex, nothing of this key is in flight and the build has ended)
     Shard* sh5[5] = {&z->A, &z->B1, &z->B2, &z->C, &z->H};
     for (int k = 0; k < 5; k++) {
+      if (k == 4 && tb.witness_only) continue;
+      const MsmGeom& g = k == 4 ? tb.gh : tb.gw;
+      const int64_t w_old = tb.witness_only ? z->geom_w.W : 1; // (tables of another width replace tables; the first build replaces plain arrays)
       (void)hipFree(sh5[k]->d_points);
       sh5[k]->d_points = tb.fresh[k];
       tb.fresh[k] = nullptr;
-      const MsmGeom& g = k == 4 ? tb.gh : tb.gw;
-      z->device_bytes += (uint64_t)sh5[k]->len() * (g.W - 1) * (k == 2 ? 128 : 64);
+      z->device_bytes += (int64_t)sh5[k]->len() * ((int64_t)g.W - w_old) * (k == 2 ? 128 : 64);
     }
     z->geom_w = tb.gw;
-    z->geom_h = tb.gh;
-    z->geom_w_default_c = tb.dense_c; // (the witness tables may have been built narrower already: see table_build_thread)
+    if (!tb.witness_only) {
+      z->geom_h = tb.gh;
+      z->geom_w_default_c = tb.dense_c; // (the witness tables may have been built narrower already: see table_build_thread)
+    }
     // what the classic proves measured (entries of 16-bit digits) says nothing about the table digits: the witness-driven
     // digit width (rebuild_witness_tables) starts over from the first table-mode prove
     z->witness_entries = 0;
     z->proves_since_rebuild = 0;
   }
+  tb.witness_only = false;
   tb.state.store(0, std::memory_order_release);
   return 1;
+}
+
+void start_witness_rebuild(ZKeyCache* z, int c_new)
+{
+  TableBuild& tb = z->tb;
+  if (!z->geom_w.tab || c_new == z->geom_w.c || tb.state.load(std::memory_order_acquire) != 0) return;
+  if (tb.th.joinable()) tb.th.join();
+  const MsmGeom g = c_new == z->geom_w_default_c ? msm_geometry(z->A.len(), 0, 1) : msm_geometry(z->A.len(), 0, c_new);
+  if (!g.tab || (c_new != z->geom_w_default_c && g.c != c_new)) return; // the entry encoding does not fit this width: keep what there is
+  // memory: the four new tables beside the old ones + a slice's temporaries; when the device cannot hold that the key keeps its width
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  const uint64_t need = (uint64_t)g.W * ((uint64_t)z->A.len() * 64 + (uint64_t)z->B1.len() * 64 + (uint64_t)z->B2.len() * 128 + (uint64_t)z->C.len() * 64) + (1ull << 30);
+  if (need > free_b) return;
+  tb.gw = g;
+  tb.gh = z->geom_h;
+  tb.witness_only = true;
+  tb.cancel.store(false);
+  tb.go.store(true);
+  tb.state.store(1, std::memory_order_release);
+  try {
+    tb.th = std::thread(table_build_thread, z);
+  } catch (...) {
+    tb.witness_only = false;
+    tb.state.store(0, std::memory_order_release); // no thread to be had: the key keeps its width
+  }
 }
 
 int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out, bool defer_tables)

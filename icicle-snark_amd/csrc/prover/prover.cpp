@@ -363,14 +363,18 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   mark("domain");
   // deferred fixed-base tables (cache.cpp): complete → this prove is the first to use them; still building → classic layout
   (void)adopt_tables(z, false);
-  // the key follows its witnesses: a digit width at least two bits off the one the last witness called for → rebuild the four
-  // witness tables now, at most once every eight proves.  On one device nothing of this prove is enqueued yet; in a device group
-  // the front end and the exchanges of this shard already are (multi.cpp) — they do not touch the tables, and the rebuild's
-  // synchronising frees wait for them.  The rebuild is all-or-nothing (cache.cpp): afterwards tables and geom_w agree either way.
-  if (z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1) {
+  // the key follows its witnesses: a digit width at least two bits off the one the last witness called for → the four witness
+  // tables are re-built with that width, at most once every eight proves — by a worker thread BESIDE the proves of the key (round 5;
+  // rounds 3–4 re-built them here, 0.1–0.3 s inside a prove), which go on with the tables they have until the new ones are complete
+  // and adopt_tables above swaps them in (all four and geom_w together).
+  if (z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1 && z->tb.state.load(std::memory_order_acquire) == 0) {
     const int c_t = witness_digit_target(z, z->witness_entries);
     if ((c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (z->geom_w.c == z->geom_w_default_c || z->proves_since_rebuild >= 8)) {
-      if (int rc = rebuild_witness_tables(z, c_t)) return rc;
+      static const bool sync_rebuild = getenv("ICICLE_SNARK_SYNC_REBUILD") && atoi(getenv("ICICLE_SNARK_SYNC_REBUILD")) != 0;
+      if (sync_rebuild) {
+        if (int rc = rebuild_witness_tables(z, c_t)) return rc;
+      } else
+        start_witness_rebuild(z, c_t);
       z->proves_since_rebuild = 0;
     }
   }

@@ -98,6 +98,7 @@ struct TableBuild {
   void* fresh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // A, B1, B2, C, H
   MsmGeom gw, gh;            // the table geometries the build works towards
   int dense_c = 0;           // digit width of the dense witness geometry (gw may be narrower: the first prove's witness was light)
+  bool witness_only = false; // a re-build of the four witness tables with another digit width (the key follows its witnesses): H stays
   double build_ms = 0;       // wall clock of the build (beside whatever proves ran meanwhile)
 };
 
@@ -160,6 +161,9 @@ inline uint64_t witness_slice_elems(uint32_t n_vars, int count) { return ((uint6
 // digit width of the witness MSMs adapted to the witnesses seen (cache.cpp)
 int witness_digit_target(const ZKeyCache* z, uint64_t entries);
 int rebuild_witness_tables(ZKeyCache* z, int c_new);
+// the same in the background (round 5): a worker builds the four tables beside the proves of the key, which go on with the tables
+// they have, and a later prove adopts them (adopt_tables).  Returns at once; nothing happens when a build is already under way.
+void start_witness_rebuild(ZKeyCache* z, int c_new);
 
 // deferred tables: 1 = the key proves with its tables (or has none coming: classic layout for good), 0 = still building.
 // `wait`: block until the build has ended.  Swaps complete tables in; the caller holds the manager's mutex (no prove in flight).

@@ -115,6 +115,9 @@ def test_keyless_standin_cache_loop_every_proof_equals_oracle(gpu, O, S, tmp_pat
         proof, public = O.groth16_assemble(cache, w, oc, r, s)
         assert json.loads(pj) == proof and json.loads(qj) == public, i
     print("[keyless stand-in] prove ms:", " ".join(f"{t:.1f}" for t in times))
+    # the key follows its witness (narrower digits for its four witness tables) WITHOUT a prove paying for the re-build: a worker
+    # thread builds the new tables beside the proves and a later prove adopts them (round 5; 162 ms inside the second prove before)
+    assert max(times[1:]) < 60, times
     # files in / files out through the same cache entry (the reference's entry point), random r, s: valid proof
     cm.prove_files(str(wp), str(zp), str(tmp_path / "proof.json"), str(tmp_path / "public.json"))
     assert K.groth16_verify_json((tmp_path / "proof.json").read_text(), (tmp_path / "public.json").read_text(), S.vk_to_json(vk))
