@@ -201,6 +201,10 @@ int adopt_tables(ZKeyCache* z, bool wait)
     z->witness_entries = 0;
     z->proves_since_rebuild = 0;
   }
+  // the first build's tables were counted in device_bytes from the load on (cache budget); the loop above has added what was really
+  // built, an abandoned build (st == 3) has added nothing
+  z->device_bytes -= tb.pending_bytes;
+  tb.pending_bytes = 0;
   tb.witness_only = false;
   tb.state.store(0, std::memory_order_release);
   return 1;
@@ -428,6 +432,11 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
       z->tb.gw = z->geom_w;
       z->tb.gh = z->geom_h;
       z->tb.dense_c = z->geom_w.c;
+      // the tables count towards the entry's size from now on (the cache budget admits and evicts keys by device_bytes: a key must not
+      // look small while its tables are still being built)
+      z->tb.pending_bytes = (uint64_t)(z->geom_w.W - 1) * ((uint64_t)z->A.len() * 64 + (uint64_t)z->B1.len() * 64 + (uint64_t)z->B2.len() * 128 + (uint64_t)z->C.len() * 64) +
+                            (uint64_t)(z->geom_h.W - 1) * (uint64_t)z->H.len() * 64;
+      z->device_bytes += z->tb.pending_bytes;
       z->geom_w = msm_geometry(z->A.len(), 0, 0);
       z->geom_h = msm_geometry(z->H.len(), 0, 0);
       z->tb.state.store(1);

@@ -98,6 +98,7 @@ struct TableBuild {
   void* fresh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // A, B1, B2, C, H
   MsmGeom gw, gh;            // the table geometries the build works towards
   int dense_c = 0;           // digit width of the dense witness geometry (gw may be narrower: the first prove's witness was light)
+  uint64_t pending_bytes = 0; // table bytes already counted in the entry's device_bytes while the first build is under way
   bool witness_only = false; // a re-build of the four witness tables with another digit width (the key follows its witnesses): H stays
   double build_ms = 0;       // wall clock of the build (beside whatever proves ran meanwhile)
 };
