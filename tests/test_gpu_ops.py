@@ -411,3 +411,39 @@ def test_msm_tables_follow_writes_the_library_cannot_see(gpu, O, grp, n):
     raw_write(b5[11], 11 * psize)
     check(b5, 2, stream=st)
     st.destroy(); d_b.free()
+
+
+@pytest.mark.parametrize("grp", ["g1", "g2"])
+def test_table_mode_sort_with_runs_of_every_length(gpu, O, grp):
+    """the LDS-staged digit sort behind the table mode (csrc/msm_sort.hip, round 5) copies its staged entries out run by run — 16 lanes per
+    run, runs above 192 entries by the whole workgroup — in both of its passes.  Scalar vectors that make runs of every kind: all equal
+    (ONE bucket per window holds everything: tile runs of 1024, row runs and bucket runs far above 192), the values 0 … 7 only (eight
+    buckets), a few large values in a sea of ones, zeros at every second place, and dense ones beside them; 2^16 + 37 points (a ragged
+    last tile), three calls per vector (classic layout, table build, table hit) against the oracle."""
+    K = gpu
+    n = (1 << 16) + 37
+    rng = np.random.default_rng(99)
+    bases = _bases(O, grp, rng, n, distinct=64)
+    bases[11] = 0
+    d_b = K.DeviceVec.from_host(bases)
+
+    def ones():
+        a = np.zeros((n, 4), dtype=np.uint64)
+        a[:, 0] = 1
+        return a
+    same = np.tile(rand_fr(O, rng, 1), (n, 1))
+    small = np.zeros((n, 4), dtype=np.uint64)
+    small[:, 0] = rng.integers(0, 8, size=n, dtype=np.uint64)
+    few = ones()
+    few[rng.integers(0, n, size=50)] = rand_fr(O, rng, 50)
+    holes = rand_fr(O, rng, n)
+    holes[::2] = 0
+    rmax = np.tile(np.frombuffer((O.R_MOD - 1).to_bytes(32, "little"), dtype=np.uint64), (n, 1))   # every digit at its negative extreme
+    for name, sc in (("ones", ones()), ("same", same), ("small", small), ("few", few), ("holes", holes), ("r-1", rmax), ("dense", rand_fr(O, rng, n))):
+        want = O.ec_to_affine(grp, O.msm(grp, sc, bases))
+        d_s = K.DeviceVec.from_host(sc)
+        for call in range(3):
+            got = K.ec(grp, "to_affine", K.msm(grp, d_s, d_b))
+            assert np.array_equal(got, want), (name, call)
+        d_s.free()
+    d_b.free()
