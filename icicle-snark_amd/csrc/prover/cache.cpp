@@ -239,7 +239,106 @@ void start_witness_rebuild(ZKeyCache* z, int c_new)
   }
 }
 
-int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out, bool defer_tables)
+// ---- cold pipeline (prover_internal.h: ColdFeed / ColdUpload) ------------------------------------------------------------------
+namespace {
+struct ColdPlan { // what the uploader task works through; owned by the task (heap), deleted when it ends
+  ColdUpload* cu;
+  ZKeyCache* z;
+  int device_id;
+  uint32_t* d_records;
+  size_t rec_bytes;
+  const uint8_t* rec_src;
+  uint32_t n_coef;
+  UploadJob sec[5]; // A, B1, B2, C, H
+};
+void cold_upload_task(ColdPlan* pl)
+{
+  std::unique_ptr<ColdPlan> own(pl);
+  ColdUpload* cu = pl->cu;
+  ColdFeed& F = cu->feed;
+  ZKeyCache* z = pl->z;
+  const bool trace = getenv("ICICLE_SNARK_TRACE_COLD") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto bail = [&](int code, const char* fmt, const char* detail) {
+    char buf[256];
+    snprintf(buf, sizeof buf, fmt, detail);
+    F.fail_with(code, buf);
+    if (pl->d_records) (void)hipFree(pl->d_records);
+    F.finish();
+  };
+  if (hipSetDevice(pl->device_id) != hipSuccess) return bail((int)ICICLE_INVALID_DEVICE, "cold upload: %s", "hipSetDevice");
+  hipStream_t su = cu->lanes[0]; // kernels and events of the stages; a stage's data has LANDED when staged_copy returns
+  auto upload = [&](const UploadJob& j, bool from_wtns) -> bool {
+    if (!j.n) return true;
+    if (from_wtns) staged_copy_file_hint(cu->wtns_base, cu->wtns_len, cu->wtns_fd);
+    else staged_copy_file_hint(cu->zkey_base, cu->zkey_len, cu->zkey_fd);
+    const hipError_t e = staged_copy(pl->device_id, &j, 1, true, cu->lanes, 2, false, nullptr);
+    staged_copy_file_hint(nullptr, 0, -1);
+    if (e != hipSuccess) {
+      bail((int)ICICLE_COPY_FAILED, "cold upload: %s", hipGetErrorString(e));
+      return false;
+    }
+    return true;
+  };
+  auto stage_done = [&](int i) -> bool {
+    if (hipEventRecord(F.ev[i], su) != hipSuccess) {
+      bail((int)ICICLE_UNKNOWN_ERROR, "cold upload: %s", "hipEventRecord");
+      return false;
+    }
+    F.post(i);
+    if (trace) fprintf(stderr, "[cold] stage %d posted at    %8.2f ms\n", i, ms_since(t0));
+    return true;
+  };
+  // coefficients → CSR (the range check of the records is part of it: a key that fails it never reaches the front end)
+  if (!upload({pl->d_records, pl->rec_src, pl->rec_bytes}, false)) return;
+  {
+    uint32_t first_bad = 0;
+    const hipError_t e = qap_build_csr(pl->d_records, pl->n_coef, z->domain_size, z->n_vars, z->d_rowptr, z->d_cols, z->d_vals, &first_bad, su);
+    if (e != hipSuccess) return bail((int)ICICLE_UNKNOWN_ERROR, "cold upload: CSR build: %s", hipGetErrorString(e));
+    if (first_bad != 0xffffffffu) {
+      char num[32];
+      snprintf(num, sizeof num, "%u", first_bad);
+      return bail(ERR_FORMAT, "zkey: coefficient %s out of range", num);
+    }
+    (void)hipFree(pl->d_records); // (qap_build_csr has synchronised su)
+    pl->d_records = nullptr;
+  }
+  if (!stage_done(ColdFeed::COEF)) return;
+  // the witness of the prove that is waiting for all this
+  if (!upload({z->d_witness, cu->wtns_values, cu->wtns_bytes}, true)) return;
+  if (!stage_done(ColdFeed::WITNESS)) return;
+  // the point sections in the order the prove enqueues their MSMs (B2 — the longest chain — first), each converted in place from the
+  // file's Montgomery form to the bucket kernels' encoding as it lands
+  const int order[5] = {2, 0, 1, 3, 4};
+  Shard* sh5[5] = {&z->A, &z->B1, &z->B2, &z->C, &z->H};
+  for (int k : order) {
+    if (!upload(pl->sec[k], false)) return;
+    const eIcicleError e = k == 2 ? msm_g2_points_to_internal(sh5[k]->d_points, sh5[k]->len(), 1, su) : msm_g1_points_to_internal(sh5[k]->d_points, sh5[k]->len(), 1, su);
+    if (e != ICICLE_SUCCESS) return bail((int)e, "cold upload: %s", "points to internal form");
+    if (!stage_done(ColdFeed::SEC_A + k)) return;
+  }
+  if (hipStreamSynchronize(su) != hipSuccess) return bail((int)ICICLE_SYNCHRONIZATION_FAILED, "cold upload: %s", "hipStreamSynchronize");
+  if (trace) fprintf(stderr, "[cold] upload task done after %8.2f ms\n", ms_since(t0));
+  F.finish();
+}
+} // namespace
+
+void cold_upload_wait(ColdUpload* cu)
+{
+  if (!cu) return;
+  if (cu->started && cu->task.queued) WorkerPool::wait(&cu->task);
+  cu->started = false;
+  for (hipStream_t& st : cu->lanes) {
+    if (st) (void)icicle_destroy_stream(st); // (drained; back to the pool)
+    st = nullptr;
+  }
+  for (hipEvent_t& e : cu->feed.ev) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+}
+
+int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out, bool defer_tables, ColdUpload* cold)
 {
   if (count < 1 || rank < 0 || rank >= count) return fail(ERR_ARG, "bad shard %d/%d", rank, count);
   const bool trace = getenv("ICICLE_SNARK_TRACE_COLD") != nullptr;
@@ -378,54 +477,59 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     z->device_bytes += (size_t)m * 64;
   } else if (int rc = alloc_shard(z->H, s9, 64, n, hlo, hhi, z->device_bytes, jobs)) return rc;
   lap("point buffers (hipMalloc)");
-  {
-    const hipStream_t lanes[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
-    if (int rc = staged_upload(device_id, jobs, lanes, 6)) return rc;
-  }
-  if (h_strided) {
-    P_HIP(qap_gather_strided((const fe*)h_full, (fe*)z->H.d_points, 2, z->H.len(), z->H.stride, z->H.first, nullptr));
-    P_HIP(hipStreamSynchronize(nullptr));
-    P_HIP(hipFree(h_full));
-    h_full = nullptr;
-  }
-  lap("staged upload");
-  {
-    uint32_t first_bad = 0;
-    P_HIP(qap_build_csr(d_records, n_coef, n, z->n_vars, z->d_rowptr, z->d_cols, z->d_vals, &first_bad, nullptr));
-    if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
-  }
-  lap("device CSR build");
   // bases: the file's Montgomery form (R = 2^256) → the bucket kernels' internal encoding (R' = 2^261), once.  Table mode
   // (msm_plan.h; ICICLE_SNARK_TABLES=0 disables it): every base array becomes W rows 2^(c·w)·P so that all digits of a
   // scalar share one bucket set — 13 instead of 16 mixed additions per scalar at 1.6 M constraints for 13× the base memory.
-  {
-    const int tables_env = getenv("ICICLE_SNARK_TABLES") ? atoi(getenv("ICICLE_SNARK_TABLES")) : 1;
-    bool tables = tables_env != 0;
-    // Above 2^22 points the 32-bit sort entry has no room for 20-bit digits beside the point index (msm_sort.hip: tab_low_bits):
-    // the tables would fall back to c = 19 / 14 digits, and measured at 6.4 M constraints (domain 2^23) that is no faster than the
-    // classic layout with c = 16 / 16 digits — 65.4 against 64.3 ms resident — for 37.7 instead of 4.4 GB of device memory and a
-    // second of table build (tests/test_gpu_fullsize.py::test_prove_at_domain_2p23_…): such keys stay classic
-    // (ICICLE_SNARK_TABLES=2 builds the tables all the same).
-    if (tables_env < 2 && (z->A.len() > (1u << 22) || z->H.len() > (1u << 22))) tables = false;
-    z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
-    z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
-    if (tables) {
-      // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
-      // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
-      size_t free_b = 0, total_b = 0;
-      release_cached_device_memory(); // blocks parked by icicle_free count as free
-      P_HIP(hipMemGetInfo(&free_b, &total_b));
-      const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W, wb = ww;
-      const uint64_t need = ww * ((uint64_t)z->A.len() * 64 + (uint64_t)z->C.len() * 64) + wb * (uint64_t)z->B1.len() * (64 + 128) + wh * (uint64_t)z->H.len() * 64 +
-                            wb * (uint64_t)z->B2.len() * (192 + 64) + ((uint64_t)n * 128 + (uint64_t)z->n_vars * 32 + (64u << 20));
-      if (need > free_b) {
-        tables = false;
-        z->geom_w = msm_geometry(z->A.len(), 0, 0);
-        z->geom_h = msm_geometry(z->H.len(), 0, 0);
-      }
+  // (decided BEFORE the upload since round 5: the cold pipeline below only applies when no table has to be built in here)
+  const int tables_env = getenv("ICICLE_SNARK_TABLES") ? atoi(getenv("ICICLE_SNARK_TABLES")) : 1;
+  bool tables = tables_env != 0;
+  // Above 2^22 points the 32-bit sort entry has no room for 20-bit digits beside the point index (msm_sort.hip: tab_low_bits):
+  // the tables would fall back to c = 19 / 14 digits, and measured at 6.4 M constraints (domain 2^23) that is no faster than the
+  // classic layout with c = 16 / 16 digits — 65.4 against 64.3 ms resident — for 37.7 instead of 4.4 GB of device memory and a
+  // second of table build (tests/test_gpu_fullsize.py::test_prove_at_domain_2p23_…): such keys stay classic
+  // (ICICLE_SNARK_TABLES=2 builds the tables all the same).
+  if (tables_env < 2 && (z->A.len() > (1u << 22) || z->H.len() > (1u << 22))) tables = false;
+  z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
+  z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
+  if (tables) {
+    // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
+    // scratch of the G2 set); keep the classic layout when the device cannot hold them next to what is already there
+    size_t free_b = 0, total_b = 0;
+    release_cached_device_memory(); // blocks parked by icicle_free count as free
+    P_HIP(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t ww = (uint64_t)z->geom_w.W, wh = (uint64_t)z->geom_h.W, wb = ww;
+    const uint64_t need = ww * ((uint64_t)z->A.len() * 64 + (uint64_t)z->C.len() * 64) + wb * (uint64_t)z->B1.len() * (64 + 128) + wh * (uint64_t)z->H.len() * 64 +
+                          wb * (uint64_t)z->B2.len() * (192 + 64) + ((uint64_t)n * 128 + (uint64_t)z->n_vars * 32 + (64u << 20));
+    if (need > free_b) {
+      tables = false;
+      z->geom_w = msm_geometry(z->A.len(), 0, 0);
+      z->geom_h = msm_geometry(z->H.len(), 0, 0);
     }
-    const bool defer_env = !(getenv("ICICLE_SNARK_DEFER_TABLES") && atoi(getenv("ICICLE_SNARK_DEFER_TABLES")) == 0);
-    const bool defer = tables && defer_tables && defer_env && count == 1;
+  }
+  const bool defer_env = !(getenv("ICICLE_SNARK_DEFER_TABLES") && atoi(getenv("ICICLE_SNARK_DEFER_TABLES")) == 0);
+  const bool defer = tables && defer_tables && defer_env && count == 1;
+  // cold pipeline: the caller's prove starts while the sections are still on their way (nothing in here needs their contents then)
+  const bool pipeline = cold != nullptr && count == 1 && !h_strided && (defer || !tables);
+  if (!pipeline) {
+    {
+      const hipStream_t lanes[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
+      if (int rc = staged_upload(device_id, jobs, lanes, 6)) return rc;
+    }
+    if (h_strided) {
+      P_HIP(qap_gather_strided((const fe*)h_full, (fe*)z->H.d_points, 2, z->H.len(), z->H.stride, z->H.first, nullptr));
+      P_HIP(hipStreamSynchronize(nullptr));
+      P_HIP(hipFree(h_full));
+      h_full = nullptr;
+    }
+    lap("staged upload");
+    {
+      uint32_t first_bad = 0;
+      P_HIP(qap_build_csr(d_records, n_coef, n, z->n_vars, z->d_rowptr, z->d_cols, z->d_vals, &first_bad, nullptr));
+      if (first_bad != 0xffffffffu) return fail(ERR_FORMAT, "zkey: coefficient %u out of range", first_bad);
+    }
+    lap("device CSR build");
+  }
+  {
     if (defer) {
       // the key proves in the classic layout until the worker thread (started at the end of this function) has built the
       // tables of these geometries; adopt_tables swaps them in
@@ -444,6 +548,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     struct Job { Shard* sh; bool g2; const MsmGeom* g; };
     const Job jobs5[5] = {{&z->A, false, &z->geom_w}, {&z->B1, false, &z->geom_w}, {&z->B2, true, &z->geom_w}, {&z->C, false, &z->geom_w}, {&z->H, false, &z->geom_h}};
     for (const Job& j : jobs5) {
+      if (pipeline) break; // (the uploader task converts every section as it lands)
       if (j.g->tab) {
         void* table = nullptr;
         P_ICICLE(j.g2 ? msm_g2_build_table(j.sh->d_points, j.sh->len(), 1, *j.g, nullptr, &table) : msm_g1_build_table(j.sh->d_points, j.sh->len(), 1, *j.g, nullptr, &table));
@@ -488,6 +593,32 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   lap("work buffers, events");
   out = std::move(z);
+  if (pipeline) {
+    // the uploader task (a pooled worker; inline when none can be had: then everything has arrived when this returns)
+    ZKeyCache* zz = out.get();
+    for (auto& e : cold->feed.ev) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& st : cold->lanes) P_ICICLE(icicle_create_stream((icicleStreamHandle*)&st));
+    ColdPlan* pl = new ColdPlan();
+    pl->cu = cold;
+    pl->z = zz;
+    pl->device_id = device_id;
+    pl->d_records = d_records;
+    pl->rec_bytes = rec_bytes;
+    pl->rec_src = s4->p + 4;
+    pl->n_coef = n_coef;
+    const Section* psec[5] = {s5, s6, s7, s8, s9};
+    Shard* sh5[5] = {&zz->A, &zz->B1, &zz->B2, &zz->C, &zz->H};
+    for (int k = 0; k < 5; k++) {
+      const size_t esz = k == 2 ? 128 : 64;
+      pl->sec[k] = {sh5[k]->d_points, psec[k]->p + (size_t)sh5[k]->lo * esz, (size_t)sh5[k]->len() * esz};
+    }
+    free_records.p = nullptr; // the records belong to the task now (freed behind the CSR build)
+    zz->feed = &cold->feed;
+    cold->task.fn = [pl] { cold_upload_task(pl); };
+    cold->started = true;
+    WorkerPool::get().run_or_inline(&cold->task);
+    lap("cold upload task started");
+  }
   // (the entry does not move any more: the worker keeps a pointer to it and ~ZKeyCache joins the worker)
   if (out->tb.state.load() == 1) {
     try {

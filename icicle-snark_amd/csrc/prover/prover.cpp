@@ -144,7 +144,9 @@ __attribute__((visibility("default"))) void groth16_cache_manager_prewarm(Groth1
   static const bool off = getenv("ICICLE_SNARK_PREWARM") && atoi(getenv("ICICLE_SNARK_PREWARM")) == 0;
   if (off) return;
   try {
-    cm->warm = std::thread([device_id] { prewarm_device(device_id, 6); });
+    // six streams for the first key, two lanes for its cold upload: a lane created on demand costs the first cold prove of a
+    // process 80 ms (profiles/r05_cold_path.txt)
+    cm->warm = std::thread([device_id] { prewarm_device(device_id, 8); });
   } catch (...) {
   }
 }
@@ -476,10 +478,17 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       head = (uint32_t)z->head_units * head_unit;
     }
     if (head < head_unit || head >= nv || nv - head < head_unit) head = 0;
+    if (z->feed) head = 0;
     const auto tu = std::chrono::steady_clock::now();
-    pinned_src = is_pinned_host(w.values, z->device_id);
+    pinned_src = !z->feed && is_pinned_host(w.values, z->device_id);
     P_HIP(hipEventRecord(z->ev[0], gq));
-    if (head) {
+    if (z->feed) {
+      // cold pipeline (prover_internal.h: ColdFeed): the uploader task that is still sending the key's sections has the witness
+      // as its second stage — wait until that stage has been POSTED (its event recorded), then order the front end behind it
+      if (int rc = z->feed->wait(ColdFeed::WITNESS)) return fail(rc, "%s", z->feed->err.c_str());
+      P_HIP(hipStreamWaitEvent(gq, z->feed->ev[ColdFeed::WITNESS], 0));
+      mark("feed: witness");
+    } else if (head) {
       // the head's kernels go to g2; the staging lanes of the upload are three of the streams with nothing to do before the whole
       // witness is there (QAP, H sort, C's own) — no extra stream, no extra hardware queue
       const hipStream_t lanes[3] = {gq, g3, z->s_g5}; // (two to five lanes measure the same: profiles/r04_upload_lanes.txt)
@@ -622,6 +631,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // witness in this call) and only once the caller has confirmed that exchange 2 delivered (groth16_dist_exchange_done)
   const bool dist_ready = !wtns && z->dist_ready && z->H.stride > 1;
   z->dist_ready = z->dist_stage2_done = false;
+  if (z->feed) { // cold pipeline: the coefficient records have landed and the CSR has been built from them
+    if (int rc = z->feed->wait(ColdFeed::COEF)) return fail(rc, "%s", z->feed->err.c_str());
+    P_HIP(hipStreamWaitEvent(gq, z->feed->ev[ColdFeed::COEF], 0));
+  }
   if (!dist_ready) P_HIP(qap_spmv(z->d_witness, z->d_rowptr, z->d_cols, z->d_vals, n, z->d_vec, gq));
   NTTConfig nc;
   memset(&nc, 0, sizeof nc);
@@ -693,6 +706,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     P_HIP(hipStreamWaitEvent(st, z->ev_sort, 0));
     if (!early) P_HIP(hipStreamWaitEvent(st, z->ev[2], 0));
     if (head && k != 2) P_HIP(hipStreamWaitEvent(st, z->ev_head_done, 0)); // the heads were accumulated on g2
+    if (z->feed) { // cold pipeline: this MSM's bases have landed and are in the bucket kernels' encoding
+      if (int rc = z->feed->wait(ColdFeed::SEC_A + k)) return fail(rc, "%s", z->feed->err.c_str());
+      P_HIP(hipStreamWaitEvent(st, z->feed->ev[ColdFeed::SEC_A + k], 0));
+    }
     if (p != psort) (void)hipEventRecord(p->ev[0], st);
     if (int rc = accumulate(k, plan_w, wlo ? 0 : head, head != 0, st, p)) return rc;
     P_ICICLE(k == 2 ? msm_g2_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]) : msm_g1_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]));
@@ -700,19 +717,26 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     p->valid = true;
     return 0;
   };
+  // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
+  auto enqueue_h_sort = [&]() -> int {
+    P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
+    (void)hipEventRecord(prof[4]->ev[0], g3);
+    // (`crowded`: H's sort runs beside the four witness accumulations of a large circuit)
+    P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab, 0, 1, 0, /*crowded=*/!early));
+    if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
+    (void)hipEventRecord(prof[4]->ev[4], g3);
+    prof[4]->has_sort_end = true;
+    P_HIP(hipEventRecord(z->ev_sort_h, g3));
+    mark("hsort");
+    return 0;
+  };
+  // (cold pipeline: the host is about to wait for B2's section — everything that needs no section is enqueued first)
+  if (z->feed)
+    if (int rc = enqueue_h_sort()) return rc;
   if (int rc = bucket_stages(2)) return rc; // commitment_b (G2) — src/proof_helper.rs:206: the longest chain first
   mark("g2");
-
-  // ---- stream g3: digit sort of the H scalars (atomics / memory bound) overlaps the ALU-bound A, B1, C stages
-  P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
-  (void)hipEventRecord(prof[4]->ev[0], g3);
-  // (`crowded`: H's sort runs beside the four witness accumulations of a large circuit)
-  P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab, 0, 1, 0, /*crowded=*/!early));
-  if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
-  (void)hipEventRecord(prof[4]->ev[4], g3);
-  prof[4]->has_sort_end = true;
-  P_HIP(hipEventRecord(z->ev_sort_h, g3));
-  mark("hsort");
+  if (!z->feed)
+    if (int rc = enqueue_h_sort()) return rc;
 
   for (int k : {0, 1, 3})
     if (int rc = bucket_stages(k)) return rc;
@@ -729,6 +753,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   hipStream_t gh = h_chain ? st4[h_behind] : g3;
   if (h_chain) P_HIP(hipStreamWaitEvent(gh, z->ev_sort_h, 0));
   fill(prof[4], plan_h, 0);
+  if (z->feed) {
+    if (int rc = z->feed->wait(ColdFeed::SEC_H)) return fail(rc, "%s", z->feed->err.c_str());
+    P_HIP(hipStreamWaitEvent(gh, z->feed->ev[ColdFeed::SEC_H], 0));
+  }
   P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
   (void)hipEventRecord(prof[4]->ev[3], gh);
   prof[4]->valid = true;
@@ -1092,6 +1120,100 @@ __attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheMa
   return rc;
 }
 
+} // extern "C"
+
+// ---- cold pipeline (prover_internal.h: ColdFeed): groth16_prove on a key that is not cached, one device ---------------------------
+// The cache entry is built with its sections still on their way (build_cache with a ColdUpload: an uploader task sends coefficients,
+// witness and point sections in the order the prove needs them), inserted, and the prove is enqueued behind the stages of the feed:
+// upload and first proof overlap.  Returns 1 when the pipeline does not apply (the caller then loads and proves as before: a witness
+// that does not fit the key is diagnosed there), 0 on success with the JSON texts filled, an error code otherwise (the key is evicted
+// again when its upload failed).
+static int cold_prove(Groth16CacheManager* cm, const std::string& key, const MappedFile& zf, const MappedFile& wf, int device_id, std::vector<char>& pj, std::vector<char>& qj)
+{
+  const bool off = getenv("ICICLE_SNARK_COLD_PIPELINE") && atoi(getenv("ICICLE_SNARK_COLD_PIPELINE")) == 0; // read per call: tests toggle it
+  if (off) return 1;
+  // the witness must fit the key BEFORE anything of it is sent: n_vars of the header (src/zkey.rs:47-85) against the .wtns header
+  Wtns w;
+  if (parse_wtns(wf.data, wf.len, w)) return 1;
+  uint32_t n_vars = 0, dom_n = 0, n_public = 0;
+  {
+    std::vector<Section> secs;
+    const Section* s2 = nullptr;
+    if (read_sections(zf.data, zf.len, "zkey", 2, secs) != 0 || unique_section(secs, 2, &s2) != 0 || s2->size < 84) return 1;
+    memcpy(&n_vars, s2->p + 72, 4);
+    memcpy(&n_public, s2->p + 76, 4);
+    memcpy(&dom_n, s2->p + 80, 4);
+    if (w.n_witness != n_vars || dom_n == 0 || (dom_n & (dom_n - 1)) || dom_n > (1u << 27) || memcmp(w.q.l, s2->p + 40, 32) != 0) return 1;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::unique_lock<std::mutex> lk(cm->mu);
+  if (find(cm, key.c_str()) || find_group(cm, key.c_str())) return 1; // (somebody else loaded it meanwhile)
+  if (cm->warm.joinable()) cm->warm.join();
+  evict_for_budget(cm, device_id, (uint64_t)zf.len * 11);
+  std::thread dom_th; // the NTT domain of the key, set up while the sections cross PCIe (as in groth16_cache_load)
+  try {
+    dom_th = std::thread([cm, device_id, dom_n] {
+      if (set_active_device(device_id) == 0) (void)ensure_domain_for(cm, device_id, dom_n);
+    });
+  } catch (...) {
+  }
+  ColdUpload cu;
+  cu.wtns_values = w.values;
+  cu.wtns_bytes = (size_t)w.n_witness * 32;
+  cu.zkey_base = zf.data; cu.zkey_len = zf.len; cu.zkey_fd = zf.fd;
+  cu.wtns_base = wf.data; cu.wtns_len = wf.len; cu.wtns_fd = wf.fd;
+  std::unique_ptr<ZKeyCache> zu;
+  const int brc = build_cache(zf.data, zf.len, device_id, 0, 1, zu, /*defer_tables=*/true, &cu);
+  if (brc) {
+    cold_upload_wait(&cu);
+    if (dom_th.joinable()) dom_th.join();
+    return brc;
+  }
+  std::shared_ptr<ZKeyCache> zp(zu.release());
+  {
+    std::lock_guard<std::mutex> lm(cm->map_mu);
+    zp->last_use = ++cm->clock;
+    cm->cache[key] = zp;
+  }
+  ZKeyCache* z = zp.get();
+  const bool piped = z->feed != nullptr;
+  // from here on as groth16_prove_resident, under the manager's mutex throughout
+  uint8_t pts[GROTH16_COMMITMENTS_BYTES];
+  Blinding bl;
+  EarlyTerms et;
+  et.bl = &bl;
+  int bl_rc = 0;
+  std::string bl_err;
+  HostTask bt;
+  bt.fn = [&] {
+    bl_rc = compute_blinding(z, nullptr, nullptr, &bl);
+    if (bl_rc) bl_err = last_error_text();
+    et.bl_ready.store(true, std::memory_order_release);
+  };
+  WorkerPool::get().run_or_inline(&bt);
+  if (dom_th.joinable()) dom_th.join(); // (shard_commitments checks the domain first: it is there, or it is set up now)
+  int rc = shard_commitments(cm, z, wf.data, wf.len, pts, nullptr, &et);
+  if (bt.queued) WorkerPool::wait(&bt);
+  // the uploader has to have ended before the mappings go away — and before anybody else proves with this entry
+  cold_upload_wait(&cu);
+  z->feed = nullptr;
+  const int up_rc = cu.feed.rc;
+  const std::string up_err = cu.feed.err;
+  lk.unlock();
+  if (up_rc) {
+    groth16_cache_evict(cm, key.c_str()); // its sections never arrived completely
+    return fail(up_rc, "%s", up_err.c_str());
+  }
+  if (rc) return rc;
+  if (bl_rc) return fail(bl_rc, "%s", bl_err.empty() ? "no entropy source for the blinding scalars" : bl_err.c_str());
+  qj.resize(64 + (size_t)n_public * 84);
+  rc = assemble_impl(z, wf.data, wf.len, pts, bl, pj.data(), pj.size(), qj.data(), qj.size(), &et);
+  if (getenv("ICICLE_SNARK_TRACE_HOST")) fprintf(stderr, "[host] cold prove (%s) %8.1f us\n", piped ? "pipelined" : "not pipelined", ms_since(t0) * 1e3);
+  return rc;
+}
+
+extern "C" {
+
 // groth16_prove — src/lib.rs:33-61.  `device`: the reference's device type string ("CUDA" there, id 0: src/lib.rs:25-31);
 // here "HIP" (alias "CUDA"), optionally with the devices to prove on: "HIP:1", "HIP:0-7", "HIP:0,2,4,6" — more than one
 // device = the MSMs sharded by point range over a device group in this process.
@@ -1105,6 +1227,33 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
   P_ICICLE(icicle_load_backend_from_env_or_default());
   if (int rc = set_active_device(devs[0])) return rc;
   const std::string key = std::string(zkey_path) + "_" + device; // src/lib.rs:44
+  static const bool trace_host0 = getenv("ICICLE_SNARK_TRACE_HOST") != nullptr;
+  static const bool quiet0 = getenv("ICICLE_SNARK_QUIET") && atoi(getenv("ICICLE_SNARK_QUIET")) != 0;
+  if (!groth16_cache_contains(cm, key.c_str()) && devs.size() == 1) {
+    // no cache entry: the key's sections and the witness cross PCIe while the first proof is being computed (cold_prove)
+    MappedFile zf, wf;
+    if (int rc = zf.open_ro(zkey_path)) return rc;
+    if (int rc = wf.open_ro(witness_path)) return rc;
+    std::vector<char> pj(4096), qj(256);
+    const int crc = cold_prove(cm, key, zf, wf, devs[0], pj, qj);
+    if (crc == 0) {
+      for (int k = 0; k < 2; k++) {
+        const char* path = k ? public_path : proof_path;
+        FILE* f = fopen(path, "wb");
+        if (!f) return fail(ERR_IO, "cannot write %s", path);
+        fputs(k ? qj.data() : pj.data(), f);
+        fclose(f);
+      }
+      if (trace_host0) fprintf(stderr, "[host] prove: files written (cold)   %8.1f us\n", ms_since(t0) * 1e3);
+      if (!quiet0) {
+        printf("proof took: %.3fms\n", ms_since(t0)); // src/lib.rs:58
+        fflush(stdout);
+      }
+      return 0;
+    }
+    if (crc != 1) return crc;
+    // (1: the pipeline does not apply — load and prove one after the other, below)
+  }
   if (!groth16_cache_contains(cm, key.c_str())) {
     if (devs.size() == 1) {
       if (int rc = groth16_cache_load_file(cm, key.c_str(), zkey_path, devs[0], 0, 1)) return rc;

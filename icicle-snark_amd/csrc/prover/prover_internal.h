@@ -24,6 +24,7 @@
 #include "../ec.h"
 #include "../msm_plan.h"
 #include "../ntt_fuse.h"
+#include "../workers.h"
 #include "qap.h"
 
 namespace isnark {
@@ -103,6 +104,52 @@ struct TableBuild {
   double build_ms = 0;       // wall clock of the build (beside whatever proves ran meanwhile)
 };
 
+// Cold pipeline (round 5): inside a groth16_prove that finds no cache entry the key's sections and the witness cross PCIe WHILE the
+// prove's kernels are being enqueued and run — upload (16–20 ms at 1.6 M constraints) and first proof (≈ 22 ms of GPU work) overlap
+// instead of following each other.  An uploader task (a pooled worker, cache.cpp: cold_upload_task) sends, in this order, the
+// coefficient records (→ CSR built on the device), the witness, and the point sections B2, A, B1, C, H (each converted to the bucket
+// kernels' encoding as it lands), records an event behind each stage and posts it; the prove's thread waits (host) until a stage
+// has been POSTED — an event that has not been recorded yet would not make a stream wait — and then makes the stream that needs
+// the stage wait for its event.
+struct ColdFeed {
+  enum { COEF = 0, WITNESS = 1, SEC_A = 2, SEC_B1 = 3, SEC_B2 = 4, SEC_C = 5, SEC_H = 6, N = 7 };
+  std::mutex m;
+  std::condition_variable cv;
+  bool posted[N] = {false, false, false, false, false, false, false};
+  hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int rc = 0;       // first error of the uploader (then nothing more is posted)
+  std::string err;
+  bool finished = false;
+  void post(int i)
+  {
+    std::lock_guard<std::mutex> lk(m);
+    posted[i] = true;
+    cv.notify_all();
+  }
+  void fail_with(int code, const char* text)
+  {
+    std::lock_guard<std::mutex> lk(m);
+    if (!rc) {
+      rc = code;
+      err = text ? text : "";
+    }
+    cv.notify_all();
+  }
+  void finish()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    finished = true;
+    cv.notify_all();
+  }
+  // 0 once stage i has been posted; the uploader's error code when it failed first
+  int wait(int i)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return posted[i] || rc != 0 || finished; });
+    return posted[i] ? 0 : (rc ? rc : (int)ICICLE_UNKNOWN_ERROR);
+  }
+};
+
 struct ZKeyCache {
   // header — src/zkey.rs:6-21
   uint32_t n8q = 0, n8r = 0, n_vars = 0, n_public = 0, domain_size = 0, n_coef = 0;
@@ -152,6 +199,7 @@ struct ZKeyCache {
   MsmProfile prof[6] = {};               // A, B1, B2, C, H of the most recent prove + [5] the digit sort of the witness HEAD (ev[0] → ev[4]; L = 0 without one): this entry's own slots (the shards of a group may share a device)
   uint64_t last_use = 0;                 // CacheManager LRU clock
   TableBuild tb;                         // deferred fixed-base tables (single-device keys)
+  ColdFeed* feed = nullptr;              // set for the ONE prove that runs while the key's sections are still arriving (cold pipeline)
 
   ~ZKeyCache();
 };
@@ -172,7 +220,24 @@ int adopt_tables(ZKeyCache* z, bool wait);
 
 // CacheManager::compute — src/cache.rs:117-241.  `defer_tables`: return once the key can prove in the classic layout and build
 // the fixed-base tables on a worker thread (single-device keys; ICICLE_SNARK_DEFER_TABLES=0 builds them before returning)
-int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out, bool defer_tables = false);
+// `cold` (single-device keys with deferred or no tables): return as soon as the buffers exist and an uploader task has been started —
+// the sections, the CSR and the witness of `cold->wtns` arrive behind the stages of cold->feed; the caller waits for cold->task
+// before it lets go of the zkey / witness memory.
+struct ColdUpload {
+  ColdFeed feed;
+  HostTask task;                      // the uploader (a pooled worker; run inline when none can be had)
+  // witness: standard-form values of the .wtns image the prove will run on
+  const uint8_t* wtns_values = nullptr;
+  size_t wtns_bytes = 0;
+  // the two images when they are mapped files (staging workers pread() instead of copying out of the mapping); fd < 0: plain memory
+  const void *zkey_base = nullptr, *wtns_base = nullptr;
+  size_t zkey_len = 0, wtns_len = 0;
+  int zkey_fd = -1, wtns_fd = -1;
+  hipStream_t lanes[2] = {nullptr, nullptr};
+  bool started = false;
+};
+void cold_upload_wait(ColdUpload* cu); // blocks until the uploader task has ended (no-op when it never started); returns its lanes to the pool
+int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int count, std::unique_ptr<ZKeyCache>& out, bool defer_tables = false, ColdUpload* cold = nullptr);
 typedef CopyJob UploadJob;
 int staged_upload(int device_id, const std::vector<UploadJob>& jobs, const hipStream_t* lanes_in = nullptr, int n_lanes = 0, StagedProgress* progress = nullptr);
 

@@ -990,7 +990,7 @@ ISNARK_API eIcicleError icicle_copy_to_device_async(void* dst, const void* src, 
 // Streams are pooled: hipStreamCreate costs ≈4 ms on this stack and the reference's host creates and destroys three to
 // five streams in every prove (src/proof_helper.rs:32,186-187, src/conversions.rs:14).  A destroyed stream is drained and
 // parked (≤ STREAM_POOL_MAX per device, with the workspace blocks cached for it); the next create takes it back.
-constexpr size_t STREAM_POOL_MAX = 8;
+constexpr size_t STREAM_POOL_MAX = 10; // a key's six + the two upload lanes of a cold pipeline (prover/cache.cpp) + slack
 ISNARK_API eIcicleError icicle_create_stream(icicleStreamHandle* stream)
 {
   if (!stream) return ICICLE_INVALID_POINTER;

@@ -568,3 +568,99 @@ def test_proofs_across_the_deferred_table_build(gpu, O, S, tmp_path):
         del os.environ["ICICLE_SNARK_DEFER_TABLES"]
     cm.close()
     K.release_domain()
+
+
+def test_cold_pipeline_first_proof_while_the_key_uploads(gpu, O, S, tmp_path):
+    """groth16_prove on a key that is not cached (one device): the cache entry is built with its sections still crossing PCIe and the
+    first proof is enqueued behind the stages of that upload (csrc/prover/prover.cpp: cold_prove; prover_internal.h: ColdFeed).
+    The proof is valid, public.json is the oracle's, the entry the pipeline left behind proves bit-identically to the oracle at
+    fixed (r, s) in both layouts, ICICLE_SNARK_COLD_PIPELINE=0 (load, then prove) gives the same, a witness that does not fit
+    and a coefficient record outside the domain are diagnosed as before, and a key whose upload failed is not left in the cache."""
+    K = gpu
+    B = importlib.import_module("bench")
+    N = 100_000
+    n = 1 << 17
+    K.release_domain()
+    K.initialize_domain(K.get_root_of_unity(n))
+    zkey, vk = S.setup_squaring_chain(N, B.GpuVec(K), _fbm(K), points_to_mont=B._to_mont(K))
+    K.release_domain()
+    wtns = S.write_wtns(S.squaring_chain_witness(N))
+    vkj = S.vk_to_json(vk)
+    cache = O.build_cache(O.parse_zkey(zkey))
+    want = O.groth16_prove(zkey, wtns, 5, 6, cache=cache)
+    wp = tmp_path / "w.wtns"
+    wp.write_bytes(wtns)
+    pp, qp = tmp_path / "proof.json", tmp_path / "public.json"
+    cm = K.CacheManager()
+    for rep, env in enumerate(({}, {"ICICLE_SNARK_COLD_PIPELINE": "0"}, {"ICICLE_SNARK_TABLES": "0"})):
+        zp = tmp_path / f"c{rep}.zkey"
+        zp.write_bytes(zkey)
+        key = f"{zp}_HIP"
+        os.environ.update(env)
+        try:
+            assert not cm.contains(key)
+            cm.prove_files(str(wp), str(zp), str(pp), str(qp))            # nothing cached: upload and first proof overlap
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert cm.contains(key)
+        assert json.loads(qp.read_text()) == want[1]
+        assert K.groth16_verify_json(pp.read_text(), qp.read_text(), vkj), rep
+        pj, qj, _ = cm.prove_mem(key, wtns, 5, 6)                         # classic layout, on what the pipeline uploaded
+        assert json.loads(pj) == want[0] and json.loads(qj) == want[1], rep
+        if "ICICLE_SNARK_TABLES" not in env:
+            assert cm.tables_ready(key, wait=True)
+            pj, qj, _ = cm.prove_mem(key, wtns, 5, 6)                     # … and on the tables built from it
+            assert json.loads(pj) == want[0], rep
+        cm.prove_files(str(wp), str(zp), str(pp), str(qp))                # cached now
+        assert K.groth16_verify_json(pp.read_text(), qp.read_text(), vkj), rep
+        cm.evict(key)
+    # a witness that does not fit the key: refused with the reference's message, before or after the key is loaded
+    zp = tmp_path / "short.zkey"
+    zp.write_bytes(zkey)
+    short = tmp_path / "short.wtns"
+    short.write_bytes(S.write_wtns(S.squaring_chain_witness(N)[:-1]))
+    for rep in range(2):
+        with pytest.raises(K.ProverError, match="witness"):
+            cm.prove_files(str(short), str(zp), str(pp), str(qp))
+    cm.prove_files(str(wp), str(zp), str(pp), str(qp))
+    assert K.groth16_verify_json(pp.read_text(), qp.read_text(), vkj)
+    cm.evict(f"{zp}_HIP")
+    # a coefficient record that points outside the domain is found by the CSR build INSIDE the upload task: the prove fails with
+    # that message and the half-uploaded key does not stay in the cache
+    (off, _), = O.read_sections(zkey, b"zkey")[4]
+    bad = bytearray(zkey)
+    bad[off + 4 + 3 * 44 + 4: off + 4 + 3 * 44 + 8] = (1 << 20).to_bytes(4, "little")
+    bp = tmp_path / "bad.zkey"
+    bp.write_bytes(bytes(bad))
+    for rep in range(2):
+        with pytest.raises(K.ProverError, match="coefficient 3 out of range"):
+            cm.prove_files(str(wp), str(bp), str(pp), str(qp))
+        assert not cm.contains(f"{bp}_HIP")
+    # a key cut short inside its last section, and one that is not a key at all
+    cut = tmp_path / "cut.zkey"
+    cut.write_bytes(zkey[:len(zkey) - 4096])
+    junk = tmp_path / "junk.zkey"
+    junk.write_bytes(b"zkey" + bytes(4096))
+    for p in (cut, junk):
+        with pytest.raises(K.ProverError):
+            cm.prove_files(str(wp), str(p), str(pp), str(qp))
+        assert not cm.contains(f"{p}_HIP")
+    # the golden key (eight wires) through the same entry point
+    g = load_golden("groth16.json")
+    gz, gw = tmp_path / "g.zkey", tmp_path / "g.wtns"
+    gz.write_bytes(base64.b64decode(g["zkey"]))
+    gw.write_bytes(base64.b64decode(g["wtns"]))
+    cm.prove_files(str(gw), str(gz), str(pp), str(qp))
+    assert json.loads(qp.read_text()) == g["cases"][0]["public"]
+    v = g["vk"]
+    gvk = dict(vk_alpha_1=unhex(v["vk_alpha_1"], 2, 4), vk_beta_2=unhex(v["vk_beta_2"], 4, 4), vk_gamma_2=unhex(v["vk_gamma_2"], 4, 4),
+               vk_delta_2=unhex(v["vk_delta_2"], 4, 4), IC=[unhex(p, 2, 4) for p in v["IC"]], n_public=len(v["IC"]) - 1)
+    assert K.groth16_verify_json(pp.read_text(), qp.read_text(), S.vk_to_json(gvk))
+    # and the good key still proves after all of that
+    zp = tmp_path / "again.zkey"
+    zp.write_bytes(zkey)
+    cm.prove_files(str(wp), str(zp), str(pp), str(qp))
+    assert K.groth16_verify_json(pp.read_text(), qp.read_text(), vkj)
+    cm.close()
+    K.release_domain()
