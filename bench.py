@@ -862,8 +862,9 @@ def main():
     cold = {}
     if world == 1:
         # ---- cold path (the reference's "without cache" figure): zkey FILE → proof.json with NOTHING cached —
-        # container parse, 0.8 GB of sections over PCIe, first proof in the classic bucket layout; the key's fixed-base tables are
-        # built behind that proof by a worker thread and adopted by a later prove (csrc/prover/cache.cpp: TableBuild).
+        # container parse, 0.8 GB of sections over PCIe WHILE the first proof (classic bucket layout) is computed behind the stages of
+        # that upload (csrc/prover/prover.cpp: cold_prove; ICICLE_SNARK_COLD_PIPELINE=0 loads first, proves then); the key's fixed-base
+        # tables are built behind that proof by a worker thread and adopted by a later prove (csrc/prover/cache.cpp: TableBuild).
         # (a) first key of this process (the manager was created — and prewarmed streams / staging buffers — before the inputs
         # were synthesised, like a worker process that waits for its first command), (b) proves beside the table build until the
         # tables are adopted, (c) the same key evicted and proved from the file again (process warm)
@@ -894,8 +895,8 @@ def main():
         cold_ms = (time.perf_counter() - t0) * 1e3
         cm.tables_ready(key, wait=True)
         cold["cold_tables_build_ms"] = (time.perf_counter() - t0) * 1e3 - cold_ms
-        cold["note"] = ("cold_prove_ms_files: groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json) with nothing cached (zkey in the page cache), first key of the "
-                        "process / again after an evict; cold_cache_build_ms: groth16_cache_load until the key can prove (classic layout); cold_tables_build_ms: "
+        cold["note"] = ("cold_prove_ms_files: groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json) with nothing cached (zkey in the page cache; upload and first "
+                        "proof overlap), first key of the process / again after an evict; cold_cache_build_ms: groth16_cache_load until the key can prove (classic layout); cold_tables_build_ms: "
                         "the deferred fixed-base tables built alone; prove_ms_beside_table_build: median file-to-file prove while the worker builds them")
         log("cold path:", json.dumps(cold))
     else:

@@ -272,6 +272,8 @@ void cold_upload_task(ColdPlan* pl)
     if (!j.n) return true;
     if (from_wtns) staged_copy_file_hint(cu->wtns_base, cu->wtns_len, cu->wtns_fd);
     else staged_copy_file_hint(cu->zkey_base, cu->zkey_len, cu->zkey_fd);
+    // two workers, one per lane: more of them (4, 6, 8 over the same two streams) were measured and are SLOWER beside a running
+    // prove — 31 → 34–53 ms process-warm, 55 → 69–80 ms for the first key of a process (profiles/r05_cold_path.txt)
     const hipError_t e = staged_copy(pl->device_id, &j, 1, true, cu->lanes, 2, false, nullptr);
     staged_copy_file_hint(nullptr, 0, -1);
     if (e != hipSuccess) {
