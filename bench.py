@@ -980,6 +980,11 @@ def main():
     # workload: the timed steps then run on a process that has proved a dozen times, not twice)
     host_ms = resident_ms = None
     if world == 1:
+        # a key whose witness carries few non-zero digits (the stand-ins) gets narrower digits for its four witness tables after its
+        # first prove on the tables — built by a worker beside later proves: warm means that build is over
+        cm.prove_mem(key, wtns)
+        cm.tables_ready(key, wait=True)
+
         def med(f, k=5):
             xs = []
             for _ in range(k):

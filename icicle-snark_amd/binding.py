@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libicicle_snark_hip.so")
 # The prover overlaps six streams; the HIP runtime's default of four hardware queues makes two of them serialise
 # (csrc/runtime.cpp does the same when the library is loaded; set here too so that it also precedes any other DSO
 # of this process that initialises the HIP runtime first, e.g. RCCL).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 SUCCESS = 0
 ERRORS = ["SUCCESS", "INVALID_DEVICE", "OUT_OF_MEMORY", "INVALID_POINTER", "ALLOCATION_FAILED", "DEALLOCATION_FAILED",

@@ -368,18 +368,22 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // the key follows its witnesses: a digit width at least two bits off the one the last witness called for → the four witness
   // tables are re-built with that width, at most once every eight proves — by a worker thread BESIDE the proves of the key (round 5;
   // rounds 3–4 re-built them here, 0.1–0.3 s inside a prove), which go on with the tables they have until the new ones are complete
-  // and adopt_tables above swaps them in (all four and geom_w together).
-  if (z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1 && z->tb.state.load(std::memory_order_acquire) == 0) {
+  // and adopt_tables above swaps them in (all four and geom_w together).  The worker is started at the END of the prove that counted
+  // the digits (follow_witness below); ICICLE_SNARK_SYNC_REBUILD=1 re-builds here, inside the next prove, as rounds 3–4 did.
+  auto follow_witness = [&](bool sync) -> int {
+    if (!(z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1 && z->tb.state.load(std::memory_order_acquire) == 0)) return 0;
     const int c_t = witness_digit_target(z, z->witness_entries);
-    if ((c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (z->geom_w.c == z->geom_w_default_c || z->proves_since_rebuild >= 8)) {
-      static const bool sync_rebuild = getenv("ICICLE_SNARK_SYNC_REBUILD") && atoi(getenv("ICICLE_SNARK_SYNC_REBUILD")) != 0;
-      if (sync_rebuild) {
-        if (int rc = rebuild_witness_tables(z, c_t)) return rc;
-      } else
-        start_witness_rebuild(z, c_t);
-      z->proves_since_rebuild = 0;
-    }
-  }
+    if (!((c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (z->geom_w.c == z->geom_w_default_c || z->proves_since_rebuild >= 8))) return 0;
+    if (sync) {
+      if (int rc = rebuild_witness_tables(z, c_t)) return rc;
+    } else
+      start_witness_rebuild(z, c_t);
+    z->proves_since_rebuild = 0;
+    return 0;
+  };
+  const bool sync_rebuild = getenv("ICICLE_SNARK_SYNC_REBUILD") && atoi(getenv("ICICLE_SNARK_SYNC_REBUILD")) != 0;
+  if (sync_rebuild)
+    if (int rc = follow_witness(true)) return rc;
   const uint32_t n = z->domain_size, nv = z->n_vars, npub = z->n_public;
   hipStream_t g1 = z->s_g1, g2 = z->s_g2, g3 = z->s_g3, gq = z->s_qap;
   double h2d_host_ms = 0;
@@ -830,6 +834,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   z->witness_entries = (uint64_t)z->h_stats[0] + z->h_stats[1] + z->h_stats[2] + z->h_stats[3];
   z->proves_since_rebuild++;
   z->tb.go.store(true, std::memory_order_release); // deferred tables: the key's first proof is out, the build may start
+  if (!sync_rebuild) (void)follow_witness(false);  // (table mode: the digits this prove counted may call for another width)
   msm_sort_release(&plan_w);
   msm_sort_release(&plan_head);
   msm_sort_release(&plan_h);

@@ -25,8 +25,11 @@
 
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share
 // a queue serialise.  The prover overlaps five streams; with four queues two of them collide and a
-// benchmark/1600k prove measured 28.5 ms instead of 25.5 ms.  Ask for eight unless the user has set the knob; this
-// runs when the library is loaded, before its first HIP call initialises the runtime.
+// benchmark/1600k prove measured 28.5 ms instead of 25.5 ms.  Ask for twelve unless the user has set the knob — a key's six
+// streams, the two lanes of a cold upload (kept in the stream pool afterwards), the staging engine's lane and a table build's
+// stream are ten; with eight queues the two pooled lanes made two of a key's streams share one (stand-in of 1.0 M constraints:
+// 6.3 instead of 5.7 ms per prove; 1600k: no difference between 8, 12 and 16).  This runs when the library is loaded, before its
+// first HIP call initialises the runtime.
 // ICICLE_SNARK_BACKTRACE=1: print the native stack of a crashing thread (the HIP runtime's callback threads carry no
 // Python frames) before the default action takes over
 static void isnark_segv(int sig)
@@ -39,7 +42,7 @@ static void isnark_segv(int sig)
 }
 __attribute__((constructor)) static void isnark_runtime_env()
 {
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  setenv("GPU_MAX_HW_QUEUES", "12", 0);
   if (getenv("ICICLE_SNARK_BACKTRACE")) {
     signal(SIGSEGV, isnark_segv);
     signal(SIGBUS, isnark_segv);
