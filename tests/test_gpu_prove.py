@@ -664,3 +664,50 @@ def test_cold_pipeline_first_proof_while_the_key_uploads(gpu, O, S, tmp_path):
     assert K.groth16_verify_json(pp.read_text(), qp.read_text(), vkj)
     cm.close()
     K.release_domain()
+
+
+def test_two_threads_prove_uncached_keys_through_one_manager(gpu, S, tmp_path):
+    """Two host threads call groth16_prove for DIFFERENT keys that are not cached, through one CacheManager, again and again
+    (evicting in between): cold pipelines, deferred table builds and adoptions of two keys interleave — every proof verifies and
+    every public.json is its key's."""
+    import threading
+    K = gpu
+    B = importlib.import_module("bench")
+    keys = []
+    for N in (40_000, 90_000):
+        n = 1
+        while n < N + 2:
+            n <<= 1
+        K.release_domain()
+        K.initialize_domain(K.get_root_of_unity(n))
+        zkey, vk = S.setup_squaring_chain(N, B.GpuVec(K), _fbm(K), points_to_mont=B._to_mont(K))
+        K.release_domain()
+        zp, wp = tmp_path / f"k{N}.zkey", tmp_path / f"k{N}.wtns"
+        zp.write_bytes(zkey)
+        wp.write_bytes(S.write_wtns(S.squaring_chain_witness(N)))
+        keys.append((N, str(zp), str(wp), S.vk_to_json(vk), [str(pow(3, 1 << N, S.R_MOD))]))
+    cm = K.CacheManager()
+    errors = []
+
+    def run(k):
+        N, zp, wp, vkj, public = keys[k]
+        pp, qp = str(tmp_path / f"p{k}.json"), str(tmp_path / f"q{k}.json")
+        try:
+            for it in range(6):
+                cm.prove_files(wp, zp, pp, qp)
+                pj, qj = open(pp).read(), open(qp).read()
+                if json.loads(qj) != public or not K.groth16_verify_json(pj, qj, vkj):
+                    errors.append((k, it, "bad proof"))
+                if it % 3 == 1:
+                    cm.evict(f"{zp}_HIP")           # (possibly in the middle of its table build)
+        except Exception as e:                      # noqa: BLE001 — collected, the main thread asserts
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    cm.close()
+    K.release_domain()
