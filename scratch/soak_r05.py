@@ -66,6 +66,7 @@ for k in ("a", "b"):
 stop[0] = True; th.join()
 K.check(K.lib().icicle_device_synchronize(), "sync")
 m1, r1 = free_mb(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e3
+cur = [int(l.split()[1]) / 1024 for l in open("/proc/self/status") if l.startswith("VmRSS")][0]
 print(f"{cycles} load / prove / evict cycles at {N} constraints, {proves} proves in {time.time() - t0:.1f} s: {bad} differing proofs; {stats}; "
-      f"free device memory {m0:.0f} -> {m1:.0f} MB; host max RSS {r0:.0f} -> {r1:.0f} MB")
+      f"free device memory {m0:.0f} -> {m1:.0f} MB; host max RSS {r0:.0f} -> {r1:.0f} MB (resident at the end: {cur:.0f} MB)")
 cm.close()
