@@ -40,6 +40,16 @@ bool is_tracked_device_ptr(const void* p);
 // create on `dev`, ahead of the first cache load, what that load would pay for: the pinned staging pool and n_streams pooled
 // streams with their DMA queues set up (runtime.cpp); the device the calling thread would use, or −1 when none is chosen yet
 void prewarm_device(int dev, int n_streams);
+// code objects of the prove path loaded onto `dev` ahead of their first use (one empty launch per translation unit)
+void prewarm_modules(int dev);
+void module_warm_csr(hipStream_t s);
+void module_warm_qap(hipStream_t s);
+void module_warm_sort(hipStream_t s);
+void module_warm_g1(hipStream_t s);
+void module_warm_g2(hipStream_t s);
+void module_warm_g2acc(hipStream_t s);
+void module_warm_ntt(hipStream_t s);
+void module_warm_vec(hipStream_t s);
 int default_device_or_none();
 // hand the blocks cached by icicle_free back to the driver (call before giving up on an allocation)
 void release_cached_device_memory();

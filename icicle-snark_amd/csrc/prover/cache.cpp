@@ -293,6 +293,7 @@ void cold_upload_task(ColdPlan* pl)
   };
   // coefficients → CSR (the range check of the records is part of it: a key that fails it never reaches the front end)
   if (!upload({pl->d_records, pl->rec_src, pl->rec_bytes}, false)) return;
+  if (trace) fprintf(stderr, "[cold] records uploaded at      %8.2f ms\n", ms_since(t0));
   {
     uint32_t first_bad = 0;
     const hipError_t e = qap_build_csr(pl->d_records, pl->n_coef, z->domain_size, z->n_vars, z->d_rowptr, z->d_cols, z->d_vals, &first_bad, su);
@@ -302,8 +303,8 @@ void cold_upload_task(ColdPlan* pl)
       snprintf(num, sizeof num, "%u", first_bad);
       return bail(ERR_FORMAT, "zkey: coefficient %s out of range", num);
     }
-    (void)hipFree(pl->d_records); // (qap_build_csr has synchronised su)
-    pl->d_records = nullptr;
+    // (the records are freed at the END of the task: a hipFree of 141 MB in front of the witness upload made the next
+    // hipMemcpyAsync of a process's first cold prove wait 8–15 ms for the runtime)
   }
   if (!stage_done(ColdFeed::COEF)) return;
   // the witness of the prove that is waiting for all this
@@ -321,6 +322,8 @@ void cold_upload_task(ColdPlan* pl)
   }
   if (hipStreamSynchronize(su) != hipSuccess) return bail((int)ICICLE_SYNCHRONIZATION_FAILED, "cold upload: %s", "hipStreamSynchronize");
   if (trace) fprintf(stderr, "[cold] upload task done after %8.2f ms\n", ms_since(t0));
+  (void)hipFree(pl->d_records);
+  pl->d_records = nullptr;
   F.finish();
 }
 } // namespace

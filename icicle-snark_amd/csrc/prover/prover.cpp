@@ -146,7 +146,10 @@ __attribute__((visibility("default"))) void groth16_cache_manager_prewarm(Groth1
   try {
     // six streams for the first key, two lanes for its cold upload: a lane created on demand costs the first cold prove of a
     // process 80 ms (profiles/r05_cold_path.txt)
-    cm->warm = std::thread([device_id] { prewarm_device(device_id, 8); });
+    cm->warm = std::thread([device_id] {
+      prewarm_device(device_id, 8);
+      prewarm_modules(device_id);
+    });
   } catch (...) {
   }
 }
@@ -1180,8 +1183,9 @@ static int cold_prove(Groth16CacheManager* cm, const std::string& key, const Map
   evict_for_budget(cm, device_id, (uint64_t)zf.len * 11);
   std::thread dom_th; // the NTT domain of the key, set up while the sections cross PCIe (as in groth16_cache_load)
   try {
-    dom_th = std::thread([cm, device_id, dom_n] {
+    dom_th = std::thread([cm, device_id, dom_n, t0] {
       if (set_active_device(device_id) == 0) (void)ensure_domain_for(cm, device_id, dom_n);
+      if (getenv("ICICLE_SNARK_TRACE_COLD")) fprintf(stderr, "[cold] NTT domain ready at      %8.2f ms\n", ms_since(t0));
     });
   } catch (...) {
   }

@@ -18,6 +18,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <unistd.h>
+#include <chrono>
 
 #include "common.h"
 #include "msm_plan.h"
@@ -1054,8 +1055,11 @@ void prewarm_device(int dev, int n_streams)
     std::lock_guard<std::mutex> lk(g_sp_mu);
     have = g_stream_pool[dev].size();
   }
+  // one staging chunk per stream, host to device: a copy of a few KB goes through a blit kernel and leaves the stream's DMA queue
+  // to be set up by the first real chunk of a cold upload (10–40 ms for the first 141 MB of a process instead of 4)
+  const size_t warm_bytes = g_staged[dev].pinned ? STAGED_CHUNK : 4096;
   void* d = nullptr;
-  if (hipMalloc(&d, 4096) != hipSuccess) {
+  if (hipMalloc(&d, warm_bytes) != hipSuccess) {
     (void)hipGetLastError();
     return;
   }
@@ -1063,7 +1067,7 @@ void prewarm_device(int dev, int n_streams)
   for (size_t k = have; k < (size_t)n_streams && k < STREAM_POOL_MAX; k++) {
     hipStream_t st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-    (void)hipMemcpyAsync(d, g_staged[dev].pinned ? (void*)g_staged[dev].pinned : d, 4096, g_staged[dev].pinned ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(d, g_staged[dev].pinned ? (void*)g_staged[dev].pinned : d, warm_bytes, g_staged[dev].pinned ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st);
     fresh.push_back(st);
   }
   for (hipStream_t st : fresh) (void)hipStreamSynchronize(st);
@@ -1075,6 +1079,29 @@ void prewarm_device(int dev, int n_streams)
     if (v.size() < STREAM_POOL_MAX) v.push_back(st);
     else (void)hipStreamDestroy(st);
   }
+}
+void prewarm_modules(int dev)
+{
+  if (dev < 0 || hipSetDevice(dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  module_warm_csr(s);
+  module_warm_qap(s);
+  module_warm_sort(s);
+  module_warm_g1(s);
+  module_warm_g2(s);
+  module_warm_g2acc(s);
+  module_warm_ntt(s);
+  module_warm_vec(s);
+  (void)hipStreamSynchronize(s);
+  (void)hipStreamDestroy(s);
+  (void)hipGetLastError();
 }
 int default_device_or_none() { return active_device(); }
 } // namespace isnark

@@ -14,6 +14,12 @@ zp, wp, pp, qp = (os.path.join(d, x) for x in ("circuit.zkey", "witness.wtns", "
 if not os.path.exists(zp):
     zkey, wtns = bench.make_inputs(K, S, N)
     open(zp, "wb").write(zkey); open(wp, "wb").write(wtns)
+    if os.environ.get("PRE_READ") == "1":          # the files read once before the first prove (a key that has been used before)
+        with open(zp, "rb") as f:
+            while f.read(1 << 24):
+                pass
+    if os.environ.get("PRE_READ") == "2":          # … or just given time (write-back of the fresh file)
+        import time as _t; os.sync(); _t.sleep(2)
     del zkey, wtns
 K.check(K.lib().icicle_device_synchronize(), "sync")
 for rnd in range(2):
