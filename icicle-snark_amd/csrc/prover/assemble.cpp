@@ -90,6 +90,36 @@ int compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_i
   return 0;
 }
 
+static std::string dec32(const void* p)
+{
+  fe v;
+  memcpy(v.l, p, 32);
+  return to_decimal(v);
+}
+void early_pi_a(const ZKeyCache* z, const Blinding& bl, const bn254_projective_t* a_plus_alpha_d1r, EarlyTerms* et)
+{
+  (void)z;
+  (void)bl;
+  bn254_affine_t a_aff;
+  bn254_to_affine(a_plus_alpha_d1r, &a_aff);
+  et->a_dec[0] = dec32(&a_aff.x);
+  et->a_dec[1] = dec32(&a_aff.y);
+  et->a_ready.store(true, std::memory_order_release);
+}
+void early_pi_b(const ZKeyCache* z, const Blinding& bl, const bn254_g2_projective_t* b2_sum, EarlyTerms* et)
+{
+  bn254_g2_projective_t pi_b = *b2_sum;
+  bn254_g2_ecadd(&pi_b, (const bn254_g2_projective_t*)&z->vk_beta_2, &pi_b);
+  bn254_g2_ecadd(&pi_b, &bl.d2s, &pi_b); // pi_b = B2 + β2 + δ2·s — src/proof_helper.rs:281
+  bn254_g2_affine_t b_aff;
+  bn254_g2_to_affine(&pi_b, &b_aff);
+  et->b_dec[0] = dec32(&b_aff.x.c0);
+  et->b_dec[1] = dec32(&b_aff.x.c1);
+  et->b_dec[2] = dec32(&b_aff.y.c0);
+  et->b_dec[3] = dec32(&b_aff.y.c1);
+  et->b_ready.store(true, std::memory_order_release);
+}
+
 int assemble_impl(const ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap, const EarlyTerms* et)
 {
   Wtns w;
@@ -128,20 +158,34 @@ int assemble_impl(const ZKeyCache* z, const void* wtns, size_t wtns_len, const u
   }
   bn254_ecsub(&pi_c, &bl.d1rs, &pi_c);          // − δ1·r·s
   (void)t2;
-  bn254_affine_t a_aff, c_aff;
-  bn254_g2_affine_t b_aff;
-  bn254_to_affine(&pi_a, &a_aff);
-  bn254_g2_to_affine(&pi_b, &b_aff);
+  bn254_affine_t c_aff;
   bn254_to_affine(&pi_c, &c_aff);
-  auto dec = [](const void* p) {
-    fe v;
-    memcpy(v.l, p, 32);
-    return to_decimal(v);
-  };
+  auto dec = [](const void* p) { return dec32(p); };
+  // pi_a and pi_b: from the tail threads of A and B2 when they got there (EarlyTerms), else here
+  std::string a_dec[2], b_dec[4];
+  if (et && et->a_ready.load(std::memory_order_acquire)) {
+    a_dec[0] = et->a_dec[0];
+    a_dec[1] = et->a_dec[1];
+  } else {
+    bn254_affine_t a_aff;
+    bn254_to_affine(&pi_a, &a_aff);
+    a_dec[0] = dec(&a_aff.x);
+    a_dec[1] = dec(&a_aff.y);
+  }
+  if (et && et->b_ready.load(std::memory_order_acquire)) {
+    for (int i = 0; i < 4; i++) b_dec[i] = et->b_dec[i];
+  } else {
+    bn254_g2_affine_t b_aff;
+    bn254_g2_to_affine(&pi_b, &b_aff);
+    b_dec[0] = dec(&b_aff.x.c0);
+    b_dec[1] = dec(&b_aff.x.c1);
+    b_dec[2] = dec(&b_aff.y.c0);
+    b_dec[3] = dec(&b_aff.y.c1);
+  }
   // serde_json::to_writer_pretty of a Value built with json!(proof): object keys sorted (BTreeMap), 2-space indent
   std::string pj = "{\n  \"curve\": \"bn128\",\n";
-  pj += "  \"pi_a\": [\n    \"" + dec(&a_aff.x) + "\",\n    \"" + dec(&a_aff.y) + "\",\n    \"1\"\n  ],\n";
-  pj += "  \"pi_b\": [\n    [\n      \"" + dec(&b_aff.x.c0) + "\",\n      \"" + dec(&b_aff.x.c1) + "\"\n    ],\n    [\n      \"" + dec(&b_aff.y.c0) + "\",\n      \"" + dec(&b_aff.y.c1) +
+  pj += "  \"pi_a\": [\n    \"" + a_dec[0] + "\",\n    \"" + a_dec[1] + "\",\n    \"1\"\n  ],\n";
+  pj += "  \"pi_b\": [\n    [\n      \"" + b_dec[0] + "\",\n      \"" + b_dec[1] + "\"\n    ],\n    [\n      \"" + b_dec[2] + "\",\n      \"" + b_dec[3] +
         "\"\n    ],\n    [\n      \"1\",\n      \"0\"\n    ]\n  ],\n";
   pj += "  \"pi_c\": [\n    \"" + dec(&c_aff.x) + "\",\n    \"" + dec(&c_aff.y) + "\",\n    \"1\"\n  ],\n";
   pj += "  \"protocol\": \"groth16\"\n}";

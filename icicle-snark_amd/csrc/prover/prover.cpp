@@ -807,6 +807,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
         bn254_ecadd(&p, k == 0 ? &et->bl->d1r : &et->bl->d1s, &p);
         bn254_mul_scalar(&p, k == 0 ? &et->bl->s : &et->bl->r, k == 0 ? &et->ta : &et->tb);
         et->done.fetch_add(1, std::memory_order_release);
+        if (k == 0) early_pi_a(z, *et->bl, &p, et); // p = pi_a
       }
     };
     // the four other tails on pooled workers (workers.h), H's — the last to arrive — on this thread
@@ -819,6 +820,12 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       (void)hipEventSynchronize(evd[2]);
       if (gw.tab) msm_g2_host_tail_tab(HP + 2 * PARTIALS_STRIDE, Wb, (bn254_g2_projective_t*)(out_points + 192));
       else msm_g2_host_tail(HP + 2 * PARTIALS_STRIDE, Wb, 1, cw, gw.wide, (bn254_g2_projective_t*)(out_points + 192));
+      if (et) {
+        while (!et->bl_ready.load(std::memory_order_acquire)) std::this_thread::yield();
+        bn254_g2_projective_t b2;
+        memcpy(&b2, out_points + 192, sizeof b2);
+        early_pi_b(z, *et->bl, &b2, et);
+      }
     };
     bool pooled[4];
     for (int k = 0; k < 4; k++) pooled[k] = WorkerPool::get().submit(&tt[k]);

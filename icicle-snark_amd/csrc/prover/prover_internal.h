@@ -214,7 +214,14 @@ struct EarlyTerms {
   std::atomic<bool> bl_ready{false};
   bn254_projective_t ta, tb;
   std::atomic<int> done{0};
+  // pi_a and pi_b complete (blinded, affine, as the decimal strings of proof.json) as soon as A's and B2's tails have run —
+  // milliseconds before H's: only pi_c is left for assemble_impl after the last kernel
+  std::string a_dec[2], b_dec[4];
+  std::atomic<bool> a_ready{false}, b_ready{false};
 };
+// pi_a = A + α1 + δ1·r / pi_b = B2 + β2 + δ2·s → affine → decimal strings (assemble.cpp)
+void early_pi_a(const ZKeyCache* z, const Blinding& bl, const bn254_projective_t* a_plus_alpha_d1r, EarlyTerms* et);
+void early_pi_b(const ZKeyCache* z, const Blinding& bl, const bn254_g2_projective_t* b2_sum, EarlyTerms* et);
 int compute_blinding(const ZKeyCache* z, const uint8_t* r_in, const uint8_t* s_in, Blinding* b);
 int assemble_impl(const ZKeyCache* z, const void* wtns, size_t wtns_len, const uint8_t* points, const Blinding& bl, char* proof_json, size_t proof_cap, char* public_json, size_t public_cap,
                   const EarlyTerms* et = nullptr);
