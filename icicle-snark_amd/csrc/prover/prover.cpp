@@ -1144,10 +1144,16 @@ __attribute__((visibility("default"))) int groth16_prove_resident(Groth16CacheMa
 static int write_json_pair(const char* proof_path, const char* proof_text, const char* public_path, const char* public_text)
 {
   auto put = [](const char* path, const char* text) -> bool {
-    FILE* f = fopen(path, "wb");
-    if (!f) return false;
-    const bool ok = fputs(text, f) >= 0;
-    return fclose(f) == 0 && ok;
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fd < 0) return false;
+    const size_t n = strlen(text);
+    size_t done = 0;
+    while (done < n) {
+      const ssize_t w = write(fd, text + done, n - done);
+      if (w <= 0) break;
+      done += (size_t)w;
+    }
+    return close(fd) == 0 && done == n;
   };
   bool ok_public = false;
   HostTask t;
