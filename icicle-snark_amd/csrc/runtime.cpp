@@ -231,6 +231,7 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
   }
   std::atomic<size_t> next{0};
   std::atomic<int> err{(int)hipSuccess};
+  static const bool trace_slow = getenv("ICICLE_SNARK_TRACE_HOST") != nullptr;
   // chunks of the head (StagedProgress): the first chunks of job 0
   const size_t head_chunks = progress && to_device && njobs ? ((progress->head_bytes < jobs[0].n ? progress->head_bytes : jobs[0].n) + CH - 1) / CH : 0;
   auto worker = [&](int t) {
@@ -260,7 +261,9 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
         if (i >= head_chunks) report_head(); // chunks are handed out in order: this lane has enqueued its last chunk of the head
         if (i >= chunks.size() || err.load() != (int)hipSuccess) break;
         hipError_t e = hipSuccess;
+        const auto tA = trace_slow ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         if (used[k]) e = hipEventSynchronize(P.events[t][k]); // the DMA that last read this buffer is done
+        const auto tB = trace_slow ? std::chrono::steady_clock::now() : tA;
         if (e == hipSuccess) {
           const uint8_t* src = (const uint8_t*)chunks[i].src;
           bool done = false;
@@ -274,7 +277,15 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
             done = got == chunks[i].n;
           }
           if (!done) memcpy(buf[k], src, chunks[i].n);
+          const auto tC = trace_slow ? std::chrono::steady_clock::now() : tA;
           e = hipMemcpyAsync(chunks[i].dst, buf[k], chunks[i].n, hipMemcpyHostToDevice, streams[t]);
+          if (trace_slow) {
+            // ICICLE_SNARK_TRACE_HOST: which step of a chunk took more than 2 ms (buffer wait / read out of the page cache / enqueue)
+            const auto tD = std::chrono::steady_clock::now();
+            const double w = std::chrono::duration<double, std::milli>(tB - tA).count(), r = std::chrono::duration<double, std::milli>(tC - tB).count(),
+                         q = std::chrono::duration<double, std::milli>(tD - tC).count();
+            if (w > 2 || r > 2 || q > 2) fprintf(stderr, "[host] staged copy: lane %d chunk %zu of %zu: buffer wait %.2f ms, read %.2f ms, enqueue %.2f ms\n", t, i, chunks.size(), w, r, q);
+          }
         }
         if (e == hipSuccess) e = hipEventRecord(P.events[t][k], streams[t]);
         used[k] = true;
