@@ -109,7 +109,10 @@ void table_build_thread(ZKeyCache* z)
   TableBuild& tb = z->tb;
   // behind the key's first proof, not beside it: a prove next to the build takes 24 instead of 19 ms at 1.6 M constraints, and
   // the first one is the one a caller without a cache waits for.  A key nobody proves with gets its tables after the grace time.
-  for (int waited = 0; !tb.witness_only && waited < TABLE_BUILD_GRACE_MS && !tb.go.load(std::memory_order_acquire) && !tb.cancel.load(); waited++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  // (cold pipeline: not before the key's sections have landed — cold_prove clears `hold` behind the upload, or evicts the key)
+  while (tb.hold.load(std::memory_order_acquire) && !tb.cancel.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  const int grace_ms = getenv("ICICLE_SNARK_TABLE_GRACE_MS") ? atoi(getenv("ICICLE_SNARK_TABLE_GRACE_MS")) : TABLE_BUILD_GRACE_MS;
+  for (int waited = 0; !tb.witness_only && waited < grace_ms && !tb.go.load(std::memory_order_acquire) && !tb.cancel.load(); waited++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   const auto t0 = std::chrono::steady_clock::now();
   bool ok = hipSetDevice(z->device_id) == hipSuccess;
   // The key's first prove (classic layout) has counted the non-zero digits of its witness: a witness of 0 / 1 wires and small values
@@ -619,6 +622,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     }
     free_records.p = nullptr; // the records belong to the task now (freed behind the CSR build)
     zz->feed = &cold->feed;
+    zz->tb.hold.store(true, std::memory_order_release); // the deferred table build reads the base arrays: not before they are complete
     cold->task.fn = [pl] { cold_upload_task(pl); };
     cold->started = true;
     WorkerPool::get().run_or_inline(&cold->task);

@@ -1243,6 +1243,7 @@ static int cold_prove(Groth16CacheManager* cm, const std::string& key, const Map
   cold_upload_wait(&cu);
   z->feed = nullptr;
   const int up_rc = cu.feed.rc;
+  if (!up_rc) z->tb.hold.store(false, std::memory_order_release); // the sections are complete: the deferred table build may read them
   const std::string up_err = cu.feed.err;
   lk.unlock();
   if (up_rc) {

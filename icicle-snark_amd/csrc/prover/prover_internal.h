@@ -97,6 +97,7 @@ struct TableBuild {
   std::atomic<int> state{0}; // 0 nothing pending, 1 building, 2 complete (fresh[] valid, not adopted yet), 3 failed / cancelled
   std::atomic<bool> cancel{false};
   std::atomic<bool> go{false}; // set at the end of the key's first prove: the build starts behind it, not beside it (or after TABLE_BUILD_GRACE_MS without one)
+  std::atomic<bool> hold{false}; // cold pipeline: the base arrays are still being uploaded — nothing may read them before cold_prove clears this (neither `go` nor the grace time counts)
   void* fresh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // A, B1, B2, C, H
   MsmGeom gw, gh;            // the table geometries the build works towards
   int dense_c = 0;           // digit width of the dense witness geometry (gw may be narrower: the first prove's witness was light)

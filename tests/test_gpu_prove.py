@@ -711,3 +711,39 @@ def test_two_threads_prove_uncached_keys_through_one_manager(gpu, S, tmp_path):
     assert not errors, errors
     cm.close()
     K.release_domain()
+
+
+def test_deferred_table_build_waits_for_the_cold_upload(gpu, S, tmp_path):
+    """The worker that builds a key's fixed-base tables reads the base arrays: inside a cold prove (sections still crossing PCIe) it
+    must not start before they have landed, whatever its grace time says.  ICICLE_SNARK_TABLE_GRACE_MS=0 makes it want to start at
+    once; 800 k constraints make the upload (≈ 15 ms) outlast the worker's start-up.  Every proof — the cold one, the ones on the
+    adopted tables — passes the pairing check (a build from half-uploaded bases gave tables, and proofs, that do not)."""
+    K = gpu
+    B = importlib.import_module("bench")
+    N = 800_000
+    K.release_domain()
+    K.initialize_domain(K.get_root_of_unity(1 << 20))
+    zkey, vk = S.setup_squaring_chain(N, B.GpuVec(K), _fbm(K), points_to_mont=B._to_mont(K))
+    K.release_domain()
+    vkj = S.vk_to_json(vk)
+    zp, wp, pp, qp = (str(tmp_path / x) for x in ("c.zkey", "w.wtns", "proof.json", "public.json"))
+    open(zp, "wb").write(zkey)
+    open(wp, "wb").write(S.write_wtns(S.squaring_chain_witness(N)))
+    del zkey
+    public = [str(pow(3, 1 << N, S.R_MOD))]
+    cm = K.CacheManager()
+    os.environ["ICICLE_SNARK_TABLE_GRACE_MS"] = "0"
+    try:
+        for rep in range(3):
+            cm.prove_files(wp, zp, pp, qp)                               # cold: upload, first proof and (held back) table worker
+            assert json.loads(open(qp).read()) == public
+            assert K.groth16_verify_json(open(pp).read(), open(qp).read(), vkj), rep
+            assert cm.tables_ready(f"{zp}_HIP", wait=True)
+            for _ in range(2):
+                cm.prove_files(wp, zp, pp, qp)                           # on the adopted tables
+                assert K.groth16_verify_json(open(pp).read(), open(qp).read(), vkj), rep
+            cm.evict(f"{zp}_HIP")
+    finally:
+        del os.environ["ICICLE_SNARK_TABLE_GRACE_MS"]
+    cm.close()
+    K.release_domain()
