@@ -1033,6 +1033,14 @@ def main():
             skew_ms = med(lambda: cm.prove_mem(key, skewed, resident=True), 3)
             cm.prove_mem(key, wtns)   # restore the resident witness
     hbm_copy_gbps, mad_tops = K.microbench() if rank == 0 else (None, None)
+    # what kind of box this is: the boxes of one pool differ most in scattered accesses (round 5: digit sort and table build 2–3× slower
+    # on some boxes at the same copy rate) — printed as config.box_access_gbps, not used in any figure
+    box_access = None
+    if rank == 0:
+        try:
+            box_access = K.access_probes()
+        except Exception as e:   # noqa: BLE001 — informational only
+            log(f"access probes failed: {e!r}")
     if world == 1 and not args.no_dropin:
         cm.evict(key)
         cm.close()
@@ -1116,7 +1124,8 @@ def main():
                        "cold_prove_ms_files": cold.get("cold_prove_ms_files"), "cold_path": cold or None,
                        "b_msm_bases": info.b_bases, "n_vars": info.n_vars,
                        "prove_ms_bit_heavy_witness_standin": skew_ms,
-                       "phase_ms": {"qap_ntt": phases["qap"] / args.steps, "msm": phases["msm"] / args.steps}},
+                       "phase_ms": {"qap_ntt": phases["qap"] / args.steps, "msm": phases["msm"] / args.steps},
+                       "box_access_gbps": box_access},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

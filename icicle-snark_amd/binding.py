@@ -101,7 +101,7 @@ bn254_msm_precompute_bases bn254_g2_msm_precompute_bases
 bn254_pairing_target_field_add bn254_pairing_target_field_sub bn254_pairing_target_field_mul bn254_pairing_target_field_inv
 bn254_pairing_target_field_pow bn254_pairing_target_field_from_u32 bn254_pairing_target_field_generate_scalars
 icicle_snark_last_error icicle_snark_g1_generator_mul icicle_snark_g2_generator_mul icicle_snark_last_msm_timings
-icicle_snark_msm_profile icicle_snark_microbench icicle_snark_pmc_probes
+icicle_snark_msm_profile icicle_snark_microbench icicle_snark_pmc_probes icicle_snark_access_probes
 """.split()
 
 _lib = None
@@ -439,6 +439,13 @@ def microbench():
     out = (C.c_double * 2)()
     check(lib().icicle_snark_microbench(out), "microbench")
     return float(out[0]), float(out[1])
+
+
+def access_probes():
+    """GB/s of 64-byte gathers, 128-byte gathers, coalesced reads, scattered 4-byte stores, coalesced 4-byte stores (2 GiB buffer), measured now"""
+    out = (C.c_double * 5)()
+    check(lib().icicle_snark_access_probes(out), "access_probes")
+    return dict(zip(("gather64_gbps", "gather128_gbps", "stream_read_gbps", "scattered_store_gbps", "coalesced_store_gbps"), (round(float(x), 1) for x in out)))
 
 
 def generator_mul(group: str, scalars: np.ndarray) -> np.ndarray:

@@ -91,6 +91,58 @@ ISNARK_API eIcicleError icicle_snark_pmc_probes(double out[5])
   return ICICLE_SUCCESS;
 }
 
+// The five probes above, timed with HIP events: out[i] = GB/s of {64-byte gathers, 128-byte gathers, coalesced 16-byte reads,
+// scattered 4-byte stores, coalesced 4-byte stores} over a 2 GiB buffer.  The boxes of one pool differ most in the scattered
+// patterns (round 5: digit sort and table build 2–3× slower on some boxes at the same copy rate): bench.py prints these next to
+// its line so that a reader can tell what kind of box a number comes from.  Takes ≈ 30 ms.
+ISNARK_API eIcicleError icicle_snark_access_probes(double out[5])
+{
+  if (!out) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(require_device());
+  const size_t table_bytes = (size_t)2 << 30;
+  uint4 *table = nullptr, *o = nullptr;
+  HIP_TRY(hipMalloc((void**)&table, table_bytes), ICICLE_ALLOCATION_FAILED);
+  if (hipMalloc((void**)&o, (size_t)4096 * 256 * 16) != hipSuccess) {
+    (void)hipFree(table);
+    return ICICLE_ALLOCATION_FAILED;
+  }
+  hipEvent_t ev[6];
+  for (auto& e : ev) (void)hipEventCreate(&e);
+  (void)hipMemsetAsync(table, 1, table_bytes, nullptr);
+  const uint32_t blocks = 4096, per = 26;
+  double bytes[5];
+  for (int rep = 0; rep < 2; rep++) { // (the first round warms the kernels' code object and the page tables)
+    (void)hipEventRecord(ev[0], nullptr);
+    hipLaunchKernelGGL(probe_gather_kernel, dim3(blocks), dim3(256), 0, nullptr, table, (uint32_t)(table_bytes / 64), per, 4, o);
+    bytes[0] = (double)blocks * 256 * per * 64;
+    (void)hipEventRecord(ev[1], nullptr);
+    hipLaunchKernelGGL(probe_gather_kernel, dim3(blocks), dim3(256), 0, nullptr, table, (uint32_t)(table_bytes / 128), per, 8, o);
+    bytes[1] = (double)blocks * 256 * per * 128;
+    (void)hipEventRecord(ev[2], nullptr);
+    hipLaunchKernelGGL(probe_stream_kernel, dim3(blocks), dim3(256), 0, nullptr, table, (uint64_t)(table_bytes / 16), o);
+    bytes[2] = (double)table_bytes;
+    (void)hipEventRecord(ev[3], nullptr);
+    hipLaunchKernelGGL(probe_store_kernel, dim3(blocks), dim3(256), 0, nullptr, (uint32_t*)table, (uint32_t)(table_bytes / 4), 20u, 1);
+    bytes[3] = (double)blocks * 256 * 20 * 4;
+    (void)hipEventRecord(ev[4], nullptr);
+    hipLaunchKernelGGL(probe_store_kernel, dim3(blocks), dim3(256), 0, nullptr, (uint32_t*)table, (uint32_t)(table_bytes / 4), 20u, 0);
+    bytes[4] = (double)blocks * 256 * 20 * 4;
+    (void)hipEventRecord(ev[5], nullptr);
+  }
+  const eIcicleError le = check_launch("access probes");
+  const hipError_t se = hipEventSynchronize(ev[5]);
+  for (int i = 0; i < 5; i++) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+    out[i] = ms > 0 ? bytes[i] / (ms * 1e-3) / 1e9 : 0;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  (void)hipFree(table);
+  (void)hipFree(o);
+  if (le != ICICLE_SUCCESS) return le;
+  return se == hipSuccess ? ICICLE_SUCCESS : ICICLE_SYNCHRONIZATION_FAILED;
+}
+
 // out[0] = device-to-device copy rate in GB/s counting read + write bytes; out[1] = v_mad_u64_u32 lane-operations per
 // second in units of 10^12.  Takes ≈20 ms.
 ISNARK_API eIcicleError icicle_snark_microbench(double out[2])

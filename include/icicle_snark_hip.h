@@ -271,6 +271,9 @@ eIcicleError icicle_snark_pmc_probes(double out_bytes[5]);
 /* measured machine constants for bench.py: out[0] = device-to-device copy GB/s (read + write bytes),
  * out[1] = v_mad_u64_u32 lane-operations per second / 10^12 */
 eIcicleError icicle_snark_microbench(double out[2]);
+/* the five access patterns of icicle_snark_pmc_probes TIMED (HIP events): out = GB/s of {64-byte gathers, 128-byte gathers, coalesced
+ * reads, scattered 4-byte stores, coalesced 4-byte stores} over a 2 GiB buffer — what kind of box a bench line comes from */
+eIcicleError icicle_snark_access_probes(double out_gbps[5]);
 
 #ifdef __cplusplus
 }
