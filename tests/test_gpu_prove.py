@@ -717,6 +717,27 @@ def test_two_threads_prove_uncached_keys_through_one_manager(gpu, S, tmp_path):
     for t in ts:
         t.join()
     assert not errors, errors
+
+    # … and the SAME uncached key from two threads at once: one of them runs the cold pipeline, the other finds the entry afterwards
+    def same(i):
+        N, zp, wp, vkj, public = keys[1]
+        pp, qp = str(tmp_path / f"sp{i}.json"), str(tmp_path / f"sq{i}.json")
+        try:
+            for it in range(3):
+                cm.prove_files(wp, zp, pp, qp)
+                if json.loads(open(qp).read()) != public or not K.groth16_verify_json(open(pp).read(), open(qp).read(), vkj):
+                    errors.append(("same", i, it))
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("same", i, repr(e)))
+
+    for rnd in range(3):
+        cm.evict(f"{keys[1][1]}_HIP")
+        ts = [threading.Thread(target=same, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errors, errors
     cm.close()
     K.release_domain()
 
