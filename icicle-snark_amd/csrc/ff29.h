@@ -360,6 +360,177 @@ F29_CONST(c256_to_261, F29_C266)  // 2^266 mod p          (x·2^256 → x·2^261
 F29_CONST(c261_to_256, F29_C256)  // 2^256 mod p          (x·2^261 → x·2^256: mul(x261, c))
 F29_CONST(one_std, 1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u) // x·2^261 → x: mul(x261, 1)
 
+// a⁻¹ (Montgomery-261 in and out; a N, < 2p; 0 ↦ 0) by Fermat, a^(p − 2), two exponent bits per step: 254 squares and ≈ 95
+// products on one lane (≈ 80 k instructions) — the reference against which inv_ds below is checked (tests/test_f29.py).
+FF_HD fe9 inv(const fe9& a)
+{
+  constexpr uint32_t E[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u}; // p − 2
+  const fe9 a2 = sqr(a), a3 = mul(a2, a);
+  fe9 r = one_m();
+  for (int i = 127; i >= 0; i--) {
+    r = sqr(sqr(r));
+    const uint32_t d = (E[i >> 4] >> ((i & 15) * 2)) & 3u;
+    if (d == 1) r = mul(r, a);
+    else if (d == 2) r = mul(r, a2);
+    else if (d == 3) r = mul(r, a3);
+  }
+  return r;
+}
+
+// The same inverse by 600 "divsteps" (Bernstein–Yang, https://gcd.cr.yp.to/safegcd-20190413.pdf, in the half-delta form: 590
+// steps bound a 256-bit modulus) in 20 batches of 30: a batch runs on the low 30 bits of f and g alone and yields a 2×2
+// transition matrix of 31-bit entries, which is then applied to the full-width pairs (f, g) — exact division by 2^30 — and
+// (d, e) — division modulo p by adding the multiple of p that clears the low limb.  Invariants: d·x ≡ f, e·x ≡ g (mod p);
+// at the end g = 0, f = ±1, so ±d = x⁻¹.  Signed limbs of 30 bits, the top one carrying the sign; everything is straight-line
+// code with masks (no data-dependent branches: lanes of a wave stay together).  ≈ 14 k instructions against the ≈ 80 k of the
+// Fermat ladder above (ff.h's 8×32 ladder: ≈ 100 k): what the batched projective → affine conversion of the fixed-base table
+// builds spends per 32 points (msm_impl.h: batch_to_affine_kernel).  Checked against inv() and ff.h's Fermat inverse by
+// tests/test_f29.py.
+namespace ds30 {
+constexpr int32_t M30 = (1 << 30) - 1;
+constexpr int32_t P30[9] = {0x187cfd47, 0x3082305b, 0x71ca8d3, 0x205aa45a, 0x1585d97, 0x116da06, 0x1a029b85, 0x139cb84c, 0x3064};
+constexpr uint32_t PINV30 = 0x1b799c77u; // p⁻¹ mod 2^30
+struct S30 {
+  int32_t v[9];
+};
+// 30 divsteps on the low limbs; returns the new zeta, t = (u, v, q, r) with 2^30·(f', g') = (u·f + v·g, q·f + r·g)
+FF_HD int32_t divsteps30(int32_t zeta, uint32_t f0, uint32_t g0, int32_t t[4])
+{
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+  for (int i = 0; i < 30; i++) {
+    uint32_t m1 = (uint32_t)(zeta >> 31);   // zeta < 0
+    const uint32_t m2 = 0u - (g & 1u);      // g odd
+    const uint32_t x = (f ^ m1) - m1, y = (u ^ m1) - m1, z = (v ^ m1) - m1; // (f, u, v) negated when zeta < 0
+    g += x & m2;
+    q += y & m2;
+    r += z & m2;
+    m1 &= m2;                               // zeta < 0 and g odd: swap roles
+    zeta = (int32_t)(((uint32_t)zeta ^ m1) - 1u);
+    f += g & m1;
+    u += q & m1;
+    v += r & m1;
+    g >>= 1;
+    u <<= 1;
+    v <<= 1;
+  }
+  t[0] = (int32_t)u;
+  t[1] = (int32_t)v;
+  t[2] = (int32_t)q;
+  t[3] = (int32_t)r;
+  return zeta;
+}
+FF_HD void update_de(S30& d, S30& e, const int32_t t[4])
+{
+  const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+  const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+  int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+  int32_t di = d.v[0], ei = e.v[0];
+  int64_t cd = (int64_t)u * di + (int64_t)v * ei, ce = (int64_t)q * di + (int64_t)r * ei;
+  md -= (int32_t)((PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+  me -= (int32_t)((PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+  cd += (int64_t)P30[0] * md;
+  ce += (int64_t)P30[0] * me;
+  cd >>= 30;
+  ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; i++) {
+    di = d.v[i];
+    ei = e.v[i];
+    cd += (int64_t)u * di + (int64_t)v * ei;
+    ce += (int64_t)q * di + (int64_t)r * ei;
+    cd += (int64_t)P30[i] * md;
+    ce += (int64_t)P30[i] * me;
+    d.v[i - 1] = (int32_t)cd & M30;
+    cd >>= 30;
+    e.v[i - 1] = (int32_t)ce & M30;
+    ce >>= 30;
+  }
+  d.v[8] = (int32_t)cd;
+  e.v[8] = (int32_t)ce;
+}
+FF_HD void update_fg(S30& f, S30& g, const int32_t t[4])
+{
+  const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+  int32_t fi = f.v[0], gi = g.v[0];
+  int64_t cf = (int64_t)u * fi + (int64_t)v * gi, cg = (int64_t)q * fi + (int64_t)r * gi;
+  cf >>= 30; // (the low 30 bits are zero by construction of t)
+  cg >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; i++) {
+    fi = f.v[i];
+    gi = g.v[i];
+    cf += (int64_t)u * fi + (int64_t)v * gi;
+    cg += (int64_t)q * fi + (int64_t)r * gi;
+    f.v[i - 1] = (int32_t)cf & M30;
+    cf >>= 30;
+    g.v[i - 1] = (int32_t)cg & M30;
+    cg >>= 30;
+  }
+  f.v[8] = (int32_t)cf;
+  g.v[8] = (int32_t)cg;
+}
+} // namespace ds30
+
+// a (Montgomery-261, N, < 16p) → a⁻¹ (Montgomery-261, N, < 2p); 0 ↦ 0
+FF_HD fe9 inv_ds(const fe9& a)
+{
+  using namespace ds30;
+  const fe w = pack(canon(a)); // the integer A = a·R' mod p, 256 bits
+  S30 d, e, f, g;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int bit = 30 * i, wd = bit >> 5, sh = bit & 31;
+    uint32_t x = w.l[wd] >> sh;
+    if (sh > 2 && wd + 1 < 8) x |= w.l[wd + 1] << (32 - sh);
+    g.v[i] = (int32_t)(x & (uint32_t)M30);
+    f.v[i] = P30[i];
+    d.v[i] = 0;
+    e.v[i] = i == 0 ? 1 : 0;
+  }
+  int32_t zeta = -1;
+  for (int it = 0; it < 20; it++) {
+    int32_t t[4];
+    zeta = divsteps30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+    update_de(d, e, t);
+    update_fg(f, g, t);
+  }
+  // d ∈ (−2p, p), f = ±1:  result = sign(f)·d brought into [0, p)
+  {
+    const int32_t neg = f.v[8] >> 31;
+    int32_t add = d.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] = ((d.v[i] + (P30[i] & add)) ^ neg) - neg;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      d.v[i + 1] += d.v[i] >> 30;
+      d.v[i] &= M30;
+    }
+    add = d.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] += P30[i] & add;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      d.v[i + 1] += d.v[i] >> 30;
+      d.v[i] &= M30;
+    }
+  }
+  // 30-bit limbs → 256-bit words → 29-bit limbs; A⁻¹ → a⁻¹·R' = A⁻¹·R'² = mul(A⁻¹, R'³)
+  fe o;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int bit = 32 * k, li = bit / 30, sh = bit % 30;
+    uint32_t x = (uint32_t)d.v[li] >> sh;
+    if (li + 1 < 9) x |= (uint32_t)d.v[li + 1] << (30 - sh);
+    if (sh > 28 && li + 2 < 9) x |= (uint32_t)d.v[li + 2] << (60 - sh);
+    o.l[k] = x;
+  }
+  constexpr uint32_t R3[9] = {0xe2312b2u, 0x16c05ca2u, 0xbc84389u, 0x1cdf310bu, 0x11adafddu, 0x32e568eu, 0x1d6ae48cu, 0x10d4cd1fu, 0x26c2d2u}; // 2^783 mod p
+  fe9 c;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.l[i] = R3[i];
+  return mul(unpack(o), c);
+}
+
 // packed Montgomery-256 / standard form (canonical) → Montgomery-261 (N, < 2p)
 FF_HD fe9 from_mont256(const fe& x) { return mul(unpack(x), c256_to_261()); }
 FF_HD fe9 from_std(const fe& x) { return mul(unpack(x), r2_m()); }

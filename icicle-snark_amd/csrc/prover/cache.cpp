@@ -120,13 +120,30 @@ void table_build_thread(ZKeyCache* z)
   // at once instead of building the dense ones and rebuilding them INSIDE a later prove (0.1–0.3 s).  The classic count (16-bit digits)
   // is an upper bound of the table-mode one, so the width chosen here is the rule's or one bit above it; the rule keeps following the
   // witnesses afterwards.  (witness_entries was written before `go` was released.)
+  const MsmGeom gw_dense = tb.gw;
+  bool narrowed = false;
   if (ok && !tb.witness_only && tb.go.load(std::memory_order_acquire) && z->witness_entries) {
     int lg = 0;
     while (((uint64_t)1 << lg) * 32 < z->witness_entries) lg++;
     int c_t = lg + 1 < 13 ? 13 : lg + 1;
     if (c_t <= tb.gw.c - 2) {
       const MsmGeom g = msm_geometry(z->A.len(), 0, c_t);
-      if (g.tab && g.c == c_t) tb.gw = g;
+      // a narrower digit = more rows per table than build_cache sized (`pending_bytes`, the budget's admission, the device's memory):
+      // taken only when the extra bytes fit what the cache budget has left (narrow_room) and the device has them free beside the
+      // slices' temporaries — as start_witness_rebuild checks for a re-build (round-5 advisor)
+      if (g.tab && g.c == c_t && g.W > tb.gw.W) {
+        const uint64_t per_row = (uint64_t)z->A.len() * 64 + (uint64_t)z->B1.len() * 64 + (uint64_t)z->B2.len() * 128 + (uint64_t)z->C.len() * 64;
+        const uint64_t extra = (uint64_t)(g.W - tb.gw.W) * per_row;
+        size_t free_b = 0, total_b = 0;
+        const bool mem_ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)g.W * per_row + (uint64_t)tb.gh.W * z->H.len() * 64 + (1ull << 30) <= free_b;
+        (void)hipGetLastError();
+        if (mem_ok && extra <= tb.narrow_room.load(std::memory_order_acquire)) {
+          tb.gw = g;
+          tb.extra_bytes.store(extra, std::memory_order_release);
+          narrowed = true;
+        }
+      } else if (g.tab && g.c == c_t)
+        tb.gw = g;
     }
   }
   hipStream_t s = nullptr;
@@ -142,21 +159,33 @@ void table_build_thread(ZKeyCache* z)
   struct Job { const Shard* sh; bool g2; const MsmGeom* g; };
   // H first: the longest of the five builds' G1 arrays; B2 (the G2 array, 60 % of the G1 four together) last
   const Job jobs[5] = {{&z->A, false, &tb.gw}, {&z->B1, false, &tb.gw}, {&z->B2, true, &tb.gw}, {&z->C, false, &tb.gw}, {&z->H, false, &tb.gh}};
-  for (int k : {4, 0, 1, 3, 2}) {
-    if (k == 4 && tb.witness_only) continue; // (a re-build for another witness density: row 0 of the current tables is the source)
-    if (!ok || tb.cancel.load()) {
-      ok = false;
-      break;
+  // (a narrowed first build that fails — out of memory after all — is tried once more with the dense geometry the key was admitted with)
+  for (int attempt = 0; attempt < 2; attempt++) {
+    for (int k : {4, 0, 1, 3, 2}) {
+      if (k == 4 && tb.witness_only) continue; // (a re-build for another witness density: row 0 of the current tables is the source)
+      if (k == 4 && tb.fresh[4]) continue;     // (second attempt: H's table is there already)
+      if (!ok || tb.cancel.load()) {
+        ok = false;
+        break;
+      }
+      const Job& j = jobs[k];
+      // the bases are in the internal encoding already (form 2); the proves of the key only read them
+      const eIcicleError e = j.g2 ? msm_g2_build_table_sliced(j.sh->d_points, j.sh->len(), 2, *j.g, s, &tb.fresh[k], &tb.cancel)
+                                  : msm_g1_build_table_sliced(j.sh->d_points, j.sh->len(), 2, *j.g, s, &tb.fresh[k], &tb.cancel);
+      if (e != ICICLE_SUCCESS) {
+        (void)hipGetLastError();
+        ok = false;
+        if (getenv("ICICLE_SNARK_VERBOSE") && !tb.cancel.load()) fprintf(stderr, "[icicle-snark-hip] deferred tables: build failed (%s)%s\n", icicle_snark_last_error(), narrowed && attempt == 0 ? "; retrying with the dense digit width" : "; the key keeps the classic layout");
+      }
     }
-    const Job& j = jobs[k];
-    // the bases are in the internal encoding already (form 2); the proves of the key only read them
-    const eIcicleError e = j.g2 ? msm_g2_build_table_sliced(j.sh->d_points, j.sh->len(), 2, *j.g, s, &tb.fresh[k], &tb.cancel)
-                                : msm_g1_build_table_sliced(j.sh->d_points, j.sh->len(), 2, *j.g, s, &tb.fresh[k], &tb.cancel);
-    if (e != ICICLE_SUCCESS) {
-      (void)hipGetLastError();
-      ok = false;
-      if (getenv("ICICLE_SNARK_VERBOSE") && !tb.cancel.load()) fprintf(stderr, "[icicle-snark-hip] deferred tables: build failed (%s); the key keeps the classic layout\n", icicle_snark_last_error());
+    if (ok || !narrowed || attempt == 1 || tb.cancel.load() || !s) break;
+    for (int k : {0, 1, 2, 3}) {
+      if (tb.fresh[k]) (void)hipFree(tb.fresh[k]);
+      tb.fresh[k] = nullptr;
     }
+    tb.gw = gw_dense;
+    tb.extra_bytes.store(0, std::memory_order_release);
+    ok = true;
   }
   if (s) (void)hipStreamDestroy(s);
   if (!ok)
@@ -208,6 +237,7 @@ int adopt_tables(ZKeyCache* z, bool wait)
   // built, an abandoned build (st == 3) has added nothing
   z->device_bytes -= tb.pending_bytes;
   tb.pending_bytes = 0;
+  tb.extra_bytes.store(0, std::memory_order_release); // (device_bytes is exact again)
   tb.witness_only = false;
   tb.state.store(0, std::memory_order_release);
   return 1;
@@ -633,7 +663,11 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
     try {
       out->tb.th = std::thread(table_build_thread, out.get());
     } catch (...) {
-      out->tb.state.store(0); // no thread to be had: the key keeps the classic layout
+      // no thread to be had: the key keeps the classic layout — and gives back what was counted for tables that will not come
+      out->tb.state.store(0);
+      out->device_bytes -= out->tb.pending_bytes;
+      out->tb.pending_bytes = 0;
+      out->tb.hold.store(false, std::memory_order_release);
     }
   }
   return 0;

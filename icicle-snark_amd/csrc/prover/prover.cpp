@@ -17,6 +17,7 @@
 //    so cache construction needs no conversion pass over ~1 GB of points;
 //  * the NTT domain is sized 2·domain_size so that the coset keys g^i (g = ω_2n, src/cache.rs:183-184,
 //    264-289) are read from the twiddle table instead of a separate array + CWD file cache.
+#include <climits>
 #include <algorithm>
 #include <fcntl.h>
 #include <errno.h>
@@ -104,7 +105,7 @@ void evict_for_budget(Groth16CacheManager* cm, int device, uint64_t need)
       auto lru = cm->cache.end();
       for (auto it = cm->cache.begin(); it != cm->cache.end(); ++it) {
         if (it->second->device_id != device) continue;
-        used += it->second->device_bytes;
+        used += it->second->device_bytes + it->second->tb.extra_bytes.load(std::memory_order_relaxed); // (+ what a narrower first table build takes beyond its estimate)
         if (lru == cm->cache.end() || it->second->last_use < lru->second->last_use) lru = it;
       }
       if (used + need <= cm->budget_bytes || lru == cm->cache.end()) return;
@@ -113,6 +114,18 @@ void evict_for_budget(Groth16CacheManager* cm, int device, uint64_t need)
     }
     victim.reset(); // frees the device memory (outside the map lock)
   }
+}
+
+// bytes the budget of `device` has left once every cached key's device_bytes is counted (no budget: no limit) — what a first table
+// build that wants more rows than the key was admitted with may take (cache.cpp: table_build_thread).  Caller holds cm->mu.
+uint64_t budget_room(Groth16CacheManager* cm, int device)
+{
+  if (!cm->budget_bytes) return UINT64_MAX;
+  std::lock_guard<std::mutex> lk(cm->map_mu);
+  uint64_t used = 0;
+  for (auto& kv : cm->cache)
+    if (kv.second->device_id == device) used += kv.second->device_bytes + kv.second->tb.extra_bytes.load(std::memory_order_relaxed);
+  return cm->budget_bytes > used ? cm->budget_bytes - used : 0;
 }
 
 } // namespace prover
@@ -220,9 +233,13 @@ __attribute__((visibility("default"))) int groth16_cache_load(Groth16CacheManage
   const int brc = build_cache((const uint8_t*)zkey, zkey_len, device_id, shard_rank, shard_count, z, /*defer_tables=*/true);
   if (dom_th.joinable()) dom_th.join();
   if (brc) return brc;
-  std::lock_guard<std::mutex> lm(cm->map_mu);
-  z->last_use = ++cm->clock;
-  cm->cache[key] = std::shared_ptr<ZKeyCache>(z.release());
+  std::shared_ptr<ZKeyCache> zp(z.release());
+  {
+    std::lock_guard<std::mutex> lm(cm->map_mu);
+    zp->last_use = ++cm->clock;
+    cm->cache[key] = zp;
+  }
+  zp->tb.narrow_room.store(budget_room(cm, device_id), std::memory_order_release);
   return 0;
 }
 
@@ -313,11 +330,16 @@ __attribute__((visibility("default"))) int groth16_cache_tables_ready(Groth16Cac
   if (!zp) return fail(ERR_NOCACHE, "no cache entry '%s'", key ? key : "");
   if (zp->tb.state.load(std::memory_order_acquire) == 0) return 1;
   if (!wait && zp->tb.state.load(std::memory_order_acquire) == 1) return 0;
-  if (wait) zp->tb.go.store(true, std::memory_order_release); // somebody waits for the tables: no point in the build waiting for a first prove
+  if (wait) {
+    zp->tb.go.store(true, std::memory_order_release); // somebody waits for the tables: no point in the build waiting for a first prove
+    // wait for the build OUTSIDE the manager's mutex (0.26–1 s: every prove of every other key would queue behind it otherwise;
+    // round-5 advisor) — the mutex is only taken for the pointer swap below
+    while (zp->tb.state.load(std::memory_order_acquire) == 1) std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
   std::lock_guard<std::mutex> lk(cm->mu);
   int prev = -1;
   (void)hipGetDevice(&prev);
-  if (int rc = set_active_device(zp->device_id)) return rc;
+  if (int rc = set_active_device(zp->device_id)) return rc > 0 ? fail(ERR_ARG, "device %d of the key cannot be made active (icicle error %d)", zp->device_id, rc) : rc; // (1 means "ready" here)
   const int r = adopt_tables(zp.get(), wait != 0);
   if (prev >= 0) (void)set_active_device(prev);
   return r;
@@ -1172,26 +1194,29 @@ static int write_json_pair(const char* proof_path, const char* proof_text, const
 // upload and first proof overlap.  Returns 1 when the pipeline does not apply (the caller then loads and proves as before: a witness
 // that does not fit the key is diagnosed there), 0 on success with the JSON texts filled, an error code otherwise (the key is evicted
 // again when its upload failed).
+// returns COLD_DECLINED when the pipeline does not apply (the caller then loads and proves one after the other) — a value no
+// eIcicleError (≥ 0) and no ERR_* code of this library (small negatives) can take (round-5 advisor: `1` is ICICLE_INVALID_DEVICE)
+static constexpr int COLD_DECLINED = INT_MIN;
 static int cold_prove(Groth16CacheManager* cm, const std::string& key, const MappedFile& zf, const MappedFile& wf, int device_id, std::vector<char>& pj, std::vector<char>& qj)
 {
   const bool off = getenv("ICICLE_SNARK_COLD_PIPELINE") && atoi(getenv("ICICLE_SNARK_COLD_PIPELINE")) == 0; // read per call: tests toggle it
-  if (off) return 1;
+  if (off) return COLD_DECLINED;
   // the witness must fit the key BEFORE anything of it is sent: n_vars of the header (src/zkey.rs:47-85) against the .wtns header
   Wtns w;
-  if (parse_wtns(wf.data, wf.len, w)) return 1;
+  if (parse_wtns(wf.data, wf.len, w)) return COLD_DECLINED;
   uint32_t n_vars = 0, dom_n = 0, n_public = 0;
   {
     std::vector<Section> secs;
     const Section* s2 = nullptr;
-    if (read_sections(zf.data, zf.len, "zkey", 2, secs) != 0 || unique_section(secs, 2, &s2) != 0 || s2->size < 84) return 1;
+    if (read_sections(zf.data, zf.len, "zkey", 2, secs) != 0 || unique_section(secs, 2, &s2) != 0 || s2->size < 84) return COLD_DECLINED;
     memcpy(&n_vars, s2->p + 72, 4);
     memcpy(&n_public, s2->p + 76, 4);
     memcpy(&dom_n, s2->p + 80, 4);
-    if (w.n_witness != n_vars || dom_n == 0 || (dom_n & (dom_n - 1)) || dom_n > (1u << 27) || memcmp(w.q.l, s2->p + 40, 32) != 0) return 1;
+    if (w.n_witness != n_vars || dom_n == 0 || (dom_n & (dom_n - 1)) || dom_n > (1u << 27) || memcmp(w.q.l, s2->p + 40, 32) != 0) return COLD_DECLINED;
   }
   const auto t0 = std::chrono::steady_clock::now();
   std::unique_lock<std::mutex> lk(cm->mu);
-  if (find(cm, key.c_str()) || find_group(cm, key.c_str())) return 1; // (somebody else loaded it meanwhile)
+  if (find(cm, key.c_str()) || find_group(cm, key.c_str())) return COLD_DECLINED; // (somebody else loaded it meanwhile)
   if (cm->warm.joinable()) cm->warm.join();
   evict_for_budget(cm, device_id, (uint64_t)zf.len * 11);
   std::thread dom_th; // the NTT domain of the key, set up while the sections cross PCIe (as in groth16_cache_load)
@@ -1220,6 +1245,7 @@ static int cold_prove(Groth16CacheManager* cm, const std::string& key, const Map
     zp->last_use = ++cm->clock;
     cm->cache[key] = zp;
   }
+  zp->tb.narrow_room.store(budget_room(cm, device_id), std::memory_order_release);
   ZKeyCache* z = zp.get();
   const bool piped = z->feed != nullptr;
   // from here on as groth16_prove_resident, under the manager's mutex throughout
@@ -1291,8 +1317,8 @@ __attribute__((visibility("default"))) int groth16_prove(const char* witness_pat
       }
       return 0;
     }
-    if (crc != 1) return crc;
-    // (1: the pipeline does not apply — load and prove one after the other, below)
+    if (crc != COLD_DECLINED) return crc;
+    // (declined: the pipeline does not apply — load and prove one after the other, below)
   }
   if (!groth16_cache_contains(cm, key.c_str())) {
     if (devs.size() == 1) {

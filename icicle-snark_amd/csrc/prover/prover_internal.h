@@ -102,6 +102,11 @@ struct TableBuild {
   MsmGeom gw, gh;            // the table geometries the build works towards
   int dense_c = 0;           // digit width of the dense witness geometry (gw may be narrower: the first prove's witness was light)
   uint64_t pending_bytes = 0; // table bytes already counted in the entry's device_bytes while the first build is under way
+  // A first build that takes a NARROWER witness digit than the dense one pending_bytes was sized for (more table rows) asks here:
+  // `narrow_room` = bytes beyond pending_bytes it may take (set by whoever admitted the key: what the cache budget has left, or no
+  // limit), `extra_bytes` = what it took (counted by evict_for_budget until adopt_tables has corrected device_bytes)
+  std::atomic<uint64_t> narrow_room{0};
+  std::atomic<uint64_t> extra_bytes{0};
   bool witness_only = false; // a re-build of the four witness tables with another digit width (the key follows its witnesses): H stays
   double build_ms = 0;       // wall clock of the build (beside whatever proves ran meanwhile)
 };
@@ -257,6 +262,7 @@ int set_active_device(int device_id);
 int ensure_domain(Groth16CacheManager* cm, const ZKeyCache* z); // works on the calling thread's active device (= z->device_id)
 int ensure_domain_for(Groth16CacheManager* cm, int device_id, uint32_t domain_size);
 void evict_for_budget(Groth16CacheManager* cm, int device, uint64_t need);
+uint64_t budget_room(Groth16CacheManager* cm, int device);
 // the shard pipeline of one device; caller holds cm->mu.  wtns == NULL: the witness (and, with z->dist_ready, the Z rows) are resident
 int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, size_t wtns_len, uint8_t* out_points, Groth16Timings* tm, EarlyTerms* et);
 // distributed front end, stages without the host synchronisation of the C API (the exchange is enqueued on z->s_qap)

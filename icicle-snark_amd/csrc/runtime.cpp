@@ -559,8 +559,14 @@ void base_table_unpin(uint64_t id, hipStream_t s)
   std::lock_guard<std::mutex> lk(g_bt_mu);
   for (BaseTable& t : g_bt)
     if (t.id == id) {
-      // the call's last kernel is enqueued: whoever refreshes the table from another stream orders itself behind this point
-      if (t.table && (t.used || hipEventCreateWithFlags(&t.used, hipEventDisableTiming) == hipSuccess)) (void)hipEventRecord(t.used, s);
+      // the call's last kernel is enqueued: whoever refreshes the table from another stream orders itself behind this point.  The
+      // marks CHAIN: the unpinning stream first waits for the previous mark (another caller's stream, perhaps still reading the
+      // table), so the one event a refresher waits for is behind the kernels of every stream that used the table, not just
+      // behind those of the last one to unpin (round-5 advisor: two concurrent callers)
+      if (t.table) {
+        if (t.used) (void)hipStreamWaitEvent(s, t.used, 0);
+        if (t.used || hipEventCreateWithFlags(&t.used, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(t.used, s);
+      }
       (void)hipGetLastError();
       if (t.pins > 0) t.pins--;
       return;

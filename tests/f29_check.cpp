@@ -41,6 +41,10 @@ extern "C" int f29_check_field(const fe* v, int n)
     // lazy squares at the stated input bound (<5p, N)
     const fe9 w = f29::norm(f29::sub<3, 1>(a9, b9));
     if (!same(f29::to_mont256(f29::sqr(w)), Fq::sqr(Fq::sub(am, bm)))) return bad("sqr of a lazy difference");
+    if (i % 64 == 0 && !same(f29::to_mont256(f29::inv(a9)), Fq::inv(am))) return bad("inv");
+    if (!same(f29::to_mont256(f29::inv_ds(a9)), Fq::inv(am))) return bad("inv_ds");
+    if (!same(f29::to_mont256(f29::inv_ds(f29::norm(f29::add(a9, f29::mul(b9, f29::one_m()))))), Fq::inv(Fq::add(am, bm)))) return bad("inv_ds of a lazy sum");
+    if (!same(f29::pack(f29::unpack(f29::pack(f29::mul(a9, b9)))), f29::pack(f29::mul(a9, b9)))) return bad("pack of a lazy (<2p) value");
     const bool z = f29::maybe_zero_mod_p(f29::norm(f29::sub<3, 1>(a9, a9)));
     if (!z || !f29::is_zero_canon(f29::canon(f29::norm(f29::sub<3, 1>(a9, a9))))) return bad("zero test");
     if (f29::g_check_failure) return 2;
