@@ -173,6 +173,10 @@ BaseTableState base_table_lookup(const void* bases, size_t bytes, uint32_t n, bo
 void base_table_publish(const void* bases, uint32_t n, bool g2, int form, void* table, size_t table_bytes, const MsmGeom& g, unsigned long long* sums, hipStream_t s, BaseTableRef* ref);
 void base_table_unpin(uint64_t id, hipStream_t s); // s: the stream the call's kernels went to (its last-use mark is recorded there)
 
+// exclusive prefix sum of m 32-bit counters on stream s (msm_sort.hip's three scan kernels); bsum: ≥ exclusive_scan_u32_scratch_words(m) words
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t m, uint32_t* out, uint32_t* bsum, hipStream_t s);
+size_t exclusive_scan_u32_scratch_words(uint32_t m);
+
 bool ext_get_int(const ConfigExtension* ext, const char* key, int* out);
 bool ext_get_bool(const ConfigExtension* ext, const char* key, bool* out);
 

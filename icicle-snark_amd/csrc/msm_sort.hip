@@ -1215,6 +1215,20 @@ void msm_sort_release(SortPlan* pl)
 }
 SortPlan::~SortPlan() { msm_sort_release(this); }
 
+// exclusive prefix sum of m 32-bit counters on stream s (the three kernels above: sums of 2048-counter blocks, their scan by one
+// workgroup, the finish): out[i] = Σ_{j<i} in[j].  `bsum`: scratch of ⌈m / 2048⌉ words.  In place (out == in) is fine.  Used by the
+// cache build's CSR (prover/csr.hip) as well — no third-party device code on any path of this library.
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t m, uint32_t* out, uint32_t* bsum, hipStream_t s)
+{
+  if (!m) return hipSuccess;
+  const uint32_t nblocks = (m + SCAN_B - 1) / SCAN_B;
+  hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, in, m, bsum);
+  hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nblocks);
+  hipLaunchKernelGGL(msm_scan_apply_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, in, m, bsum, out);
+  return hipGetLastError();
+}
+size_t exclusive_scan_u32_scratch_words(uint32_t m) { return (m + SCAN_B - 1) / SCAN_B + 1; }
+
 } // namespace isnark
 
 // Profile of the `back`-th most recent MSM (0 = latest) issued by this process.  The caller must have

@@ -1,11 +1,10 @@
 // csr.hip — cold path: zkey section 4 (coefficients) → device CSR, built on the device (see qap.h).
 // Replaces the host loops of CacheManager::compute (src/cache.rs:126-166: parse, :214 from_mont) and the
 // per-prove serial scatter-add they feed (src/proof_helper.rs:81-92).  The raw 44-byte records are uploaded
-// once; three streaming kernels (count → exclusive scan → scatter with the Montgomery conversion fused)
+// once; streaming kernels (count → exclusive scan, msm_sort.hip's → scatter with the Montgomery conversion fused)
 // produce rowptr/cols/vals.  Entries of one row land in arbitrary order — the row sum is exact field
 // arithmetic, so the order is immaterial.
-#include <hipcub/hipcub.hpp>
-
+#include "../msm_plan.h"
 #include "qap.h"
 
 using namespace bn254;
@@ -61,13 +60,11 @@ hipError_t qap_build_csr(const uint32_t* d_records, uint32_t n_coef, uint32_t n,
 {
   *first_bad = 0xffffffffu;
   const size_t rows = 2 * (size_t)n + 1;
-  uint32_t *counts = nullptr, *err = nullptr;
-  void* tmp = nullptr;
-  size_t tmp_bytes = 0;
-  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, counts, d_rowptr, (int)rows, s);
-  if (e != hipSuccess) return e;
+  uint32_t *counts = nullptr, *err = nullptr, *tmp = nullptr;
+  hipError_t e;
+  if (rows >= (1ull << 32)) return hipErrorInvalidValue;
   if ((e = hipMalloc((void**)&counts, (rows + 1) * 4)) != hipSuccess) return e;
-  if ((e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 4)) != hipSuccess) {
+  if ((e = hipMalloc((void**)&tmp, exclusive_scan_u32_scratch_words((uint32_t)rows) * 4)) != hipSuccess) {
     (void)hipFree(counts);
     return e;
   }
@@ -75,7 +72,7 @@ hipError_t qap_build_csr(const uint32_t* d_records, uint32_t n_coef, uint32_t n,
   hipLaunchKernelGGL(csr_fill_kernel, dim3(1024), dim3(256), 0, s, counts, rows, 0u);
   hipLaunchKernelGGL(csr_fill_kernel, dim3(1), dim3(1), 0, s, err, (size_t)1, 0xffffffffu);
   if (n_coef) hipLaunchKernelGGL(csr_count_kernel, dim3((n_coef + 255) / 256), dim3(256), 0, s, d_records, n_coef, n, n_vars, counts, err);
-  e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, counts, d_rowptr, (int)rows, s);
+  e = exclusive_scan_u32(counts, (uint32_t)rows, d_rowptr, tmp, s); // (msm_sort.hip: this library's own scan kernels)
   if (e == hipSuccess) e = hipMemcpyAsync(first_bad, err, 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e == hipSuccess && *first_bad == 0xffffffffu && n_coef) {
