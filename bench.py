@@ -915,18 +915,58 @@ def main():
         cold["prove_ms_beside_table_build"] = sorted(during)[len(during) // 2] if during else None
         if not standin:
             assert json.loads(cold_public) == [str(pow(3, 1 << N, S.R_MOD))]
-        cm.evict(key)
-        t0 = time.perf_counter()
-        cm.prove_files(wtns_path, zkey_path, proof_path, public_path)
-        cold["cold_prove_ms_files_process_warm"] = (time.perf_counter() - t0) * 1e3
+        # (c) evict-and-prove cycles, process warm (round-5 verdict item 3: min / median / max instead of one sample): the key evicted
+        # with its tables and proved from the file again; every cycle also times its proves beside the table build, the time until the
+        # tables are adopted and the first proves ON the adopted tables (against the warm median of this box)
+        cyc = {"cold_prove_ms": [], "tables_adopted_after_ms": [], "prove_ms_beside_table_build": [], "first_prove_on_tables_ms": [], "warm_prove_ms": []}
+        for _ in range(5):
+            cm.evict(key)
+            t0 = time.perf_counter()
+            cm.prove_files(wtns_path, zkey_path, proof_path, public_path)
+            cyc["cold_prove_ms"].append((time.perf_counter() - t0) * 1e3)
+            during2, t0 = [], time.perf_counter()
+            while not cm.tables_ready(key):
+                t1 = time.perf_counter()
+                cm.prove_files(wtns_path, zkey_path, proof_path, public_path)
+                during2.append((time.perf_counter() - t1) * 1e3)
+            cyc["tables_adopted_after_ms"].append((time.perf_counter() - t0) * 1e3)
+            if during2:
+                cyc["prove_ms_beside_table_build"].append(sorted(during2)[len(during2) // 2])
+            after = []
+            for _ in range(6):
+                t1 = time.perf_counter()
+                cm.prove_files(wtns_path, zkey_path, proof_path, public_path)
+                after.append((time.perf_counter() - t1) * 1e3)
+            cyc["first_prove_on_tables_ms"].append(after[0])
+            cyc["warm_prove_ms"].append(sorted(after[1:])[2])
+
+        def mmm(v):
+            v = sorted(v)
+            return {"min": round(v[0], 2), "median": round(v[len(v) // 2], 2), "max": round(v[-1], 2)} if v else None
+        cold["cycles"] = {k: mmm(v) for k, v in cyc.items()}
+        cold["cycles"]["n"] = 5
+        cold["cold_prove_ms_files_process_warm"] = cold["cycles"]["cold_prove_ms"]["median"]
         cm.tables_ready(key, wait=True)
         cm.evict(key)
         # (d) the cache alone: until the key can prove, then until its tables are there with nothing running beside the build
-        t0 = time.perf_counter()
-        cm.load(key, zkey, device_id=local_rank, wait_tables=False)
-        cold_ms = (time.perf_counter() - t0) * 1e3
-        cm.tables_ready(key, wait=True)
-        cold["cold_tables_build_ms"] = (time.perf_counter() - t0) * 1e3 - cold_ms
+        # (three times: the build is enqueued by a host thread, and a host whose CPU quota is taken stretches it — 240 → 507 / 900 ms
+        # beside 32 / 64 busy processes, profiles/r06_cold_path_outliers.txt; the load average of the moment is printed beside it)
+        builds = []
+        for rep in range(3):
+            if rep:
+                cm.evict(key)
+            t0 = time.perf_counter()
+            cm.load(key, zkey, device_id=local_rank, wait_tables=False)
+            cold_ms = (time.perf_counter() - t0) * 1e3
+            cm.tables_ready(key, wait=True)
+            builds.append((time.perf_counter() - t0) * 1e3 - cold_ms)
+        cold["cold_tables_build_ms"] = sorted(builds)[1]
+        cold["cold_tables_build_ms_min_max"] = [round(min(builds), 1), round(max(builds), 1)]
+        try:
+            cold["host_loadavg_1m"] = round(os.getloadavg()[0], 2)
+            cold["host_cpus_usable"] = len(os.sched_getaffinity(0))
+        except OSError:
+            pass
         cold["note"] = ("cold_prove_ms_files: groth16_prove(witness.wtns, circuit.zkey, proof.json, public.json) with nothing cached (zkey in the page cache; upload and first "
                         "proof overlap), first key of the process / again after an evict; cold_cache_build_ms: groth16_cache_load until the key can prove (classic layout); cold_tables_build_ms: "
                         "the deferred fixed-base tables built alone; prove_ms_beside_table_build: median file-to-file prove while the worker builds them")

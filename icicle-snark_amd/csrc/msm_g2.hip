@@ -21,7 +21,7 @@ eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form,
 }
 eIcicleError msm_g2_build_table_sliced(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table, const std::atomic<bool>* cancel)
 {
-  return build_table_sliced_run<G2, Fq2Ops>(d_points, n, from_form, g, s, d_table, 1u << 16, cancel);
+  return build_table_sliced_run<G2, Fq2Ops>(d_points, n, from_form, g, s, d_table, table_slice_bases(), cancel);
 }
 void msm_g2_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_g2_projective_t* out)
 {

@@ -485,6 +485,21 @@ __global__ __launch_bounds__(256) void fixed_base_mul_kernel(const fe* __restric
   out[i] = C::x_to_projective(acc); // Montgomery projective; normalised by the batch-affine kernels below
 }
 
+// the one inversion of a chunk: 600 divsteps on the lazy field (ff29.h: inv_ds, ≈ 14 k instructions) instead of ff.h's Fermat ladder
+// (≈ 100 k instructions on ONE lane: 0.25 ms of latency per launch of the sliced table build, a fifth of its length).  Montgomery-256
+// in and out, 0 ↦ 0 like Fq::inv.
+__device__ __forceinline__ fe fq_inv_fast(const fe& a) { return f29::to_mont256(f29::inv_ds(f29::from_mont256(a))); }
+template <class F> struct FastInv;
+template <> struct FastInv<FqOps> {
+  static __device__ __forceinline__ fe inv(const fe& a) { return fq_inv_fast(a); }
+};
+template <> struct FastInv<Fq2Ops> {
+  static __device__ __forceinline__ fe2 inv(const fe2& a)
+  {
+    const fe d = fq_inv_fast(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
+    return {Fq::mul(a.c0, d), Fq::neg(Fq::mul(a.c1, d))};
+  }
+};
 // batched projective → affine (standard form) with one inversion per thread-chunk (Montgomery trick)
 template <class C, class F>
 __global__ __launch_bounds__(64) void batch_to_affine_kernel(const typename C::P* __restrict__ in, uint64_t n, int chunk, typename C::A* __restrict__ out, typename F::T* __restrict__ scratch)
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(64) void batch_to_affine_kernel(const typename C::P
     T z = in[i].z;
     if (!F::is_zero(z)) run = F::mul(run, z);
   }
-  T inv = F::inv(run);
+  T inv = FastInv<F>::inv(run);
   for (uint64_t i = hi; i-- > lo;) {
     T z = in[i].z;
     typename C::A a;
@@ -721,21 +736,24 @@ eIcicleError build_table_sliced_run(const void* d_points, uint32_t n, int from_f
     return ICICLE_ALLOCATION_FAILED;
   }
   const int chunk = 32;
-  // one slice in flight and one queued: the stream never runs dry and the host is never far ahead of a cancel
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  (void)hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+  // up to DEPTH slices enqueued ahead of the one that runs (the temporaries are reused in stream order): the stream does not run
+  // dry when this thread is descheduled — with one slice in flight and one queued (rounds 4–5) a host whose CPU quota was taken by
+  // other work doubled and quadrupled the build (profiles/r06_cold_path_outliers.txt: 240 → 507 / 900–980 ms beside 32 / 64 busy
+  // processes) — and the host is still no more than DEPTH slices (≈ 10 ms) ahead of a cancel
+  constexpr int DEPTH = 8;
+  hipEvent_t ev[DEPTH] = {};
+  for (int q = 0; q < DEPTH; q++) (void)hipEventCreateWithFlags(&ev[q], hipEventDisableTiming);
   struct EvGuard {
     hipEvent_t* e;
     ~EvGuard()
     {
-      for (int k = 0; k < 2; k++)
-        if (e[k]) (void)hipEventDestroy(e[k]);
+      for (int q = 0; q < DEPTH; q++)
+        if (e[q]) (void)hipEventDestroy(e[q]);
     }
   } ev_guard{ev};
   uint32_t k = 0;
   for (uint32_t lo = 0; lo < n; lo += slice, k++) {
-    if (k >= 2 && ev[k & 1]) (void)hipEventSynchronize(ev[k & 1]); // slice k − 2 is done
+    if (k >= (uint32_t)DEPTH && ev[k % DEPTH]) (void)hipEventSynchronize(ev[k % DEPTH]); // slice k − DEPTH is done
     if (cancel && cancel->load(std::memory_order_relaxed)) {
       cleanup(true);
       return ICICLE_UNKNOWN_ERROR;
@@ -750,7 +768,7 @@ eIcicleError build_table_sliced_run(const void* d_points, uint32_t n, int from_f
       cleanup(true);
       return e;
     }
-    if (ev[k & 1]) (void)hipEventRecord(ev[k & 1], s);
+    if (ev[k % DEPTH]) (void)hipEventRecord(ev[k % DEPTH], s);
   }
   const hipError_t he = hipStreamSynchronize(s);
   cleanup(he != hipSuccess);

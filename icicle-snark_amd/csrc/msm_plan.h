@@ -112,6 +112,12 @@ eIcicleError msm_g2_build_table(const void* d_points, uint32_t n, int from_form,
 // The same table built in slices of the base array (temporaries of a slice's size, no launch larger than the device holds at a
 // time, `cancel` polled between slices): the deferred build of a cached key's tables on a low-priority stream beside the
 // proves that already use the key (prover/cache.cpp).  Returns with stream s synchronised.
+// bases per slice of the sliced build (ICICLE_SNARK_TABLE_SLICE_LOG overrides the default of 2^18 for G2, twice that for G1)
+inline uint32_t table_slice_bases()
+{
+  static const int lg = getenv("ICICLE_SNARK_TABLE_SLICE_LOG") ? atoi(getenv("ICICLE_SNARK_TABLE_SLICE_LOG")) : 18;
+  return 1u << (lg < 12 ? 12 : lg > 22 ? 22 : lg);
+}
 eIcicleError msm_g1_build_table_sliced(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table, const std::atomic<bool>* cancel);
 eIcicleError msm_g2_build_table_sliced(const void* d_points, uint32_t n, int from_form, const MsmGeom& g, hipStream_t s, void** d_table, const std::atomic<bool>* cancel);
 // table mode: h_partials = [T | S_0 … S_{nbits−1}] (msm_partials_bytes gives nbits as *W)

@@ -19,14 +19,18 @@ for G in (1, 2, 4, 8):
     p, _, _ = cm.prove_mem(key, wtns, 3, 4)
     want = want or p
     assert p == want
-    res, host = [], []
-    for _ in range(12):
+    # (round 6: ten warm-up proves, then the two series INTERLEAVED — round 5 timed twelve resident proves right after the load and the
+    #  host-witness ones behind them, and at eight shards the first ones after a load are slow: "resident 28.5 / host 25.0" was that order)
+    res, host, first = [], [], []
+    for i in range(10):
+        t = time.perf_counter(); cm.prove_mem(key, wtns, 3, 4, resident=i % 2 == 1); first.append((time.perf_counter() - t) * 1e3)
+    for _ in range(10):
         t = time.perf_counter(); cm.prove_mem(key, wtns, 3, 4, resident=True); res.append((time.perf_counter() - t) * 1e3)
-    for _ in range(8):
         t = time.perf_counter(); cm.prove_mem(key, wtns, 3, 4); host.append((time.perf_counter() - t) * 1e3)
     res.sort(); host.sort()
+    print(f"   first ten proves after the load: {' '.join(f'{x:.1f}' for x in first)}")
     tm = cm.last_timings(key)
-    print(f"benchmark/{N}: {G} shard(s) on ONE GPU: cache build {cold:.0f} ms, {cm.info(key).device_bytes / 1e6:.0f} MB | prove resident median {res[len(res) // 2]:.2f} ms, host witness median {host[len(host) // 2]:.2f} ms "
+    print(f"benchmark/{N}: {G} shard(s) on ONE GPU: cache build {cold:.0f} ms, {cm.info(key).device_bytes / 1e6:.0f} MB | prove resident median {res[len(res) // 2]:.2f} (min {res[0]:.2f}) ms, host witness median {host[len(host) // 2]:.2f} (min {host[0]:.2f}) ms "
           f"(slowest shard: upload {tm.h2d_ms:.2f}, qap {tm.qap_ms:.2f}, msm {tm.msm_ms:.2f})")
     cm.evict(key)
 cm.close()
