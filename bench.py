@@ -594,7 +594,7 @@ def roofline_block(g, kern_ms, pmc, pmc_note, hbm_copy_gbps, mad_tops):
                     # issues when every one is priced at 4 cycles (the multiplier instructions are; 2-operand 32-bit ones take 2)
                     "valu_issue_util_at_4_cycles": iv * 4 / (1024 * ga / 8),
                     "source": "rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE child pass of this run (kernels serialised by the profiler)"}
-    # algorithmic bytes of one bucket-accumulation launch: per non-zero digit one 4-B
+    # algorithmic bytes of one bucket-accumulation launch (HISTORY.md §kernels): per non-zero digit one 4-B
     # sorted index + one 64-B affine base gathered; per bucket 8 B of (offset,count) + a 128-B XYZZ result
     alg_bytes = g["L"] * g["W"] * (4 + 64) + g["nbuckets"] * (8 + 128)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -1053,7 +1053,7 @@ def main():
     host_ms = resident_ms = None
     if world == 1:
         # a key whose witness carries few non-zero digits (the stand-ins) gets narrower digits for its four witness tables after its
-        # first prove on the tables — built by a worker beside later proves: warm means that build is over
+        # first prove on the tables — built by a worker beside later proves (HISTORY.md §9-2a): warm means that build is over
         cm.prove_mem(key, wtns)
         cm.tables_ready(key, wait=True)
 

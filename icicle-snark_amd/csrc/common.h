@@ -206,7 +206,7 @@ private:
 // that safe without any synchronisation); blocks are returned to the driver when their stream is
 // destroyed or the library unloads.  hipMallocAsync's stream-ordered pool is deliberately not used:
 // on this ROCm stack recycled pool blocks were observed to be handed out while earlier kernels on
-// the stream were still using them (nondeterministic MSM results; see DESIGN.md "Workspace arena").
+// the stream were still using them (nondeterministic MSM results; see DESIGN.md §1 "workspace arena").
 hipError_t ws_alloc(void** p, size_t bytes, hipStream_t s);
 hipError_t ws_free(void* p, hipStream_t s);
 void ws_release_stream(hipStream_t s); // caller has synchronised the stream

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const typename C
 // The reference halves the bucket count per launch and doubles the window count (cuda_msm.cuh:821-956: log c launches of
 // dependent additions); the three table-mode reductions this replaces (per-thread triangle sums, suffix scans for small
 // sets, row / column sums) had chains of 56, 34 and 26 additions.  Measured on MI355X, G1 / G2 set of 2^19 buckets alone:
-// see DESIGN.md §3.2-5.
+// see HISTORY.md §3.2-5.
 constexpr int ZR_LOG = 8, ZR_M = 1 << ZR_LOG, ZR_T = ZR_M / 2, ZR_OUT = ZR_LOG + 1;
 
 // in: `gridDim.y` rows of n entries (internal encoding; entries ≥ n count as the identity), row r at in + r·n.

@@ -116,7 +116,7 @@ void table_build_thread(ZKeyCache* z)
   const auto t0 = std::chrono::steady_clock::now();
   bool ok = hipSetDevice(z->device_id) == hipSuccess;
   // The key's first prove (classic layout) has counted the non-zero digits of its witness: a witness of 0 / 1 wires and small values
-  // wants narrower digits than the dense default (witness_digit_target) — build the four witness tables with that width
+  // wants narrower digits than the dense default (witness_digit_target; HISTORY.md §9-2a) — build the four witness tables with that width
   // at once instead of building the dense ones and rebuilding them INSIDE a later prove (0.1–0.3 s).  The classic count (16-bit digits)
   // is an upper bound of the table-mode one, so the width chosen here is the rule's or one bit above it; the rule keeps following the
   // witnesses afterwards.  (witness_entries was written before `go` was released.)
@@ -677,7 +677,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
 // The tables fix the digit width c at cache build for DENSE scalars: c = 20 at a million wires, 2^19 buckets per MSM, whose
 // reduction is 1 M point additions per MSM whatever the witness.  Witnesses of real circuits are mostly 0/1 wires and small values:
 // a tenth to a fifth of the non-zero digits of a dense witness, so the four witness MSMs (A, B1, B2, C) spend more in reducing
-// empty-ish buckets than in filling them — the G2 reduction heads the critical chain.  After a prove the
+// empty-ish buckets than in filling them — the G2 reduction heads the critical chain (HISTORY.md §9-2a).  After a prove the
 // entry count of the witness digit sort is known; if it calls for a digit at least two bits narrower (target ≈ 32 entries per
 // bucket), the four tables are rebuilt from their own row 0 with that width — once, ≈ 0.1–0.3 s, like a cache build — and the
 // next proves sort with it and size the large-bucket threshold from the observed count.  Measured on the stand-in keys of

@@ -1,7 +1,7 @@
 // multi.cpp — one Groth16 prove over a GROUP of devices inside ONE process: what groth16_prove() does for a device string
 // such as "HIP:0-7" (the reference's entry point takes a device type and uses id 0: src/lib.rs:25-61, src/main.rs:46-70).
 //
-// Partition: shard r of G holds the point range r of the A, B1, B2, C bases, the residue class
+// Partition (HISTORY.md §5): shard r of G holds the point range r of the A, B1, B2, C bases, the residue class
 // k ≡ r (mod G) of the H bases and computes 1/G of the QAP front end.  One host thread per shard enqueues that shard's
 // whole pipeline on its own device; the shards meet in three device-side exchanges and once on the host:
 //   1. witness       every shard uploads 1/G over PCIe; an in-place all-gather over xGMI completes the buffer on every device;

@@ -776,7 +776,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   // ones to start and to finish (behind A: +0.1 ms, behind C: +0.4 ms); on g3 right behind its own sort for the small ones and for
   // multi-GPU shards, where the GPU is far from full and only the length of the chains counts (200 k: 4.3 → 3.9 ms).  Letting H
   // wait only for B1's ACCUMULATION kernel instead of B1's whole chain fills a ≈ 1 ms gap in the timeline and still makes the
-  // prove slower (16.35–16.48 against 16.0–16.2 ms; DESIGN.md §4 lists this and the other schedules that were measured).
+  // prove slower (16.35–16.48 against 16.0–16.2 ms; HISTORY.md §4 lists this and the other schedules that were measured).
   const int h_behind = 1; // B1
   const bool h_chain = z->H.len() > (1u << 19);
   hipStream_t gh = h_chain ? st4[h_behind] : g3;

@@ -25,7 +25,7 @@
 #include "workers.h"
 
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share
-// a queue serialise.  The prover overlaps five streams; with four queues two of them collide and a
+// a queue serialise.  The prover overlaps five streams (HISTORY.md §4); with four queues two of them collide and a
 // benchmark/1600k prove measured 28.5 ms instead of 25.5 ms.  Ask for twelve unless the user has set the knob — a key's six
 // streams, the two lanes of a cold upload (kept in the stream pool afterwards), the staging engine's lane and a table build's
 // stream are ten; with eight queues the two pooled lanes made two of a key's streams share one (stand-in of 1.0 M constraints:

@@ -101,7 +101,7 @@ int groth16_commitments(Groth16CacheManager* cm, const char* key, const void* wt
 int groth16_upload_witness_slice(Groth16CacheManager* cm, const char* key, const void* wtns, size_t wtns_len, void** d_witness, uint64_t* slice_bytes);
 int groth16_witness_ready(Groth16CacheManager* cm, const char* key);
 
-/* Distributed QAP front end for 2, 4 or 8 shards (H sharded by residue class; DESIGN.md §5, tests/dist_qap_model.py):
+/* Distributed QAP front end for 2, 4 or 8 shards (H sharded by residue class; HISTORY.md §5, tests/dist_qap_model.py):
  * instead of replicating the spmv and the inverse transform on every rank, each rank transforms 1/count of the rows and
  * two all-to-alls move the blocks.  Sequence per prove, on every rank:
  *     groth16_dist_stage1(wtns)  →  all-to-all(send, recv)  →  groth16_dist_stage2()  →  all-to-all(send, recv)

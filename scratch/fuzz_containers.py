@@ -1,7 +1,7 @@
 """mutation fuzzing of the container and JSON parsers on a host WITHOUT a GPU (every call must return an error code or a
 verdict, never crash): flips / truncations / length-field edits of the golden zkey and wtns through groth16_cache_load and
 groth16_commitments' parsers, and of proof / public / vkey JSON through groth16_verify_json.  Meant to be run against a
-library built with -fsanitize=address,undefined."""
+library built with -fsanitize=address,undefined (see HISTORY.md §6b)."""
 import base64, importlib, json, os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -38,7 +38,7 @@ Cc, metaC, _ = load("pmcC")
 if not metaA:
     sys.exit("no counter_collection.csv of pass A")
 print("# rocprofv3 --kernel-trace --pmc <counters> -- python3 scratch/pmc_child.py   (three passes: SQ + GRBM | FETCH_SIZE | WRITE_SIZE)")
-print("# benchmark/1600k, four proves from a host buffer; per family the launches of the LAST prove in dispatch order — its witness is split (DESIGN.md §4): sort2_* #0 = digit sort of the HEAD,")
+print("# benchmark/1600k, four proves from a host buffer; per family the launches of the LAST prove in dispatch order — its witness is split (HISTORY.md §4): sort2_* #0 = digit sort of the HEAD,")
 print("# #1 = of the TAIL (bench.py's roofline.scatter.traffic = #0 + #1), #2 = of the H scalars; msm_accumulate<G1> #0-2 / <G2> #0 = the head's, the next four the tail's (into the same buckets), the last G1 one H's.")
 print("# Under --pmc the kernels of a prove run serialised.")
 print("# SQ_* are sums over all XCDs / shader engines (rows per dispatch and counter: %s); *_CYCLES of SQ count quad-cycles" % sorted(set(rowsA.values())))
