@@ -40,6 +40,13 @@ bool is_tracked_device_ptr(const void* p);
 // create on `dev`, ahead of the first cache load, what that load would pay for: the pinned staging pool and n_streams pooled
 // streams with their DMA queues set up (runtime.cpp); the device the calling thread would use, or −1 when none is chosen yet
 void prewarm_device(int dev, int n_streams);
+// pipe class (0 … 3) of each of n ≤ 16 streams, measured (microbench.hip); false (and −1 everywhere) when the measurement was disturbed
+bool probe_stream_pipes(hipStream_t* st, int n, int* cls);
+// the same through a per-process cache (a stream keeps its queue): measured once — by the prewarm thread for the pool's streams
+// (stream_pipes_measure), else by the first key that asks — and looked up afterwards; stream_pipes_forget when a stream is destroyed
+void stream_pipes_measure(hipStream_t* st, int n);
+bool stream_pipe_classes(hipStream_t* st, int n, int* cls);
+void stream_pipes_forget(hipStream_t st);
 // code objects of the prove path loaded onto `dev` ahead of their first use (one empty launch per translation unit)
 void prewarm_modules(int dev);
 void module_warm_csr(hipStream_t s);

@@ -1,6 +1,9 @@
 // microbench.hip — the two machine constants SURVEY.md §8d asks the bench to MEASURE rather than assume:
 // device-to-device copy bandwidth (HBM ceiling for streaming kernels) and the issue rate of v_mad_u64_u32 (the
 // ceiling of the modular-arithmetic kernels).  Used by bench.py as denominators next to the nominal peaks.
+#include <map>
+#include <mutex>
+
 #include "common.h"
 
 using namespace isnark;
@@ -179,3 +182,136 @@ ISNARK_API eIcicleError icicle_snark_microbench(double out[2])
   (void)hipEventDestroy(e1);
   return ICICLE_SUCCESS;
 }
+
+// ---- which streams share a hardware pipe --------------------------------------------------------------------------------------------
+// The HIP runtime puts streams on hardware queues and queue k sits on pipe k mod 4 (profiles/r05_pipe_probe.txt).  A kernel with more
+// workgroups than the GPU holds keeps its pipe busy dispatching for as long as it has workgroups to place, and the packets of every
+// other queue on that pipe — kernels, event records — wait meanwhile (0.5–1 ms behind a 3 ms kernel).  The prover's transform passes and
+// accumulations are such kernels, so WHICH of a key's six streams share a pipe decides whether the witness digit sort waits behind the
+// front end (its slow mode: 2.2 instead of 0.9 ms) and whether two accumulation chains take turns.  The mapping is an accident of the
+// order in which a process's streams were first used; this probe measures it: per round one oversubscribed kernel on stream X and a
+// one-workgroup kernel + event on every other stream — those that complete late are X's pipe-mates.
+namespace {
+__global__ __launch_bounds__(256) void pipe_probe_big_kernel(unsigned long long* out, int iters)
+{
+  unsigned long long x = threadIdx.x + blockIdx.x;
+  for (int i = 0; i < iters; i++) x = x * 6364136223846793005ull + 1442695040888963407ull;
+  if (x == 42) out[0] = x;
+}
+__global__ void pipe_probe_tiny_kernel(unsigned long long* out)
+{
+  if (threadIdx.x == 999) out[1] = 1;
+}
+} // namespace
+
+namespace isnark {
+// cls[i] = pipe class of st[i] (0 … 3 in order of first appearance), or −1 everywhere when the measurement is not clean (another key
+// proving beside it, an odd runtime): the caller then keeps the streams' roles as they are.  ≈ 3.3 ms per round, at most four rounds.
+bool probe_stream_pipes(hipStream_t* st, int n, int* cls)
+{
+  for (int i = 0; i < n; i++) cls[i] = -1;
+  if (n < 2 || n > 16) return false;
+  unsigned long long* d = nullptr;
+  if (hipMalloc((void**)&d, 64) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  hipEvent_t ref = nullptr, big_end = nullptr, stop[16] = {};
+  bool ok = hipEventCreate(&ref) == hipSuccess && hipEventCreate(&big_end) == hipSuccess;
+  for (int i = 0; i < n && ok; i++) ok = hipEventCreate(&stop[i]) == hipSuccess;
+  // first use of every stream in a fixed order (a fresh stream gets its queue now), and a warm code object
+  for (int i = 0; i < n && ok; i++) {
+    hipLaunchKernelGGL(pipe_probe_tiny_kernel, dim3(1), dim3(64), 0, st[i], d);
+    ok = hipStreamSynchronize(st[i]) == hipSuccess;
+  }
+  if (ok) {
+    hipLaunchKernelGGL(pipe_probe_big_kernel, dim3(64), dim3(256), 0, st[0], d, 8);
+    ok = hipStreamSynchronize(st[0]) == hipSuccess;
+  }
+  int next_class = 0;
+  for (int x = 0; x < n && ok; x++) {
+    if (cls[x] >= 0) continue;
+    if (next_class >= 4) { // more than four classes cannot be: the measurement was disturbed
+      ok = false;
+      break;
+    }
+    cls[x] = next_class;
+    ok = hipEventRecord(ref, st[x]) == hipSuccess;
+    hipLaunchKernelGGL(pipe_probe_big_kernel, dim3(40000), dim3(256), 0, st[x], d, 3000); // ≈ 3 ms: pipe-mates wait 0.5–1 ms, the others ≈ 0.1
+    ok = ok && hipEventRecord(big_end, st[x]) == hipSuccess;
+    for (int j = 0; j < n && ok; j++) {
+      if (j == x) continue;
+      hipLaunchKernelGGL(pipe_probe_tiny_kernel, dim3(1), dim3(64), 0, st[j], d);
+      ok = hipEventRecord(stop[j], st[j]) == hipSuccess;
+    }
+    for (int j = 0; j < n && ok; j++) ok = hipStreamSynchronize(st[j]) == hipSuccess;
+    float big_ms = 0;
+    ok = ok && hipEventElapsedTime(&big_ms, ref, big_end) == hipSuccess;
+    for (int j = 0; j < n && ok; j++) {
+      if (j == x) continue;
+      float ms = 0;
+      ok = hipEventElapsedTime(&ms, ref, stop[j]) == hipSuccess;
+      const bool mate = ms > 0.35f && ms > 0.1f * big_ms;
+      if (mate) {
+        if (cls[j] >= 0 && cls[j] != next_class) ok = false; // a stream on two pipes: disturbed
+        cls[j] = next_class;
+      }
+    }
+    next_class++;
+  }
+  (void)hipGetLastError();
+  if (ref) (void)hipEventDestroy(ref);
+  if (big_end) (void)hipEventDestroy(big_end);
+  for (int i = 0; i < n; i++)
+    if (stop[i]) (void)hipEventDestroy(stop[i]);
+  (void)hipFree(d);
+  if (!ok)
+    for (int i = 0; i < n; i++) cls[i] = -1;
+  return ok;
+}
+
+// Classes once measured are kept per stream for the life of the process (a stream keeps its queue; the library's streams are pooled and
+// come back): the prewarm thread of a CacheManager measures the pool's streams in the background, a key built later looks its six
+// up — and measures them itself (≈ 10 ms) only when one of them is new.  Labels are comparable within one measurement (`epoch`) only.
+namespace {
+std::mutex g_pipe_mu;
+std::map<hipStream_t, std::pair<int, int>> g_pipe_cls; // stream → (epoch, class)
+int g_pipe_epoch = 0;
+} // namespace
+void stream_pipes_measure(hipStream_t* st, int n)
+{
+  int cls[16];
+  if (n > 16) n = 16;
+  if (!probe_stream_pipes(st, n, cls)) return;
+  std::lock_guard<std::mutex> lk(g_pipe_mu);
+  const int ep = ++g_pipe_epoch;
+  for (int i = 0; i < n; i++) g_pipe_cls[st[i]] = {ep, cls[i]};
+}
+bool stream_pipe_classes(hipStream_t* st, int n, int* cls)
+{
+  for (int attempt = 0; attempt < 2; attempt++) {
+    {
+      std::lock_guard<std::mutex> lk(g_pipe_mu);
+      int ep = -1;
+      bool all = true;
+      for (int i = 0; i < n && all; i++) {
+        const auto it = g_pipe_cls.find(st[i]);
+        if (it == g_pipe_cls.end() || (ep >= 0 && it->second.first != ep)) all = false;
+        else {
+          ep = it->second.first;
+          cls[i] = it->second.second;
+        }
+      }
+      if (all) return true;
+    }
+    if (attempt == 0) stream_pipes_measure(st, n);
+  }
+  for (int i = 0; i < n; i++) cls[i] = -1;
+  return false;
+}
+void stream_pipes_forget(hipStream_t st)
+{
+  std::lock_guard<std::mutex> lk(g_pipe_mu);
+  g_pipe_cls.erase(st);
+}
+} // namespace isnark

@@ -101,6 +101,54 @@ int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint
 }
 } // namespace
 
+// ---- which physical stream plays which role ----------------------------------------------------------------------------------------
+// The six streams of a key sit on hardware queues, and queue k on pipe k mod 4 — in whatever order the process happened to use its
+// streams first (pooled streams, prewarm threads, the stream of a table build, other keys).  Two pairs of the six share a pipe, and a
+// kernel with more workgroups than the GPU holds delays everything else on its pipe by 0.5–1 ms while it dispatches (microbench.hip:
+// probe_stream_pipes; profiles/r05_pipe_probe.txt).  Left to chance, the witness digit sort was bimodal from one key instance to the
+// next — 1.05 or 2.3–2.8 ms inside the prove: its stream on the front end's pipe or not — and with it the start of the accumulations.
+// So the pipes are MEASURED (once per process and stream) and the roles dealt the way six consecutive queues fall: the front end shares
+// its pipe with B1 + H's stream and A's with C's — streams that idle while their mate is busy —, the sort / B2 stream and the
+// H-sort / tail-sort stream have a pipe each.  Measured over five boxes (profiles/r06_stream_roles_by_pipe.txt): the sort 1.03–1.12 ms
+// in every run, the prove −0.2 … ±0 ms; "everything apart" (the four accumulation chains on four pipes, the front end beside A) is
+// +0.1–0.25 ms and the sort ON the front end's pipe +0.5 ms (it then ends after the front end and the accumulations wait for it).
+namespace {
+void assign_stream_roles(ZKeyCache* z)
+{
+  static const bool off = getenv("ICICLE_SNARK_PIPE_ROLES") && atoi(getenv("ICICLE_SNARK_PIPE_ROLES")) == 0;
+  if (off) return;
+  hipStream_t phys[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
+  int cls[6];
+  if (!stream_pipe_classes(phys, 6, cls)) return;
+  // roles: 0 front end, 1 A, 2 B2 (+ witness sort / head chain), 3 H sort (+ tail sort of a split witness), 4 B1 + H, 5 C
+  auto cost = [&](const int* perm) {
+    auto same = [&](int a, int b) { return cls[perm[a]] == cls[perm[b]] ? 1 : 0; };
+    int c = 1000 * (same(0, 2) + same(0, 3) + same(2, 3)) + 200 * (same(2, 1) + same(2, 4) + same(2, 5) + same(3, 1) + same(3, 4) + same(3, 5)) + 100 * (1 - same(0, 4)) +
+            100 * (1 - same(1, 5));
+    for (int r = 0; r < 6; r++) c += perm[r] != r ? 1 : 0; // among equals: the fewest moves
+    return c;
+  };
+  int perm[6] = {0, 1, 2, 3, 4, 5}, best[6] = {0, 1, 2, 3, 4, 5};
+  int best_cost = cost(perm);
+  while (std::next_permutation(perm, perm + 6)) {
+    const int c = cost(perm);
+    if (c < best_cost) {
+      best_cost = c;
+      memcpy(best, perm, sizeof best);
+    }
+  }
+  z->s_qap = phys[best[0]];
+  z->s_g1 = phys[best[1]];
+  z->s_g2 = phys[best[2]];
+  z->s_g3 = phys[best[3]];
+  z->s_g4 = phys[best[4]];
+  z->s_g5 = phys[best[5]];
+  if (getenv("ICICLE_SNARK_TRACE_COLD") || getenv("ICICLE_SNARK_VERBOSE"))
+    fprintf(stderr, "[icicle-snark-hip] stream pipes %d %d %d %d %d %d -> roles (qap A B2 Hsort B1 C) take streams %d %d %d %d %d %d (cost %d)\n", cls[0], cls[1], cls[2], cls[3], cls[4], cls[5], best[0],
+            best[1], best[2], best[3], best[4], best[5], best_cost);
+}
+} // namespace
+
 // CacheManager::compute — src/cache.rs:117-241
 // ---- deferred fixed-base tables (prover_internal.h: TableBuild) --------------------------------------------------------------
 namespace {
@@ -458,6 +506,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g4));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g5));
+  assign_stream_roles(z.get());
   lap("six streams");
   // device CSR built by kernels from the raw records (prover/csr.hip); the records travel with the points below
   uint32_t* d_records = nullptr;

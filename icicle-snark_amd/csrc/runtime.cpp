@@ -1048,6 +1048,7 @@ ISNARK_API eIcicleError icicle_destroy_stream(icicleStreamHandle stream)
   }
   // the workspace blocks cached for this stream move to the device's orphan list
   ws_release_stream((hipStream_t)stream);
+  stream_pipes_forget((hipStream_t)stream);
   HIP_TRY(hipStreamDestroy((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
   return ICICLE_SUCCESS;
 }
@@ -1090,6 +1091,9 @@ void prewarm_device(int dev, int n_streams)
   for (hipStream_t st : fresh) (void)hipStreamSynchronize(st);
   (void)hipFree(d);
   (void)hipGetLastError();
+  // which of them share a hardware pipe (microbench.hip): the keys built later deal their streams' roles by it (prover/cache.cpp)
+  static const bool pipe_roles = !(getenv("ICICLE_SNARK_PIPE_ROLES") && atoi(getenv("ICICLE_SNARK_PIPE_ROLES")) == 0);
+  if (pipe_roles && fresh.size() >= 2) stream_pipes_measure(fresh.data(), (int)fresh.size());
   std::lock_guard<std::mutex> lk(g_sp_mu);
   std::vector<hipStream_t>& v = g_stream_pool[dev];
   for (hipStream_t st : fresh) {
