@@ -236,6 +236,11 @@ bool probe_stream_pipes(hipStream_t* st, int n, int* cls)
       ok = false;
       break;
     }
+    if (next_class == 3) { // three pipes are known: whatever is left sits on the fourth (no round needed)
+      for (int j = x; j < n; j++)
+        if (cls[j] < 0) cls[j] = 3;
+      break;
+    }
     cls[x] = next_class;
     ok = hipEventRecord(ref, st[x]) == hipSuccess;
     hipLaunchKernelGGL(pipe_probe_big_kernel, dim3(40000), dim3(256), 0, st[x], d, 3000); // ≈ 3 ms: pipe-mates wait 0.5–1 ms, the others ≈ 0.1
