@@ -18,14 +18,14 @@ size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M)
   if (W) *W = (uint32_t)pl->g.Wb; // classic: one folded sum per window
   return (size_t)pl->g.Wb * xs;
 }
-eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len, int ticket_slot)
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_mont, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len, int ticket_slot, const LargeSide* side)
 {
-  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_partials, prof, ticket_slot);
+  return msm_buckets_run<G1>(pl, (const G1::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_partials, prof, ticket_slot, side);
 }
 size_t msm_bucket_bytes(const SortPlan* pl, bool g2) { return (size_t)(pl->nbuckets ? pl->nbuckets : 1) * (g2 ? sizeof(G2::X) : sizeof(G1::X)); }
-eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len, bool resident)
+eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len, bool resident, const LargeSide* side)
 {
-  return msm_accumulate_stage<G1>(pl, (const G1::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_buckets, into, prof, resident);
+  return msm_accumulate_stage<G1>(pl, (const G1::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G1::X*)d_buckets, into, prof, resident, side);
 }
 eIcicleError msm_g1_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot)
 {

@@ -7,9 +7,9 @@ eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int point
 {
   return msm_buckets_run<G2>(pl, (const G2::A*)d_points, points_mont, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_partials, prof, ticket_slot);
 }
-eIcicleError msm_g2_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len, bool resident)
+eIcicleError msm_g2_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len, bool resident, const LargeSide* side)
 {
-  return msm_accumulate_stage<G2>(pl, (const G2::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_buckets, into, prof, resident);
+  return msm_accumulate_stage<G2>(pl, (const G2::A*)d_points, points_form, skip_below, pl->g.tab ? row_len : 1, s, (G2::X*)d_buckets, into, prof, resident, side);
 }
 eIcicleError msm_g2_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot)
 {

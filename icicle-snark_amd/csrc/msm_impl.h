@@ -876,10 +876,18 @@ inline void allow_big_lds(K kernel, size_t bytes)
 // `into`: the array holds the sums of an earlier segment of the same scalar vector (same geometry) and is continued;
 // otherwise every bucket is written (empty ones as the identity).
 template <class C>
-eIcicleError msm_accumulate_stage(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, bool into, MsmProfile* prof, bool resident = false)
+eIcicleError msm_accumulate_stage(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* buckets, bool into, MsmProfile* prof, bool resident = false, const LargeSide* side = nullptr)
 {
   typedef typename C::X X;
   WsScoped<X> item_partials;
+  // (side stream: everything enqueued on s so far — the bucket array's earlier users, the head's sums that `into` continues — is
+  //  ordered in front of the large-bucket kernels by `fork`; they write the large buckets only, the accumulation the others)
+  const bool on_side = side && side->stream && side->fork && side->join;
+  hipStream_t sl = on_side ? side->stream : s;
+  if (on_side) {
+    HIP_TRY(hipEventRecord(side->fork, s), ICICLE_UNKNOWN_ERROR);
+    HIP_TRY(hipStreamWaitEvent(sl, side->fork, 0), ICICLE_UNKNOWN_ERROR);
+  }
   if (prof) (void)hipEventRecord(prof->ev[1], s);
   AccumulateLauncher<C>::launch(pl, d_points, mont_pt, skip_below, stride, s, buckets, into ? 1 : 0, resident);
   ICICLE_TRY(check_launch("msm_accumulate"));
@@ -887,9 +895,13 @@ eIcicleError msm_accumulate_stage(const SortPlan* pl, const typename C::A* d_poi
   const uint32_t lb = sizeof(X) > 128 ? 128 : 256;
   const size_t lds_l = lb * sizeof(typename Lazy<C>::type::X); // 36 KiB
   HIP_TRY(item_partials.alloc(pl->item_cap, s), ICICLE_ALLOCATION_FAILED);
-  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lds_l, s, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
-  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lds_l, s, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, into ? 1 : 0, buckets);
+  hipLaunchKernelGGL((msm_accumulate_large_kernel<C>), dim3(1024), dim3(lb), lds_l, sl, d_points, pl->sorted, pl->offsets, pl->counts, pl->n_large, pl->large_items, pl->item_cap, skip_below, stride, pl->g.tab ? pl->g.IB : 0, mont_pt, item_partials.p);
+  hipLaunchKernelGGL((msm_combine_large_kernel<C>), dim3(256), dim3(lb), lds_l, sl, pl->counts, pl->n_large, pl->large_list, pl->large_first, item_partials.p, into ? 1 : 0, buckets);
   ICICLE_TRY(check_launch("msm_accumulate_large"));
+  if (on_side) { // whatever follows on s (the reduction; the arena's next user of item_partials) is behind the side stream's kernels
+    HIP_TRY(hipEventRecord(side->join, sl), ICICLE_UNKNOWN_ERROR);
+    HIP_TRY(hipStreamWaitEvent(s, side->join, 0), ICICLE_UNKNOWN_ERROR);
+  }
   return ICICLE_SUCCESS;
 }
 
@@ -949,11 +961,11 @@ eIcicleError msm_reduce_stage(const SortPlan* pl, hipStream_t s, const typename 
 
 // stages 4, 4b, 5 for one base set
 template <class C>
-eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof, int ticket_slot = 0)
+eIcicleError msm_buckets_run(const SortPlan* pl, const typename C::A* d_points, int mont_pt, uint32_t skip_below, uint32_t stride, hipStream_t s, typename C::X* d_partials, MsmProfile* prof, int ticket_slot = 0, const LargeSide* side = nullptr)
 {
   WsScoped<typename C::X> buckets;
   HIP_TRY(buckets.alloc(pl->nbuckets, s), ICICLE_ALLOCATION_FAILED);
-  ICICLE_TRY(msm_accumulate_stage<C>(pl, d_points, mont_pt, skip_below, stride, s, buckets.p, false, prof));
+  ICICLE_TRY(msm_accumulate_stage<C>(pl, d_points, mont_pt, skip_below, stride, s, buckets.p, false, prof, false, side));
   return msm_reduce_stage<C>(pl, s, buckets.p, d_partials, ticket_slot);
 }
 

@@ -123,9 +123,17 @@ eIcicleError msm_g2_build_table_sliced(const void* d_points, uint32_t n, int fro
 // table mode: h_partials = [T | S_0 … S_{nbits−1}] (msm_partials_bytes gives nbits as *W)
 void msm_g1_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_projective_t* out);
 void msm_g2_host_tail_tab(const void* h_partials, uint32_t nbits, bn254_g2_projective_t* out);
+// The large-bucket kernels of a bucket stage on a SIDE stream, beside the accumulation instead of behind it (they write disjoint
+// buckets): for uniform scalars their work lists are empty, but their 1024 + 256 workgroups still have to be dispatched one by one
+// onto a GPU the accumulations keep full — 0.3–1.8 ms in which the MSM's chain did nothing (prover.cpp).  `fork` / `join`: events of
+// the caller (disable-timing), recorded on s / on the side stream; the reduction behind the stage waits for `join`.
+struct LargeSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
 size_t msm_partials_bytes(const SortPlan* pl, bool g2, uint32_t* W, uint32_t* M);
 // `ticket_slot` < MSM_TICKET_SLOTS: every run of the bucket stages on one plan needs its own (the runs may overlap in time)
-eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0);
+eIcicleError msm_g1_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0, const LargeSide* side = nullptr);
 eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_partials, MsmProfile* prof, uint32_t row_len = 1, int ticket_slot = 0);
 // The two bucket stages separately, over a bucket array the caller owns (msm_bucket_bytes; workspace of ITS choice), so that
 // several SEGMENTS of one scalar vector — each with its own sort plan of the same geometry — can be accumulated one after the
@@ -135,8 +143,8 @@ eIcicleError msm_g2_partials(const SortPlan* pl, const void* d_points, int point
 size_t msm_bucket_bytes(const SortPlan* pl, bool g2);
 // `resident`: the accumulation kernel is launched with no more workgroups than the device holds at a time and strides over
 // the buckets — its dispatch then never sits in a hardware pipe's way (see msm_accumulate_kernel).
-eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1, bool resident = false);
-eIcicleError msm_g2_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1, bool resident = false);
+eIcicleError msm_g1_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1, bool resident = false, const LargeSide* side = nullptr);
+eIcicleError msm_g2_accumulate(const SortPlan* pl, const void* d_points, int points_form, uint32_t skip_below, hipStream_t s, void* d_buckets, bool into, MsmProfile* prof, uint32_t row_len = 1, bool resident = false, const LargeSide* side = nullptr);
 eIcicleError msm_g1_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot = 0);
 eIcicleError msm_g2_reduce(const SortPlan* pl, hipStream_t s, const void* d_buckets, void* d_partials, int ticket_slot = 0);
 // host-side tail: window sums (Σ of bpw partials) → Horner with c doublings → standard-form projective

@@ -53,6 +53,10 @@ ZKeyCache::~ZKeyCache()
       if (e) (void)hipEventDestroy(e);
     for (auto e : ev_done)
       if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_lfork)
+      if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_ljoin)
+      if (e) (void)hipEventDestroy(e);
     for (auto& p : prof) msm_profile_own_destroy(&p);
   }
 
@@ -678,6 +682,8 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_HIP(hipEventCreate(&z->ev_t_witness));
   for (auto& e : z->ev) P_HIP(hipEventCreate(&e));
   for (auto& e : z->ev_done) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : z->ev_lfork) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : z->ev_ljoin) P_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   lap("work buffers, events");
   out = std::move(z);
   if (pipeline) {

@@ -454,7 +454,19 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   hipStream_t st4[4] = {g1, z->s_g4, g2, z->s_g5}; // A, B1, B2, C: separate streams, so that one MSM's latency-bound reduction overlaps another's accumulation
   // accumulation of witness[first … first + pl.L) into the bucket array of MSM k (0 A, 1 B1, 2 B2, 3 C) on stream st: the sort
   // entries index scalars relative to `first`, so the table pointer moves with it (C's bases start at wire n_public + 1)
-  auto accumulate = [&](int k, const SortPlan& pl, uint32_t first, bool into, hipStream_t st, MsmProfile* p, bool resident = false) -> int {
+  // The large-bucket kernels of an MSM on a SIDE stream beside its accumulation (msm_plan.h: LargeSide): B2's on the front end's
+  // stream and H's on the H-sort stream — both idle by then.  ICICLE_SNARK_LARGE_SIDE: bit k = MSM k (A, B1, B2, C, H); default B2 + H.
+  static const int large_side_mask = getenv("ICICLE_SNARK_LARGE_SIDE") ? atoi(getenv("ICICLE_SNARK_LARGE_SIDE")) : 0x14;
+  auto large_side = [&](int k, hipStream_t side_stream) {
+    LargeSide ls;
+    if ((large_side_mask >> k) & 1) {
+      ls.stream = side_stream;
+      ls.fork = z->ev_lfork[k];
+      ls.join = z->ev_ljoin[k];
+    }
+    return ls;
+  };
+  auto accumulate = [&](int k, const SortPlan& pl, uint32_t first, bool into, hipStream_t st, MsmProfile* p, bool resident = false, const LargeSide* side = nullptr) -> int {
     const size_t esz = k == 2 ? 128 : 64;
     uint32_t sb = 0;
     size_t base_off = first;
@@ -466,8 +478,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       }
     }
     const void* pts = (const uint8_t*)sh4[k]->d_points + base_off * esz;
-    if (k == 2) P_ICICLE(msm_g2_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len(), resident));
-    else P_ICICLE(msm_g1_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len(), resident));
+    if (k == 2) P_ICICLE(msm_g2_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len(), resident, side));
+    else P_ICICLE(msm_g1_accumulate(&pl, pts, 2, sb, st, bk[k].p, into, p, sh4[k]->len(), resident, side));
     return 0;
   };
 
@@ -740,7 +752,9 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
       P_HIP(hipStreamWaitEvent(st, z->feed->ev[ColdFeed::SEC_A + k], 0));
     }
     if (p != psort) (void)hipEventRecord(p->ev[0], st);
-    if (int rc = accumulate(k, plan_w, wlo ? 0 : head, head != 0, st, p)) return rc;
+    // side streams idle in the MSM phase: the front end's for B2, A and B1; H-sort's (behind H's sort) for C
+    const LargeSide ls = large_side(k, k == 3 ? g3 : gq);
+    if (int rc = accumulate(k, plan_w, wlo ? 0 : head, head != 0, st, p, false, ls.stream ? &ls : nullptr)) return rc;
     P_ICICLE(k == 2 ? msm_g2_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]) : msm_g1_reduce(&plan_w, st, bk[k].p, DP + k * PARTIALS_STRIDE, slot4[k]));
     (void)hipEventRecord(p->ev[3], st);
     p->valid = true;
@@ -786,7 +800,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     if (int rc = z->feed->wait(ColdFeed::SEC_H)) return fail(rc, "%s", z->feed->err.c_str());
     P_HIP(hipStreamWaitEvent(gh, z->feed->ev[ColdFeed::SEC_H], 0));
   }
-  P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len()));
+  {
+    const LargeSide ls = large_side(4, g3);
+    P_ICICLE(msm_g1_partials(&plan_h, z->H.d_points, 2, 0, gh, DP + 4 * PARTIALS_STRIDE, prof[4], z->H.len(), 0, ls.stream && gh != g3 ? &ls : nullptr));
+  }
   (void)hipEventRecord(prof[4]->ev[3], gh);
   prof[4]->valid = true;
   mark("h");

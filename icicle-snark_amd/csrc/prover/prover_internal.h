@@ -148,6 +148,7 @@ struct ZKeyCache {
   hipEvent_t ev_witness = nullptr, ev_sort = nullptr, ev_sort_h = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // head / tail of a witness on its way in (prover.cpp): head resident (pinned source), the head's four accumulations done;
   // with timing: end of the head's chain, end of the upload
+  hipEvent_t ev_lfork[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, ev_ljoin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // large-bucket kernels on a side stream (msm_plan.h: LargeSide)
   hipEvent_t ev_head_in = nullptr, ev_head_done = nullptr, ev_t_head_start = nullptr, ev_t_head_end = nullptr, ev_t_witness = nullptr;
   int head_units = -1; // upload chunks of the witness that are sorted and accumulated while the rest is still on its way (follows the measured upload, prover.cpp); −1: not chosen yet
   uint64_t device_bytes = 0;
