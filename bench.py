@@ -299,6 +299,19 @@ def pmc_traffic(workload, timeout=600):
     return pmc_summary(fetch, write, sq)
 
 
+def cpu_throttle():
+    """(periods, throttled periods, throttled µs) of this container's CPU quota so far (cgroup v2 cpu.stat; v1 as a fallback) — the boxes
+    of this pool share a 16-CPU quota between the jobs of a pod, and a throttled period stops every host thread of the prover for up to
+    100 ms: round 5's unexplained outliers (profiles/r06_cold_path_outliers.txt)"""
+    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            kv = dict(line.split() for line in open(f).read().splitlines() if len(line.split()) == 2)
+            return int(kv.get("nr_periods", 0)), int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", kv.get("throttled_time", 0)))
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def two_in_flight_ms(K, cm, key, zkey, wtns, n=8):
     """ms per prove (wall / proves) with one thread, two threads on one key, two threads on two managers (host witness in, JSON out)"""
     import threading
@@ -892,6 +905,7 @@ def main():
     # single GPU: the cache key groth16_prove derives from the zkey path (src/lib.rs:44), so that the timed calls find it
     key = f"{zkey_path}_HIP" if world == 1 else f"bench{N}"
     cold = {}
+    thr_start = cpu_throttle()
     if world == 1:
         # ---- cold path (the reference's "without cache" figure): zkey FILE → proof.json with NOTHING cached —
         # container parse, 0.8 GB of sections over PCIe WHILE the first proof (classic bucket layout) is computed behind the stages of
@@ -1070,11 +1084,13 @@ def main():
     for _ in range(max(1, args.warmup)):
         step()
     sync(); barrier()
+    thr_t0 = cpu_throttle()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step(timed=True)
     sync(); barrier()
     dt = exch.max(time.perf_counter() - t0)
+    thr_t1 = cpu_throttle()
     ms_per_step = dt * 1e3 / args.steps
     if world == 1:
         proof, public = open(proof_path).read(), open(public_path).read()
@@ -1205,6 +1221,11 @@ def main():
                        # cold path, reported separately: zkey bytes in host memory → device-resident cache
                        "cold_cache_build_ms": cold_ms, "cache_device_mb": info.device_bytes / 1e6,
                        "prove_ms_two_in_flight": two_in_flight,
+                       # the container's CPU quota (shared by the jobs of a pod on this pool): periods in which it was exhausted stop every
+                       # host thread of the prover — upload workers, tails, the table build — for up to 100 ms
+                       "host_cpu_quota": (None if not (thr_start and thr_t0 and thr_t1) else
+                                          {"throttled_periods_in_timed_steps": thr_t1[1] - thr_t0[1], "throttled_ms_in_timed_steps": round((thr_t1[2] - thr_t0[2]) / 1e3, 1),
+                                           "throttled_periods_before": thr_t0[1] - thr_start[1], "throttled_ms_before": round((thr_t0[2] - thr_start[2]) / 1e3, 1)}),
                        "cold_prove_ms_files": cold.get("cold_prove_ms_files"), "cold_path": cold or None,
                        "b_msm_bases": info.b_bases, "n_vars": info.n_vars,
                        "prove_ms_bit_heavy_witness_standin": skew_ms,

@@ -32,6 +32,7 @@
 // 4·L·W read thanks to the implicit key) + the L·W·P gather of step 4.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string.h>
 #include <vector>
@@ -720,6 +721,9 @@ eIcicleError build_table_sliced_run(const void* d_points, uint32_t n, int from_f
   }
   if (slice > n) slice = n;
   const uint64_t ms = (uint64_t)slice * g.W;
+  static const bool trace_tb = getenv("ICICLE_SNARK_TRACE_TABLES") != nullptr;
+  const auto tb0 = std::chrono::steady_clock::now();
+  auto tb_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
   P* rows = nullptr;
   A* aff = nullptr;
   typename F::T* scratch = nullptr;
@@ -735,6 +739,7 @@ eIcicleError build_table_sliced_run(const void* d_points, uint32_t n, int from_f
     cleanup(true);
     return ICICLE_ALLOCATION_FAILED;
   }
+  const double t_alloc = tb_ms();
   const int chunk = 32;
   // up to DEPTH slices enqueued ahead of the one that runs (the temporaries are reused in stream order): the stream does not run
   // dry when this thread is descheduled — with one slice in flight and one queued (rounds 4–5) a host whose CPU quota was taken by
@@ -770,8 +775,11 @@ eIcicleError build_table_sliced_run(const void* d_points, uint32_t n, int from_f
     }
     if (ev[k % DEPTH]) (void)hipEventRecord(ev[k % DEPTH], s);
   }
+  const double t_enq = tb_ms();
   const hipError_t he = hipStreamSynchronize(s);
+  const double t_sync = tb_ms();
   cleanup(he != hipSuccess);
+  if (trace_tb) fprintf(stderr, "[tables] %s n=%u: table+temps hipMalloc %.1f ms, enqueue %.1f, wait %.1f, hipFree %.1f\n", sizeof(A) > 64 ? "G2" : "G1", n, t_alloc, t_enq - t_alloc, t_sync - t_enq, tb_ms() - t_sync);
   if (he != hipSuccess) return ICICLE_SYNCHRONIZATION_FAILED;
   *d_table = table;
   return ICICLE_SUCCESS;

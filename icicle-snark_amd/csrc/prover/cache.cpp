@@ -166,7 +166,9 @@ void table_build_thread(ZKeyCache* z)
   const int grace_ms = getenv("ICICLE_SNARK_TABLE_GRACE_MS") ? atoi(getenv("ICICLE_SNARK_TABLE_GRACE_MS")) : TABLE_BUILD_GRACE_MS;
   for (int waited = 0; !tb.witness_only && waited < grace_ms && !tb.go.load(std::memory_order_acquire) && !tb.cancel.load(); waited++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   const auto t0 = std::chrono::steady_clock::now();
+  static const bool trace_tb = getenv("ICICLE_SNARK_TRACE_TABLES") != nullptr;
   bool ok = hipSetDevice(z->device_id) == hipSuccess;
+  if (trace_tb) fprintf(stderr, "[tables] thread: device set at %.1f ms\n", ms_since(t0));
   // The key's first prove (classic layout) has counted the non-zero digits of its witness: a witness of 0 / 1 wires and small values
   // wants narrower digits than the dense default (witness_digit_target; HISTORY.md §9-2a) — build the four witness tables with that width
   // at once instead of building the dense ones and rebuilding them INSIDE a later prove (0.1–0.3 s).  The classic count (16-bit digits)
@@ -208,6 +210,7 @@ void table_build_thread(ZKeyCache* z)
       ok = false;
     }
   }
+  if (trace_tb) fprintf(stderr, "[tables] thread: stream created at %.1f ms\n", ms_since(t0));
   struct Job { const Shard* sh; bool g2; const MsmGeom* g; };
   // H first: the longest of the five builds' G1 arrays; B2 (the G2 array, 60 % of the G1 four together) last
   const Job jobs[5] = {{&z->A, false, &tb.gw}, {&z->B1, false, &tb.gw}, {&z->B2, true, &tb.gw}, {&z->C, false, &tb.gw}, {&z->H, false, &tb.gh}};
@@ -239,7 +242,9 @@ void table_build_thread(ZKeyCache* z)
     tb.extra_bytes.store(0, std::memory_order_release);
     ok = true;
   }
+  if (trace_tb) fprintf(stderr, "[tables] thread: arrays built at %.1f ms\n", ms_since(t0));
   if (s) (void)hipStreamDestroy(s);
+  if (trace_tb) fprintf(stderr, "[tables] thread: stream destroyed at %.1f ms\n", ms_since(t0));
   if (!ok)
     for (void*& t : tb.fresh) {
       if (t) (void)hipFree(t);
