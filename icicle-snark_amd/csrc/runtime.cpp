@@ -267,7 +267,8 @@ hipError_t staged_copy(int device_id, const CopyJob* jobs, size_t njobs, bool to
         if (e == hipSuccess) {
           const uint8_t* src = (const uint8_t*)chunks[i].src;
           bool done = false;
-          if (file_fd >= 0 && src >= file_base && src + chunks[i].n <= file_base + file_len) {
+          static const bool use_pread = !(getenv("ICICLE_SNARK_FILE_PREAD") && atoi(getenv("ICICLE_SNARK_FILE_PREAD")) == 0);
+          if (use_pread && file_fd >= 0 && src >= file_base && src + chunks[i].n <= file_base + file_len) {
             size_t got = 0;
             while (got < chunks[i].n) {
               const ssize_t r = pread(file_fd, buf[k] + got, chunks[i].n - got, (off_t)(src - file_base + got));
