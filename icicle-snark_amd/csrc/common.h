@@ -45,7 +45,7 @@ bool probe_stream_pipes(hipStream_t* st, int n, int* cls);
 // the same through a per-process cache (a stream keeps its queue): measured once — by the prewarm thread for the pool's streams
 // (stream_pipes_measure), else by the first key that asks — and looked up afterwards; stream_pipes_forget when a stream is destroyed
 void stream_pipes_measure(hipStream_t* st, int n);
-bool stream_pipe_classes(hipStream_t* st, int n, int* cls);
+bool stream_pipe_classes(hipStream_t* st, int n, int* cls, bool allow_measure = true); // (false: only what has been measured already)
 void stream_pipes_forget(hipStream_t st);
 // code objects of the prove path loaded onto `dev` ahead of their first use (one empty launch per translation unit)
 void prewarm_modules(int dev);

@@ -305,9 +305,9 @@ void stream_pipes_measure(hipStream_t* st, int n)
   const int ep = ++g_pipe_epoch;
   for (int i = 0; i < n; i++) g_pipe_cls[st[i]] = {ep, cls[i]};
 }
-bool stream_pipe_classes(hipStream_t* st, int n, int* cls)
+bool stream_pipe_classes(hipStream_t* st, int n, int* cls, bool allow_measure)
 {
-  for (int attempt = 0; attempt < 2; attempt++) {
+  for (int attempt = 0; attempt < (allow_measure ? 2 : 1); attempt++) {
     {
       std::lock_guard<std::mutex> lk(g_pipe_mu);
       int ep = -1;

@@ -117,13 +117,16 @@ int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint
 // in every run, the prove −0.2 … ±0 ms; "everything apart" (the four accumulation chains on four pipes, the front end beside A) is
 // +0.1–0.25 ms and the sort ON the front end's pipe +0.5 ms (it then ends after the front end and the accumulations wait for it).
 namespace {
-void assign_stream_roles(ZKeyCache* z)
+void assign_stream_roles(ZKeyCache* z, bool allow_measure)
 {
   static const bool off = getenv("ICICLE_SNARK_PIPE_ROLES") && atoi(getenv("ICICLE_SNARK_PIPE_ROLES")) == 0;
   if (off) return;
   hipStream_t phys[6] = {z->s_qap, z->s_g1, z->s_g2, z->s_g3, z->s_g4, z->s_g5};
   int cls[6];
-  if (!stream_pipe_classes(phys, 6, cls)) return;
+  // (the shards of a device group do not measure: with all of them on one device — the aliased test groups — 48 streams share 12
+  //  queues and the classes mean nothing, and on G devices G probes would sit in the group's load; a shard whose streams the prewarm
+  //  thread has measured — rank-per-GPU processes, the group's first device — still gets its roles)
+  if (!stream_pipe_classes(phys, 6, cls, allow_measure)) return;
   // roles: 0 front end, 1 A, 2 B2 (+ witness sort / head chain), 3 H sort (+ tail sort of a split witness), 4 B1 + H, 5 C
   auto cost = [&](const int* perm) {
     auto same = [&](int a, int b) { return cls[perm[a]] == cls[perm[b]] ? 1 : 0; };
@@ -515,7 +518,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g3));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g4));
   P_ICICLE(icicle_create_stream((icicleStreamHandle*)&z->s_g5));
-  assign_stream_roles(z.get());
+  assign_stream_roles(z.get(), /*allow_measure=*/count <= 1);
   lap("six streams");
   // device CSR built by kernels from the raw records (prover/csr.hip); the records travel with the points below
   uint32_t* d_records = nullptr;
