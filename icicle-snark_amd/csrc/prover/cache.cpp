@@ -105,6 +105,26 @@ int alloc_shard(Shard& sh, const Section* sec, size_t elem, uint32_t total, uint
 }
 } // namespace
 
+// ---- digit width of a key's witness tables (A, B1, B2, C) for DENSE scalars --------------------------------------------------------
+// msm_geometry's table rule takes the widest digit the sort entry holds (c = 20 from 2^19 wires on): fewest additions.  For the four
+// witness MSMs that is not the fastest below ≈ 28 entries per bucket: their bucket sets are reduced four times over (the G2 one
+// alone is a millisecond of latency-bound work) while the accumulations they save are throughput-bound — measured (round 6,
+// profiles/r06_witness_digit_width.txt): 800 k constraints c = 19 instead of 20: 8.35 → 8.19 ms, 400 k c = 18 instead of 19: 4.72 → 4.39 ms;
+// 1600 k (40 entries per bucket at c = 20) and 200 k (46 at c = 17) stay; below c = 17 the bucket count no longer fills the GPU (one
+// thread per bucket: 100 k with c = 16 is 0.35 ms slower).  H keeps the widest digit (narrower measured slower at 400 k and 800 k).
+MsmGeom witness_table_geometry(uint32_t len)
+{
+  MsmGeom g = msm_geometry(len, 0, 1);
+  if (!g.tab) return g;
+  int c = g.c;
+  while (c > 17 && (((uint64_t)len * (uint64_t)(254 / c + 1)) >> (c - 1)) < 28) c--;
+  if (c != g.c) {
+    const MsmGeom h = msm_geometry(len, 0, c);
+    if (h.tab && h.c == c) return h;
+  }
+  return g;
+}
+
 // ---- which physical stream plays which role ----------------------------------------------------------------------------------------
 // The six streams of a key sit on hardware queues, and queue k on pipe k mod 4 — in whatever order the process happened to use its
 // streams first (pooled streams, prewarm threads, the stream of a table build, other keys).  Two pairs of the six share a pipe, and a
@@ -183,7 +203,7 @@ void table_build_thread(ZKeyCache* z)
     int lg = 0;
     while (((uint64_t)1 << lg) * 32 < z->witness_entries) lg++;
     int c_t = lg + 1 < 13 ? 13 : lg + 1;
-    if (c_t <= tb.gw.c - 2) {
+    if (c_t < tb.gw.c) { // (one bit is worth taking since the dense width itself follows the load: witness_table_geometry)
       const MsmGeom g = msm_geometry(z->A.len(), 0, c_t);
       // a narrower digit = more rows per table than build_cache sized (`pending_bytes`, the budget's admission, the device's memory):
       // taken only when the extra bytes fit what the cache budget has left (narrow_room) and the device has them free beside the
@@ -308,7 +328,7 @@ void start_witness_rebuild(ZKeyCache* z, int c_new)
   TableBuild& tb = z->tb;
   if (!z->geom_w.tab || c_new == z->geom_w.c || tb.state.load(std::memory_order_acquire) != 0) return;
   if (tb.th.joinable()) tb.th.join();
-  const MsmGeom g = c_new == z->geom_w_default_c ? msm_geometry(z->A.len(), 0, 1) : msm_geometry(z->A.len(), 0, c_new);
+  const MsmGeom g = c_new == z->geom_w_default_c ? witness_table_geometry(z->A.len()) : msm_geometry(z->A.len(), 0, c_new);
   if (!g.tab || (c_new != z->geom_w_default_c && g.c != c_new)) return; // the entry encoding does not fit this width: keep what there is
   // memory: the four new tables beside the old ones + a slice's temporaries; when the device cannot hold that the key keeps its width
   size_t free_b = 0, total_b = 0;
@@ -588,7 +608,7 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
   // second of table build (tests/test_gpu_fullsize.py::test_prove_at_domain_2p23_…): such keys stay classic
   // (ICICLE_SNARK_TABLES=2 builds the tables all the same).
   if (tables_env < 2 && (z->A.len() > (1u << 22) || z->H.len() > (1u << 22))) tables = false;
-  z->geom_w = msm_geometry(z->A.len(), 0, tables ? 1 : 0);
+  z->geom_w = tables ? witness_table_geometry(z->A.len()) : msm_geometry(z->A.len(), 0, 0);
   z->geom_h = msm_geometry(z->H.len(), 0, tables ? 1 : 0);
   if (tables) {
     // the tables need W× the base memory plus the temporaries of the largest build (projective rows + inversion
@@ -761,7 +781,7 @@ int rebuild_witness_tables(ZKeyCache* z, int c_new)
   if (!z->geom_w.tab || c_new == z->geom_w.c) return 0;
   static std::mutex rebuild_mu; // the shards of a device group may share a device (and its null stream)
   std::lock_guard<std::mutex> lk(rebuild_mu);
-  const MsmGeom g = c_new == z->geom_w_default_c ? msm_geometry(z->A.len(), 0, 1) : msm_geometry(z->A.len(), 0, c_new);
+  const MsmGeom g = c_new == z->geom_w_default_c ? witness_table_geometry(z->A.len()) : msm_geometry(z->A.len(), 0, c_new);
   if (!g.tab || (c_new != z->geom_w_default_c && g.c != c_new)) return 0; // the entry encoding does not fit this width: keep what there is
   // ALL four new tables are built next to the old ones, then pointers and geometry are swapped together: a failure at any
   // point (allocation, launch) frees what was built and leaves the key exactly as it was — the old tables with the old

@@ -398,7 +398,10 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   auto follow_witness = [&](bool sync) -> int {
     if (!(z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1 && z->tb.state.load(std::memory_order_acquire) == 0)) return 0;
     const int c_t = witness_digit_target(z, z->witness_entries);
-    if (!((c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (z->geom_w.c == z->geom_w_default_c || z->proves_since_rebuild >= 8))) return 0;
+    // (from the dense width one bit narrower is taken at once — below 16 entries per bucket it pays, cache.cpp: witness_table_geometry —;
+    //  every later move needs two bits and eight proves: no flapping)
+    const bool from_default = z->geom_w.c == z->geom_w_default_c;
+    if (!(((from_default && c_t < z->geom_w.c) || c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (from_default || z->proves_since_rebuild >= 8))) return 0;
     if (sync) {
       if (int rc = rebuild_witness_tables(z, c_t)) return rc;
     } else
@@ -644,7 +647,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     {
       const uint32_t tail_len = wlen - head;
       const uint64_t hint = adapted_w ? (uint64_t)((double)z->witness_entries * tail_len / wlen) + 1 : 0;
-      P_ICICLE(msm_sort_run(z->d_witness + wlo + head, tail_len, 0, 0, 0, gs, &plan_w, head || adapted_w ? z->geom_w.c : z->geom_w.tab, 0, 1, hint));
+      P_ICICLE(msm_sort_run(z->d_witness + wlo + head, tail_len, 0, 0, 0, gs, &plan_w, z->geom_w.tab ? z->geom_w.c : 0, 0, 1, hint)); // (table mode: the KEY's digit width, whatever msm_geometry's rule says for this length)
     }
     if (plan_w.g.tab != z->geom_w.tab || plan_w.g.c != z->geom_w.c || (head && plan_w.nbuckets != plan_head.nbuckets))
       return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the witness sort");
@@ -765,7 +768,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
     P_HIP(hipStreamWaitEvent(g3, z->ev[2], 0));
     (void)hipEventRecord(prof[4]->ev[0], g3);
     // (`crowded`: H's sort runs beside the four witness accumulations of a large circuit)
-    P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab, 0, 1, 0, /*crowded=*/!early));
+    P_ICICLE(msm_sort_run(d_hscalars, z->H.len(), 0, 0, 0, g3, &plan_h, z->geom_h.tab ? z->geom_h.c : 0, 0, 1, 0, /*crowded=*/!early));
     if (plan_h.g.tab != z->geom_h.tab || plan_h.g.c != z->geom_h.c) return fail((int)ICICLE_UNKNOWN_ERROR, "window geometry of the cached tables does not match the H sort");
     (void)hipEventRecord(prof[4]->ev[4], g3);
     prof[4]->has_sort_end = true;
