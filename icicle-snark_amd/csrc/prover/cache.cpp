@@ -761,8 +761,8 @@ int build_cache(const uint8_t* data, size_t len, int device_id, int rank, int co
 // reduction is 1 M point additions per MSM whatever the witness.  Witnesses of real circuits are mostly 0/1 wires and small values:
 // a tenth to a fifth of the non-zero digits of a dense witness, so the four witness MSMs (A, B1, B2, C) spend more in reducing
 // empty-ish buckets than in filling them — the G2 reduction heads the critical chain (HISTORY.md §9-2a).  After a prove the
-// entry count of the witness digit sort is known; if it calls for a digit at least two bits narrower (target ≈ 32 entries per
-// bucket), the four tables are rebuilt from their own row 0 with that width — once, ≈ 0.1–0.3 s, like a cache build — and the
+// entry count of the witness digit sort is known; if it calls for a narrower digit (target ≈ 32 entries per bucket; one bit is
+// enough from the dense width, two bits afterwards: prover.cpp, follow_witness), the four tables are rebuilt from their own row 0 with that width — once, ≈ 0.1–0.3 s, like a cache build — and the
 // next proves sort with it and size the large-bucket threshold from the observed count.  Measured on the stand-in keys of
 // BASELINE configs 4 / 5: c = 20 → 18, prove 5.5 → 4.7 ms (1.0 M constraints) and 8.15 → 7.3 ms (1.4 M); c ≤ 16 is slower again
 // (one thread per bucket: chains of hundreds).  A later, denser witness moves the key back the same way.  H stays dense.

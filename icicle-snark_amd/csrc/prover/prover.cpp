@@ -390,7 +390,8 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   mark("domain");
   // deferred fixed-base tables (cache.cpp): complete → this prove is the first to use them; still building → classic layout
   (void)adopt_tables(z, false);
-  // the key follows its witnesses: a digit width at least two bits off the one the last witness called for → the four witness
+  // the key follows its witnesses: a digit width at least two bits off the one the last witness called for (one bit when the key still
+  // has its dense width) → the four witness
   // tables are re-built with that width, at most once every eight proves — by a worker thread BESIDE the proves of the key (round 5;
   // rounds 3–4 re-built them here, 0.1–0.3 s inside a prove), which go on with the tables they have until the new ones are complete
   // and adopt_tables above swaps them in (all four and geom_w together).  The worker is started at the END of the prove that counted
@@ -398,7 +399,7 @@ int shard_commitments(Groth16CacheManager* cm, ZKeyCache* z, const void* wtns, s
   auto follow_witness = [&](bool sync) -> int {
     if (!(z->geom_w.tab && z->witness_entries && z->proves_since_rebuild >= 1 && z->tb.state.load(std::memory_order_acquire) == 0)) return 0;
     const int c_t = witness_digit_target(z, z->witness_entries);
-    // (from the dense width one bit narrower is taken at once — below 16 entries per bucket it pays, cache.cpp: witness_table_geometry —;
+    // (from the dense width one bit narrower is taken at once — below ≈ 28 entries per bucket it pays, cache.cpp: witness_table_geometry —;
     //  every later move needs two bits and eight proves: no flapping)
     const bool from_default = z->geom_w.c == z->geom_w_default_c;
     if (!(((from_default && c_t < z->geom_w.c) || c_t <= z->geom_w.c - 2 || c_t >= z->geom_w.c + 2) && (from_default || z->proves_since_rebuild >= 8))) return 0;
